@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def problem_from_golden(g):
+    """The static problem description stored with a fixture (keys prob_*)."""
+    return {k[5:]: g[k] for k in g if k.startswith("prob_")}
+
+
+def D_tau_from_golden(g, prob):
+    D = [g["D_%d" % n] for n in prob["num_nodes"]]
+    tau = [g["tau_%d" % n] for n in prob["num_nodes"]]
+    return D, tau
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
