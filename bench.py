@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- defect-residual + FD-Jacobian evaluations per second on the 6-phase x 64-node LGR mesh.
+
+A "step" is one pass of the hot path over one batch of B synthetic decision vectors per GPU:
+one fused launch that writes the four defect residuals and every x-dependent Jacobian value of
+each vector (1 eval = the hot-path share of one objfunc + one sens call).  Inputs are
+resident in HBM when the timed region starts; outputs stay in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: the path shards by independent decision vectors (replicas of the static problem, B
+vectors per rank, no data-path collective) -> "scaling": "weak".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(prob, D, tau, X, budget_s=12.0):
+    """The oracle (scalar C port of the reference algorithm) timed on this box's host cores, 1 thread,
+    on a bounded sample of the same workload."""
+    import oracle
+    P = oracle.Problem(prob, D=D, tau=tau)
+    t0 = time.perf_counter()
+    P.eval_batch(X[:2], nthreads=1)
+    per = (time.perf_counter() - t0) / 2
+    n = int(max(4, min(len(X), budget_s / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    P.eval_batch(X[:n], nthreads=1)
+    dt = time.perf_counter() - t0
+    out = {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+           "sample": "%d evals (4 residuals + 4 COO Jacobians each, full value arrays) of the same workload, "
+                     "oracle/libgelato_oracle.so, 1 thread, %.1f s" % (n, dt),
+           "ms_per_eval": 1e3 * dt / n}
+    try:  # informational: all host cores, evals spread over OpenMP threads
+        nc = len(os.sched_getaffinity(0))
+        if nc > 1:
+            m = min(len(X), max(nc * 4, int(n * min(nc, 8) / 4)))
+            t0 = time.perf_counter()
+            P.eval_batch(X[:m], nthreads=nc)
+            dt2 = time.perf_counter() - t0
+            out["all_cores"] = {"value": m / dt2, "cores": nc, "sample": "%d evals, %.1f s" % (m, dt2)}
+    except Exception:
+        pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="decision vectors per GPU per step")
+    ap.add_argument("--workload", default="mixed-6x64", help="mixed-6x64 | dense-6x64 | 3x32 | stress-12x128 | example")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational full-COO and B=1 legs")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from gelato_amd import Engine, con_dynamics, pack_x, problem
+
+    pdict, unitdict, condition, xdict = problem.make_problem(a.workload)
+    prob = con_dynamics.problem_arrays(pdict, unitdict)
+    S = pdict["num_sections"]
+    ps = pdict["ps_params"]
+    D = [ps.D(i) for i in range(S)]
+    tau = [ps.tau(i) for i in range(S)]
+    E = Engine(prob, D=D, tau=tau, device=local)
+    B, K, W = a.batch, a.steps, a.warmup
+
+    x0 = pack_x(xdict)
+    X = problem.synthetic_batch(x0, E.M, B, seed=20260313 + rank * B)
+    dX = torch.from_numpy(X).to(dev)
+    dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    djv = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream  # the engine launches on torch's current stream
+
+    def step():
+        E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    status = E.sync(stream)
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))  # HIP events around each launch
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    T = float(tmax.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # parity spot check of what was just timed (element 0 against the oracle), never inside the timed region
+    check = None
+    if not a.no_cpu_baseline:
+        import oracle
+        P = oracle.Problem(prob, D=D, tau=tau)
+        ores, ovals = P.eval_batch(X[:1])
+        r0 = dres[0].cpu().numpy()
+        full0 = E.expand(djv[0].cpu().numpy())
+        check = {"residual_max_abs_diff": float(np.max(np.abs(r0 - ores[0]))),
+                 "jacobian_max_abs_diff": float(np.max(np.abs(full0 - ovals[0])))}
+
+    evals = world * B * K
+    abytes = E.algorithmic_bytes * B  # per launch: SURVEY.md 8(d) A_min x evals per launch
+    achieved = abytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s_B%d.json" % (a.workload, B))
+    if os.path.exists(tpath):  # PMC-derived HBM bytes per launch, written by tools/pmc_traffic.py
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "residual+Jacobian evals/sec (and ms/eval), 6-phase x 64-node LGR mesh",
+        "value": evals / T, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * T / K, "ms_per_eval": 1e3 * T / (B * K), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": a.workload, "phases": int(S), "nodes_per_phase": [int(n) for n in prob["num_nodes"]],
+                   "batch_per_gpu": B, "decision_vars": E.nvars, "residual_rows": E.nres,
+                   "jacobian_values_per_eval": E.V, "coo_nnz": E.total_nnz, "parallelism": "replicas x%d" % world,
+                   "output": "4 defect residuals + all x-dependent COO Jacobian values (compact), in HBM"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "gel::eval_kernel<true>",
+                     "kernel_ms": kern_ms, "algorithmic_bytes_per_eval": E.algorithmic_bytes,
+                     "algorithmic_bytes_per_launch": abytes,
+                     "note": "fp64 VALU-bound at this arithmetic intensity (~13 flop/B incl. libm), see DESIGN.md"},
+        "status": int(status),
+    }
+    if check:
+        out["parity_spot_check"] = check
+
+    if not a.no_extras:
+        # informational: materialise every COO value like the reference does (compact -> full expansion)
+        try:
+            Bf = min(B, 1024)
+            dfull = torch.empty((Bf, E.total_nnz), dtype=torch.float64, device=dev)
+            for _ in range(2):
+                E.expand_full_device(Bf, djv.data_ptr(), dfull.data_ptr(), stream)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5):
+                E.expand_full_device(Bf, djv.data_ptr(), dfull.data_ptr(), stream)
+            e.record()
+            torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / 5
+            out["full_coo_expand"] = {"batch": Bf, "kernel_ms": ms,
+                                      "write_GBps": Bf * E.total_nnz * 8 / (ms * 1e-3) / 1e9,
+                                      "evals_per_s_fused_plus_expand": Bf / ((kern_ms * Bf / B + ms) * 1e-3)}
+            del dfull
+        except Exception as ex:  # noqa: BLE001
+            out["full_coo_expand"] = {"error": str(ex)}
+        # informational: the B = 1 host-buffer callback path (launch-latency bound), PCIe inclusive
+        t0 = time.perf_counter()
+        vals = None
+        for _ in range(50):
+            r, vals, _ = E.eval(x0, out=vals)
+        out["b1_host_callback_ms"] = 1e3 * (time.perf_counter() - t0) / 50
+
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(prob, D, tau, X)
+        out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""ctypes binding of libgelato_amd.so (the C-ABI of include/gelato_amd.h).
+
+There is no CPU fallback anywhere in this package: if the HIP library is missing
+or no MI355X is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libgelato_amd.so")
+_LIB = None
+
+GEL_OK, GEL_NONFINITE = 0, 1
+NUM_BLOCKS = 13
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+class GelProblemDesc(C.Structure):
+    _fields_ = [
+        ("num_sections", C.c_int32),
+        ("num_nodes", _ip),
+        ("thrust", _dp), ("massflow", _dp), ("reference_area", _dp), ("nozzle_area", _dp),
+        ("engine_on", _ip), ("attitude_hold", _ip),
+        ("unit_mass", C.c_double), ("unit_position", C.c_double), ("unit_velocity", C.c_double),
+        ("unit_u", C.c_double), ("unit_t", C.c_double),
+        ("dx", C.c_double), ("barC20", C.c_double),
+        ("wind_rows", C.c_int32), ("wind_table", _dp),
+        ("ca_rows", C.c_int32), ("ca_table", _dp),
+        ("D", _dp), ("tau", _dp),
+        ("device", C.c_int32), ("flags", C.c_int32),
+    ]
+
+
+class GelDims(C.Structure):
+    _fields_ = [
+        ("S", C.c_int32), ("N", C.c_int32), ("M", C.c_int32), ("num_vars", C.c_int32),
+        ("num_rows", C.c_int32 * 4),
+        ("block_nnz", C.c_int64 * NUM_BLOCKS),
+        ("block_shape", (C.c_int64 * 2) * NUM_BLOCKS),
+        ("total_nnz", C.c_int64), ("num_var_entries", C.c_int64), ("algorithmic_bytes", C.c_int64),
+    ]
+
+
+# every symbol include/gelato_amd.h declares, with its signature
+SIGNATURES = {
+    "gel_lgr_nodes": (C.c_int, [C.c_int32, _dp]),
+    "gel_lgr_diffmat": (C.c_int, [C.c_int32, _dp]),
+    "gel_problem_create": (C.c_int, [C.POINTER(GelProblemDesc), C.POINTER(C.c_void_p)]),
+    "gel_problem_destroy": (C.c_int, [C.c_void_p]),
+    "gel_problem_dims": (C.c_int, [C.c_void_p, C.POINTER(GelDims)]),
+    "gel_problem_D": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
+    "gel_problem_tau": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
+    "gel_pattern": (C.c_int, [C.c_void_p, C.c_int32, _ip, _ip]),
+    "gel_const_values": (C.c_int, [C.c_void_p, _dp]),
+    "gel_var_index": (C.c_int, [C.c_void_p, _lp]),
+    "gel_eval_residual": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "gel_eval_jacobian": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32]),
+    "gel_eval": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int32]),
+    "gel_eval_batch": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
+    "gel_eval_batch_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gel_expand_full_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gel_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gel_jac_fd": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+    "gel_dynamics_velocity": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32,
+                                         _dp, C.c_double, _dp]),
+    "gel_dynamics_velocity_NoAir": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]),
+    "gel_dynamics_quaternion": (C.c_int, [C.c_int32, _dp, _dp, C.c_double, _dp]),
+    "gel_point_eval": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, C.c_int32, _dp]),
+    "gel_last_error": (C.c_char_p, []),
+    "gel_version": (C.c_char_p, []),
+}
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(SO_PATH):
+        os.remove(SO_PATH)
+    subprocess.check_call(["make", "-s", "-C", src_dir])
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError("building %s failed" % SO_PATH)
+    return SO_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "gelato_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C gelato_amd/csrc`).  There is no CPU fallback." % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+class GelatoAmdError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """negative -> raise; 0 / GEL_NONFINITE are returned to the caller."""
+    if rc < 0:
+        msg = lib().gel_last_error()
+        raise GelatoAmdError("gelato_amd C-ABI error %d: %s" % (rc, msg.decode() if msg else "?"))
+    return rc

@@ -1,0 +1,150 @@
+"""Defect (dynamics) equality constraints and their sparse Jacobians on the GPU.
+
+Drop-in for the reference's lib/con_dynamics.py: the same eight functions with the same
+signature ``fn(xdict, pdict, unitdict, condition)`` and the same return layouts
+
+  equality_dynamics_{mass,position,velocity,quaternion}      -> 1-D float64 ndarray
+  equality_jac_dynamics_{mass,position,velocity,quaternion}  -> {var: {"coo": [rows i4, cols i4, vals f8],
+                                                                       "shape": (r, c)}}
+
+(lib/con_dynamics.py:34-63,66-113,116-152,155-213,216-289,292-496,499-533,536-632).  pyoptsparse
+calls them one after another with the same xdict (Trajectory_Optimization.py:199-210,250-261);
+here the first call of a group of four evaluates ALL four on the device in one fused launch and the
+other three return slices of the cached result.  xdict is never mutated (the reference perturbs it
+in place and restores it, con_dynamics.py:362-370).
+
+The static problem (device-resident D matrices, tables, pattern) is created once per pdict and
+cached in ``pdict["_gelato_amd"]``.  ``fail`` is reported through ``last_status(pdict)``:
+non-finite output -> 1 (the reference hard-codes fail=False).
+"""
+import numpy as np
+
+from .engine import BLOCKS, Engine, pack_x
+
+_KEY = "_gelato_amd"
+
+
+def problem_arrays(pdict, unitdict):
+    """Flatten what the hot path reads from pdict / unitdict (Trajectory_Optimization.py:116-167)."""
+    S = pdict["num_sections"]
+    P = pdict["params"]
+    ps = pdict["ps_params"]
+    return {
+        "num_nodes": np.array([ps.nodes(i) for i in range(S)], dtype=np.int32),
+        "thrust": np.array([P[i]["thrust"] for i in range(S)], dtype=np.float64),
+        "massflow": np.array([P[i]["massflow"] for i in range(S)], dtype=np.float64),
+        "reference_area": np.array([P[i]["reference_area"] for i in range(S)], dtype=np.float64),
+        "nozzle_area": np.array([P[i]["nozzle_area"] for i in range(S)], dtype=np.float64),
+        "engine_on": np.array([1 if P[i]["engineOn"] else 0 for i in range(S)], dtype=np.int32),
+        "attitude_hold": np.array([1 if P[i]["attitude"] in ["hold", "vertical"] else 0 for i in range(S)],
+                                  dtype=np.int32),
+        "units": np.array([unitdict[k] for k in ["mass", "position", "velocity", "u", "t"]], dtype=np.float64),
+        "dx": float(pdict["dx"]),
+        "wind_table": np.asarray(pdict["wind_table"], dtype=np.float64),
+        "ca_table": np.asarray(pdict["ca_table"], dtype=np.float64),
+    }
+
+
+class _State:
+    def __init__(self, pdict, unitdict):
+        prob = problem_arrays(pdict, unitdict)
+        ps = pdict["ps_params"]
+        S = pdict["num_sections"]
+        # D and tau are inputs of the path: whatever PSparams the caller put in pdict is used as is
+        self.engine = Engine(prob, D=[ps.D(i) for i in range(S)], tau=[ps.tau(i) for i in range(S)],
+                             barC20=float(pdict.get("barC20", 0.0)), device=int(pdict.get("device", 0)))
+        self.x_res = None
+        self.res = None
+        self.x_jac = None
+        self.vals = None
+        self.status = 0
+
+    def residuals(self, xdict):
+        x = pack_x(xdict)
+        if self.x_res is None or not np.array_equal(x, self.x_res):
+            self.res, rc = self.engine.eval_residual(x)
+            self.x_res = x
+            self.status = rc
+        return self.engine.split_res(self.res)
+
+    def jacobians(self, xdict):
+        x = pack_x(xdict)
+        if self.x_jac is None or not np.array_equal(x, self.x_jac):
+            self.vals, rc = self.engine.eval_jacobian(x, out=self.vals)
+            self.x_jac = x
+            self.status = rc
+        return self.engine.jac_dicts(self.vals)
+
+
+def _state(pdict, unitdict):
+    st = pdict.get(_KEY)
+    if st is None:
+        st = _State(pdict, unitdict)
+        pdict[_KEY] = st
+    return st
+
+
+def engine_of(pdict, unitdict):
+    return _state(pdict, unitdict).engine
+
+
+def last_status(pdict):
+    st = pdict.get(_KEY)
+    return 0 if st is None else st.status
+
+
+def _copy_jac(j):
+    # values are copied so that the caller may keep them across calls, like the reference's fresh arrays
+    return {var: {"coo": [blk["coo"][0], blk["coo"][1], blk["coo"][2].copy()], "shape": blk["shape"]}
+            for var, blk in j.items()}
+
+
+def equality_dynamics_mass(xdict, pdict, unitdict, condition):
+    """Equality constraint about dynamics of mass."""
+    return _state(pdict, unitdict).residuals(xdict)["mass"].copy()
+
+
+def equality_jac_dynamics_mass(xdict, pdict, unitdict, condition):
+    """Jacobian of equality_dynamics_mass."""
+    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["mass"])
+
+
+def equality_dynamics_position(xdict, pdict, unitdict, condition):
+    """Equality constraint about dynamics of position."""
+    return _state(pdict, unitdict).residuals(xdict)["pos"].copy()
+
+
+def equality_jac_dynamics_position(xdict, pdict, unitdict, condition):
+    """Jacobian of equality_dynamics_position."""
+    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["pos"])
+
+
+def equality_dynamics_velocity(xdict, pdict, unitdict, condition):
+    """Equality constraint about dynamics of velocity."""
+    return _state(pdict, unitdict).residuals(xdict)["vel"].copy()
+
+
+def equality_jac_dynamics_velocity(xdict, pdict, unitdict, condition):
+    """Jacobian of equality_dynamics_velocity."""
+    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["vel"])
+
+
+def equality_dynamics_quaternion(xdict, pdict, unitdict, condition):
+    """Equality constraint about dynamics of quaternion."""
+    return _state(pdict, unitdict).residuals(xdict)["quat"].copy()
+
+
+def equality_jac_dynamics_quaternion(xdict, pdict, unitdict, condition):
+    """Jacobian of equality_dynamics_quaternion."""
+    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["quat"])
+
+
+RESIDUAL_FUNCTIONS = {
+    equality_dynamics_mass: "mass",
+    equality_dynamics_position: "pos",
+    equality_dynamics_velocity: "vel",
+    equality_dynamics_quaternion: "quat",
+}
+__all__ = ["equality_dynamics_mass", "equality_jac_dynamics_mass", "equality_dynamics_position",
+           "equality_jac_dynamics_position", "equality_dynamics_velocity", "equality_jac_dynamics_velocity",
+           "equality_dynamics_quaternion", "equality_jac_dynamics_quaternion", "BLOCKS"]

@@ -1,0 +1,39 @@
+// gel_device.h -- device-resident problem description shared by host and kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gel {
+
+// One LGR phase (section).  Index arithmetic follows PSparams.get_index
+// (lib/SectionParameters.py:83-103): ua = sum n_{<i}, xa = ua + i.
+struct PhaseDev {
+  int32_t n, ua, xa;
+  int32_t air;        // reference_area != 0  -> dynamics_velocity, else _NoAir (lib/con_dynamics.py:257,346)
+  int32_t air_fd;     // reference_area  > 0  -> velocity / t0 / tf sweeps are finite differences (:403,454)
+  int32_t engine_on;  // lib/con_dynamics.py:53,80
+  int32_t hold;       // attitude in ("hold","vertical")  (lib/con_dynamics.py:521,559)
+  int32_t K;          // compact Jacobian slots per node of this phase
+  int32_t s_vv, s_vq, s_vt, s_qq;  // slot bases (s_pos = 0, s_vm = 9, s_vp = 12)
+  int32_t doff;       // offset of this phase's transposed D in Dt (doubles)
+  int32_t toff;       // offset of tau
+  int64_t voff;       // offset of this phase in the compact Jacobian vector
+  double thrust, massflow, area, nozzle;
+};
+
+struct ProblemDev {
+  int32_t S, N, M, nvars;
+  int32_t Kw, Kc;
+  int32_t nchunks;           // sum over phases of ceil(n/64): wavefront work items per eval
+  const int2* chunks;        // [nchunks] {phase, first node of the chunk}
+  int64_t V;                 // compact entries per eval
+  const PhaseDev* phases;    // [S]
+  const int32_t* node_phase; // [N]
+  const double* Dt;          // per phase, transposed: Dt[doff + i*n + j] = D[j][i]
+  const double* tau;         // per phase
+  const double* tables;      // atm[44] | wind[Kw*3] | ca[Kc*2]
+  int32_t* flag;             // non-finite flag
+  double um, up, uv, uu, ut, dx, barC20;
+};
+
+}  // namespace gel

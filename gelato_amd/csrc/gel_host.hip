@@ -1,0 +1,693 @@
+// gel_host.hip -- host side of the engine: LGR generator, fixed sparsity pattern,
+// device-resident problem, and the C-ABI of include/gelato_amd.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/gelato_amd.h"
+#include "gel_device.h"
+#include "gel_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail(GEL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// LGR nodes / differentiation matrix.
+// What: lib/PSfunctions.py:149-168 (flipped LGR nodes, ending at +1) and :182-208
+// (D[k][i] = l_i'(tau_x[k+1]) on tau_x = [-1, tau]).  How: the flipped LGR points
+// are the negated roots of P_{n-1}(x) + P_n(x) (Legendre), found by Newton in
+// extended precision from the classic -cos(2 pi k/(2n-1)) guesses; D comes from
+// barycentric weights in O(n^2) instead of the reference's O(n^4) products.
+// ---------------------------------------------------------------------------
+typedef long double ld;
+
+void legendre_pair(int n, ld x, ld& Pn, ld& Pn1) {  // P_n, P_{n-1}
+  ld p0 = 1.0L, p1 = x;
+  if (n == 0) { Pn = 1.0L; Pn1 = 0.0L; return; }
+  for (int k = 2; k <= n; k++) {
+    const ld p2 = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+    p0 = p1; p1 = p2;
+  }
+  Pn = p1; Pn1 = p0;
+}
+
+int lgr_nodes_ld(int n, std::vector<ld>& tau) {
+  if (n < 2) return -1;
+  std::vector<ld> xs(n);
+  xs[0] = -1.0L;  // the Radau end point of the un-flipped set
+  const ld pi = 3.141592653589793238462643383279502884L;
+  for (int k = 1; k < n; k++) {
+    ld x = -cosl(2.0L * pi * k / (2 * n - 1));
+    for (int it = 0; it < 100; it++) {
+      ld Pn, Pn1;
+      legendre_pair(n, x, Pn, Pn1);  // P_n, P_{n-1}
+      ld Pm, Pm1;
+      legendre_pair(n - 1, x, Pm, Pm1);  // P_{n-1}, P_{n-2}
+      const ld f = Pn1 + Pn;
+      // P_k'(x) = k (x P_k - P_{k-1}) / (x^2 - 1)
+      const ld dPn = n * (x * Pn - Pn1) / (x * x - 1.0L);
+      const ld dPn1 = (n - 1) * (x * Pm - Pm1) / (x * x - 1.0L);
+      // deflate the known root at -1: g = f/(1+x)
+      const ld gval = f / (1.0L + x);
+      const ld dg = (dPn + dPn1) / (1.0L + x) - f / ((1.0L + x) * (1.0L + x));
+      const ld step = gval / dg;
+      x -= step;
+      if (fabsl(step) < 1e-19L) break;
+    }
+    xs[k] = x;
+  }
+  tau.resize(n);
+  for (int k = 0; k < n; k++) tau[k] = -xs[k];
+  std::sort(tau.begin(), tau.end());
+  tau[n - 1] = 1.0L;
+  return 0;
+}
+
+int lgr_diffmat_ld(int n, std::vector<double>& D, std::vector<double>& tau_out) {
+  std::vector<ld> tau;
+  if (lgr_nodes_ld(n, tau)) return -1;
+  std::vector<ld> t(n + 1), w(n + 1);
+  t[0] = -1.0L;
+  for (int k = 0; k < n; k++) t[k + 1] = tau[k];
+  for (int i = 0; i <= n; i++) {
+    ld p = 1.0L;
+    for (int m = 0; m <= n; m++)
+      if (m != i) p *= (t[i] - t[m]);
+    w[i] = 1.0L / p;
+  }
+  D.assign((size_t)n * (n + 1), 0.0);
+  for (int k = 0; k < n; k++) {
+    ld diag = 0.0L;
+    for (int i = 0; i <= n; i++) {
+      if (i == k + 1) continue;
+      const ld v = (w[i] / w[k + 1]) / (t[k + 1] - t[i]);
+      D[(size_t)k * (n + 1) + i] = (double)v;
+      diag -= v;
+    }
+    D[(size_t)k * (n + 1) + k + 1] = (double)diag;
+  }
+  tau_out.resize(n);
+  for (int k = 0; k < n; k++) tau_out[k] = (double)tau[k];
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+struct HostPhase {
+  int n, ua, xa;
+  int air, air_fd, engine_on, hold;
+  int K, s_vv, s_vq, s_vt, s_qq;
+  int64_t voff;
+  double thrust, massflow, area, nozzle;
+  std::vector<double> D, tau;
+};
+
+}  // namespace
+
+struct gel_problem {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  gel::ProblemDev dev{};
+  std::vector<HostPhase> ph;
+  gel_dims dims{};
+  int64_t block_off[GEL_NUM_BLOCKS + 1]{};
+  double um, up, uv, uu, ut, dx, barC20;
+  // host copies of the pattern-derived data
+  std::vector<double> cval;      // [total_nnz] constants (x-dependent entries 0)
+  std::vector<int32_t> src;      // [total_nnz] -1 or compact slot
+  std::vector<int64_t> var_idx;  // [V] compact slot -> full index
+  // device buffers (static)
+  gel::PhaseDev* d_phases = nullptr;
+  int32_t* d_node_phase = nullptr;
+  int2* d_chunks = nullptr;
+  double* d_Dt = nullptr;
+  double* d_tau = nullptr;
+  double* d_tables = nullptr;
+  double* d_cval = nullptr;
+  int32_t* d_src = nullptr;
+  int32_t* d_flag = nullptr;
+  // B = 1 / small-batch working set
+  int capB = 0;
+  double *d_x = nullptr, *d_res = nullptr, *d_jv = nullptr;
+  double *h_x = nullptr, *h_res = nullptr, *h_jv = nullptr;  // pinned
+  int32_t* h_flag = nullptr;                                  // pinned
+};
+
+namespace {
+
+// kind: 0 = constant value, 1 = x-dependent (slot = compact index within the eval)
+using Visitor = std::function<void(int block, int64_t k, int32_t row, int32_t col, int kind, double cval, int64_t slot)>;
+
+// Walks all 13 blocks in the reference's emission order (lib/con_dynamics.py:66-113,
+// 155-213,292-496,536-632).  k is the index inside the block.
+void walk_pattern(const gel_problem& P, const Visitor& vis) {
+  const int S = (int)P.ph.size();
+  int64_t k[GEL_NUM_BLOCKS] = {0};
+  auto cs = [&](const HostPhase& h, int slot, int j) { return h.voff + (int64_t)slot * h.n + j; };
+  for (int i = 0; i < S; i++) {
+    const HostPhase& h = P.ph[i];
+    const int n = h.n, ua = h.ua, xa = h.xa;
+    auto Dji = [&](int j, int c) { return h.D[(size_t)j * (n + 1) + c]; };
+    // ---- group 0: mass ----
+    if (h.engine_on) {
+      for (int j = 0; j < n; j++)
+        for (int c = 0; c <= n; c++) vis(0, k[0]++, ua + j, xa + c, 0, Dji(j, c), -1);
+      const double a = -h.massflow / P.um * P.ut / 2.0, b = h.massflow / P.um * P.ut / 2.0;
+      for (int j = 0; j < n; j++) vis(1, k[1]++, ua + j, i, 0, a, -1);
+      for (int j = 0; j < n; j++) vis(1, k[1]++, ua + j, i + 1, 0, b, -1);
+    } else {
+      for (int j = 0; j < n; j++) vis(0, k[0]++, ua + j, xa, 0, -1.0, -1);
+      for (int j = 0; j < n; j++) vis(0, k[0]++, ua + j, xa + 1 + j, 0, 1.0, -1);
+    }
+    // ---- group 1: position ----
+    for (int ki = 0; ki < 3; ki++)
+      for (int j = 0; j < n; j++)
+        for (int c = 0; c <= n; c++) vis(2, k[2]++, 3 * (ua + j) + ki, 3 * (xa + c) + ki, 0, Dji(j, c), -1);
+    for (int jj = 0; jj < 3 * n; jj++) vis(3, k[3]++, 3 * ua + jj, 3 * (xa + 1) + jj, 1, 0, cs(h, 0 + jj % 3, jj / 3));
+    for (int jj = 0; jj < 3 * n; jj++) vis(4, k[4]++, 3 * ua + jj, i, 1, 0, cs(h, 3 + jj % 3, jj / 3));
+    for (int jj = 0; jj < 3 * n; jj++) vis(4, k[4]++, 3 * ua + jj, i + 1, 1, 0, cs(h, 6 + jj % 3, jj / 3));
+    // ---- group 2: velocity ----
+    for (int j = 0; j < n; j++)
+      for (int c = 0; c < 3; c++) vis(5, k[5]++, 3 * (ua + j) + c, xa + 1 + j, 1, 0, cs(h, 9 + c, j));
+    for (int kk = 0; kk < 3; kk++)
+      for (int j = 0; j < n; j++)
+        for (int c = 0; c < 3; c++) vis(6, k[6]++, 3 * (ua + j) + c, 3 * (xa + 1 + j) + kk, 1, 0, cs(h, 12 + 3 * kk + c, j));
+    for (int ki = 0; ki < 3; ki++)
+      for (int kj = 0; kj < 3; kj++)
+        for (int j = 0; j < n; j++)
+          for (int cc = 0; cc <= n; cc++) {
+            const double dv = (ki == kj) ? Dji(j, cc) : 0.0;
+            if (cc == j + 1 && h.air_fd)
+              vis(7, k[7]++, 3 * (ua + j) + ki, 3 * (xa + cc) + kj, 1, 0, cs(h, h.s_vv + 3 * kj + ki, j));
+            else
+              vis(7, k[7]++, 3 * (ua + j) + ki, 3 * (xa + cc) + kj, 0, dv, -1);
+          }
+    for (int kk = 0; kk < 4; kk++)
+      for (int j = 0; j < n; j++)
+        for (int c = 0; c < 3; c++) vis(8, k[8]++, 3 * (ua + j) + c, 4 * (xa + 1 + j) + kk, 1, 0, cs(h, h.s_vq + 3 * kk + c, j));
+    for (int jj = 0; jj < 3 * n; jj++) vis(9, k[9]++, 3 * ua + jj, i, 1, 0, cs(h, h.s_vt + jj % 3, jj / 3));
+    for (int jj = 0; jj < 3 * n; jj++) vis(9, k[9]++, 3 * ua + jj, i + 1, 1, 0, cs(h, h.s_vt + 3 + jj % 3, jj / 3));
+    // ---- group 3: quaternion ----
+    if (h.hold) {
+      for (int jj = 0; jj < 4 * n; jj++) vis(10, k[10]++, 4 * ua + jj, 4 * xa + jj % 4, 0, -1.0, -1);
+      for (int jj = 0; jj < 4 * n; jj++) vis(10, k[10]++, 4 * ua + jj, 4 * (xa + 1) + jj, 0, 1.0, -1);
+    } else {
+      for (int j = 0; j < n; j++)
+        for (int c = 0; c < 4; c++)
+          for (int cc = 0; cc <= n; cc++)
+            for (int kk = 0; kk < 4; kk++) {
+              if (cc == j + 1)
+                vis(10, k[10]++, 4 * (ua + j) + c, 4 * (xa + cc) + kk, 1, 0, cs(h, h.s_qq + 4 * kk + c, j));
+              else
+                vis(10, k[10]++, 4 * (ua + j) + c, 4 * (xa + cc) + kk, 0, (c == kk) ? Dji(j, cc) : 0.0, -1);
+            }
+      for (int kk = 0; kk < 2; kk++)
+        for (int j = 0; j < n; j++)
+          for (int c = 0; c < 4; c++) vis(11, k[11]++, 4 * (ua + j) + c, 2 * (ua + j) + kk, 1, 0, cs(h, h.s_qq + 16 + 4 * kk + c, j));
+      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i, 1, 0, cs(h, h.s_qq + 24 + jj % 4, jj / 4));
+      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i + 1, 1, 0, cs(h, h.s_qq + 28 + jj % 4, jj / 4));
+    }
+  }
+}
+
+int64_t phase_block_nnz(const HostPhase& h, int blk) {
+  const int64_t n = h.n;
+  switch (blk) {
+    case 0: return h.engine_on ? n * (n + 1) : 2 * n;
+    case 1: return h.engine_on ? 2 * n : 0;
+    case 2: return 3 * n * (n + 1);
+    case 3: return 3 * n;
+    case 4: return 6 * n;
+    case 5: return 3 * n;
+    case 6: return 9 * n;
+    case 7: return 9 * n * (n + 1);
+    case 8: return 12 * n;
+    case 9: return 6 * n;
+    case 10: return h.hold ? 8 * n : 16 * n * (n + 1);
+    case 11: return h.hold ? 0 : 8 * n;
+    default: return h.hold ? 0 : 8 * n;
+  }
+}
+
+template <class T>
+int upload(T** d, const std::vector<T>& h) {
+  HIPCHK(hipMalloc((void**)d, std::max<size_t>(1, h.size()) * sizeof(T)));
+  if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return GEL_OK;
+}
+
+int ensure_capacity(gel_problem* p, int B) {
+  if (B <= p->capB) return GEL_OK;
+  HIPCHK(hipSetDevice(p->device));
+  if (p->d_x) { hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv); hipHostFree(p->h_x); hipHostFree(p->h_res); hipHostFree(p->h_jv); }
+  const size_t nx = (size_t)B * p->dims.num_vars, nr = (size_t)B * 11 * p->dims.N, nj = (size_t)B * std::max<int64_t>(1, p->dims.num_var_entries);
+  HIPCHK(hipMalloc((void**)&p->d_x, nx * 8));
+  HIPCHK(hipMalloc((void**)&p->d_res, nr * 8));
+  HIPCHK(hipMalloc((void**)&p->d_jv, nj * 8));
+  HIPCHK(hipHostMalloc((void**)&p->h_x, nx * 8));
+  HIPCHK(hipHostMalloc((void**)&p->h_res, nr * 8));
+  HIPCHK(hipHostMalloc((void**)&p->h_jv, nj * 8));
+  p->capB = B;
+  return GEL_OK;
+}
+
+// run B evals from host x; leaves results in the pinned staging buffers
+int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_jac) {
+  int rc = ensure_capacity(p, B);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(p->device));
+  const size_t nx = (size_t)B * p->dims.num_vars, nr = (size_t)B * 11 * p->dims.N, nj = (size_t)B * p->dims.num_var_entries;
+  std::memcpy(p->h_x, x, nx * 8);
+  HIPCHK(hipMemcpyAsync(p->d_x, p->h_x, nx * 8, hipMemcpyHostToDevice, p->stream));
+  HIPCHK(gel::launch_eval(p->dev, B, p->d_x, want_res ? p->d_res : nullptr, want_jac ? p->d_jv : nullptr, p->stream));
+  if (want_res) HIPCHK(hipMemcpyAsync(p->h_res, p->d_res, nr * 8, hipMemcpyDeviceToHost, p->stream));
+  if (want_jac && nj) HIPCHK(hipMemcpyAsync(p->h_jv, p->d_jv, nj * 8, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (*p->h_flag) {
+    HIPCHK(hipMemsetAsync(p->d_flag, 0, 4, p->stream));
+    return GEL_NONFINITE;
+  }
+  return GEL_OK;
+}
+
+void scatter_full(const gel_problem* p, const double* jv, double* vals_full, int fill) {
+  if (fill) std::memcpy(vals_full, p->cval.data(), p->cval.size() * 8);
+  const int64_t V = p->dims.num_var_entries;
+  const int64_t* idx = p->var_idx.data();
+  for (int64_t s = 0; s < V; s++) vals_full[idx[s]] = jv[s];
+}
+
+}  // namespace
+
+namespace gel {
+void fill_atmosphere_table(double* atm) {
+  // src/Air.cpp:31-45
+  const double lmb[11] = {-0.0065, 0.0, 0.001, 0.0028, 0.0, -0.0028, -0.002, 0.0, 0.0025, 0.012, 0.012};
+  const double tmb[11] = {288.15, 216.65, 216.65, 228.65, 270.65, 270.65, 214.65, 186.8673, 186.8673, 240.0, 360.0};
+  const double pb[11] = {101325.0, 22632.0, 5474.9, 868.02, 110.91, 66.939, 3.9564, 0.37338, 0.15381, 7.1042e-3, 2.5382e-3};
+  const double mb[11] = {28.9644, 28.9644, 28.9644, 28.9644, 28.9644, 28.9644, 28.9644, 28.9522, 28.89, 27.27, 26.20};
+  for (int k = 0; k < 11; k++) {
+    atm[k] = lmb[k];
+    atm[11 + k] = tmb[k];
+    atm[22 + k] = pb[k];
+    atm[33 + k] = 8314.32 / mb[k];  // Rstar / mb[k], src/Air.cpp:67
+  }
+}
+}  // namespace gel
+
+extern "C" {
+
+const char* gel_last_error(void) { return g_err.c_str(); }
+const char* gel_version(void) { return "gelato_amd 0.1 (gfx950, fp64)"; }
+
+int gel_lgr_nodes(int32_t n, double* tau) {
+  std::vector<ld> t;
+  if (!tau || lgr_nodes_ld(n, t)) return fail(GEL_ERR_ARG, "gel_lgr_nodes: n >= 2 required");
+  for (int k = 0; k < n; k++) tau[k] = (double)t[k];
+  return GEL_OK;
+}
+
+int gel_lgr_diffmat(int32_t n, double* D) {
+  std::vector<double> d, t;
+  if (!D || lgr_diffmat_ld(n, d, t)) return fail(GEL_ERR_ARG, "gel_lgr_diffmat: n >= 2 required");
+  std::memcpy(D, d.data(), d.size() * 8);
+  return GEL_OK;
+}
+
+int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
+  if (!d || !out) return fail(GEL_ERR_ARG, "null argument");
+  if (d->num_sections < 1 || !d->num_nodes || !d->thrust || !d->massflow || !d->reference_area || !d->nozzle_area ||
+      !d->engine_on || !d->attitude_hold || !d->wind_table || !d->ca_table || d->wind_rows < 2 || d->ca_rows < 2)
+    return fail(GEL_ERR_ARG, "incomplete problem description");
+  if (!(d->dx > 0.0)) return fail(GEL_ERR_ARG, "dx must be positive");
+  for (int i = 0; i < d->num_sections; i++)
+    if (d->num_nodes[i] < 2) return fail(GEL_ERR_ARG, "every phase needs >= 2 LGR nodes (nodes_LGR requires n >= 2)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(GEL_ERR_HIP, "no HIP device: the engine has no CPU fallback");
+  if (d->device < 0 || d->device >= ndev) return fail(GEL_ERR_ARG, "device ordinal out of range");
+
+  gel_problem* p = new gel_problem();
+  p->device = d->device;
+  p->um = d->unit_mass; p->up = d->unit_position; p->uv = d->unit_velocity; p->uu = d->unit_u; p->ut = d->unit_t;
+  p->dx = d->dx;
+  p->barC20 = (d->barC20 == 0.0) ? -0.484165371736e-3 : d->barC20;
+  const int S = d->num_sections;
+  int N = 0;
+  size_t offD = 0, offT = 0;
+  int64_t V = 0;
+  p->ph.resize(S);
+  for (int i = 0; i < S; i++) {
+    HostPhase& h = p->ph[i];
+    h.n = d->num_nodes[i]; h.ua = N; h.xa = N + i; N += h.n;
+    h.thrust = d->thrust[i]; h.massflow = d->massflow[i]; h.area = d->reference_area[i]; h.nozzle = d->nozzle_area[i];
+    h.air = (h.area != 0.0); h.air_fd = (h.area > 0.0);
+    h.engine_on = d->engine_on[i] != 0; h.hold = d->attitude_hold[i] != 0;
+    h.s_vv = 21; h.s_vq = h.air_fd ? 30 : 21; h.s_vt = h.s_vq + 12; h.s_qq = h.s_vt + 6;
+    h.K = h.s_qq + (h.hold ? 0 : 32);
+    h.voff = V; V += (int64_t)h.K * h.n;
+    const size_t nd = (size_t)h.n * (h.n + 1);
+    if (d->D && d->tau) {
+      h.D.assign(d->D + offD, d->D + offD + nd);
+      h.tau.assign(d->tau + offT, d->tau + offT + h.n);
+    } else {
+      int same = -1;
+      for (int j = 0; j < i; j++) if (p->ph[j].n == h.n) { same = j; break; }
+      if (same >= 0) { h.D = p->ph[same].D; h.tau = p->ph[same].tau; }
+      else lgr_diffmat_ld(h.n, h.D, h.tau);
+    }
+    offD += nd; offT += h.n;
+  }
+  const int M = N + S;
+  gel_dims& dm = p->dims;
+  dm.S = S; dm.N = N; dm.M = M; dm.num_vars = 11 * M + 2 * N + S + 1;
+  dm.num_rows[0] = N; dm.num_rows[1] = 3 * N; dm.num_rows[2] = 3 * N; dm.num_rows[3] = 4 * N;
+  const int64_t T = S + 1;
+  const int64_t rk[13] = {1, 1, 3, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4};
+  const int64_t ck[13] = {M, T, 3 * M, 3 * M, T, M, 3 * M, 3 * M, 4 * M, T, 4 * M, 2 * N, T};
+  int64_t tot = 0;
+  for (int b = 0; b < GEL_NUM_BLOCKS; b++) {
+    int64_t s = 0;
+    for (int i = 0; i < S; i++) s += phase_block_nnz(p->ph[i], b);
+    dm.block_nnz[b] = s;
+    dm.block_shape[b][0] = rk[b] * N;
+    dm.block_shape[b][1] = ck[b];
+    p->block_off[b] = tot;
+    tot += s;
+  }
+  p->block_off[GEL_NUM_BLOCKS] = tot;
+  dm.total_nnz = tot;
+  dm.num_var_entries = V;
+  dm.algorithmic_bytes = 8 * ((int64_t)dm.num_vars + 11 * (int64_t)N + V);
+
+  // pattern-derived host arrays
+  p->cval.assign((size_t)tot, 0.0);
+  p->src.assign((size_t)tot, -1);
+  p->var_idx.assign((size_t)V, -1);
+  walk_pattern(*p, [&](int blk, int64_t k, int32_t, int32_t, int kind, double cv, int64_t slot) {
+    const int64_t f = p->block_off[blk] + k;
+    if (kind == 0) p->cval[(size_t)f] = cv;
+    else { p->src[(size_t)f] = (int32_t)slot; p->var_idx[(size_t)slot] = f; }
+  });
+  for (int64_t s = 0; s < V; s++)
+    if (p->var_idx[(size_t)s] < 0) { delete p; return fail(GEL_ERR_ARG, "internal: compact slot without a COO entry"); }
+
+  // device side
+  if (hipSetDevice(p->device) != hipSuccess) { delete p; return fail(GEL_ERR_HIP, "hipSetDevice failed"); }
+  std::vector<gel::PhaseDev> dph(S);
+  std::vector<int32_t> node_phase(N);
+  std::vector<double> Dt, tau;
+  for (int i = 0; i < S; i++) {
+    const HostPhase& h = p->ph[i];
+    gel::PhaseDev& q = dph[i];
+    q.n = h.n; q.ua = h.ua; q.xa = h.xa; q.air = h.air; q.air_fd = h.air_fd; q.engine_on = h.engine_on; q.hold = h.hold;
+    q.K = h.K; q.s_vv = h.s_vv; q.s_vq = h.s_vq; q.s_vt = h.s_vt; q.s_qq = h.s_qq;
+    q.doff = (int32_t)Dt.size(); q.toff = (int32_t)tau.size(); q.voff = h.voff;
+    q.thrust = h.thrust; q.massflow = h.massflow; q.area = h.area; q.nozzle = h.nozzle;
+    for (int c = 0; c <= h.n; c++)
+      for (int j = 0; j < h.n; j++) Dt.push_back(h.D[(size_t)j * (h.n + 1) + c]);
+    tau.insert(tau.end(), h.tau.begin(), h.tau.end());
+    for (int j = 0; j < h.n; j++) node_phase[h.ua + j] = i;
+  }
+  std::vector<double> tables(44 + 3 * (size_t)d->wind_rows + 2 * (size_t)d->ca_rows);
+  gel::fill_atmosphere_table(tables.data());
+  std::memcpy(tables.data() + 44, d->wind_table, sizeof(double) * 3 * d->wind_rows);
+  std::memcpy(tables.data() + 44 + 3 * d->wind_rows, d->ca_table, sizeof(double) * 2 * d->ca_rows);
+  std::vector<int2> chunks;
+  for (int i = 0; i < S; i++)
+    for (int j0 = 0; j0 < p->ph[i].n; j0 += 64) chunks.push_back(make_int2(i, j0));
+
+  int rc = GEL_OK;
+  if ((rc = upload(&p->d_chunks, chunks)) || (rc = upload(&p->d_phases, dph)) || (rc = upload(&p->d_node_phase, node_phase)) || (rc = upload(&p->d_Dt, Dt)) ||
+      (rc = upload(&p->d_tau, tau)) || (rc = upload(&p->d_tables, tables)) || (rc = upload(&p->d_cval, p->cval)) ||
+      (rc = upload(&p->d_src, p->src))) {
+    gel_problem_destroy(p);
+    return rc;
+  }
+  if (hipMalloc((void**)&p->d_flag, 4) != hipSuccess || hipMemset(p->d_flag, 0, 4) != hipSuccess ||
+      hipHostMalloc((void**)&p->h_flag, 4) != hipSuccess || hipStreamCreate(&p->stream) != hipSuccess) {
+    gel_problem_destroy(p);
+    return fail(GEL_ERR_HIP, "device allocation failed");
+  }
+  *p->h_flag = 0;
+  gel::ProblemDev& dv = p->dev;
+  dv.S = S; dv.N = N; dv.M = M; dv.nvars = dm.num_vars; dv.Kw = d->wind_rows; dv.Kc = d->ca_rows; dv.V = V;
+  dv.phases = p->d_phases; dv.node_phase = p->d_node_phase; dv.Dt = p->d_Dt; dv.tau = p->d_tau; dv.tables = p->d_tables;
+  dv.flag = p->d_flag;
+  dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks;
+  dv.um = p->um; dv.up = p->up; dv.uv = p->uv; dv.uu = p->uu; dv.ut = p->ut; dv.dx = p->dx; dv.barC20 = p->barC20;
+  *out = p;
+  return GEL_OK;
+}
+
+int gel_problem_destroy(gel_problem* p) {
+  if (!p) return GEL_OK;
+  hipSetDevice(p->device);
+  if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
+  hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
+  hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag);
+  hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv);
+  if (p->h_x) hipHostFree(p->h_x);
+  if (p->h_res) hipHostFree(p->h_res);
+  if (p->h_jv) hipHostFree(p->h_jv);
+  if (p->h_flag) hipHostFree(p->h_flag);
+  delete p;
+  return GEL_OK;
+}
+
+int gel_problem_dims(const gel_problem* p, gel_dims* out) {
+  if (!p || !out) return fail(GEL_ERR_ARG, "null argument");
+  *out = p->dims;
+  return GEL_OK;
+}
+
+int gel_problem_D(const gel_problem* p, int32_t i, double* D) {
+  if (!p || !D || i < 0 || i >= (int)p->ph.size()) return fail(GEL_ERR_ARG, "Index out of range");
+  std::memcpy(D, p->ph[i].D.data(), p->ph[i].D.size() * 8);
+  return GEL_OK;
+}
+
+int gel_problem_tau(const gel_problem* p, int32_t i, double* tau) {
+  if (!p || !tau || i < 0 || i >= (int)p->ph.size()) return fail(GEL_ERR_ARG, "Index out of range");
+  std::memcpy(tau, p->ph[i].tau.data(), p->ph[i].tau.size() * 8);
+  return GEL_OK;
+}
+
+int gel_pattern(const gel_problem* p, int32_t block, int32_t* rows, int32_t* cols) {
+  if (!p || !rows || !cols || block < 0 || block >= GEL_NUM_BLOCKS) return fail(GEL_ERR_ARG, "bad block");
+  walk_pattern(*p, [&](int blk, int64_t k, int32_t r, int32_t c, int, double, int64_t) {
+    if (blk == block) { rows[k] = r; cols[k] = c; }
+  });
+  return GEL_OK;
+}
+
+int gel_const_values(const gel_problem* p, double* vals_full) {
+  if (!p || !vals_full) return fail(GEL_ERR_ARG, "null argument");
+  std::memcpy(vals_full, p->cval.data(), p->cval.size() * 8);
+  return GEL_OK;
+}
+
+int gel_var_index(const gel_problem* p, int64_t* idx) {
+  if (!p || !idx) return fail(GEL_ERR_ARG, "null argument");
+  std::memcpy(idx, p->var_idx.data(), p->var_idx.size() * 8);
+  return GEL_OK;
+}
+
+int gel_eval_residual(gel_problem* p, const double* x, double* res) {
+  if (!p || !x || !res) return fail(GEL_ERR_ARG, "null argument");
+  const int rc = run_host(p, 1, x, true, false);
+  if (rc < 0) return rc;
+  std::memcpy(res, p->h_res, (size_t)11 * p->dims.N * 8);
+  return rc;
+}
+
+int gel_eval_jacobian(gel_problem* p, const double* x, double* vals_full, int32_t fill_constants) {
+  return gel_eval(p, x, nullptr, vals_full, fill_constants);
+}
+
+int gel_eval(gel_problem* p, const double* x, double* res, double* vals_full, int32_t fill_constants) {
+  if (!p || !x || !vals_full) return fail(GEL_ERR_ARG, "null argument");
+  const int rc = run_host(p, 1, x, res != nullptr, true);
+  if (rc < 0) return rc;
+  if (res) std::memcpy(res, p->h_res, (size_t)11 * p->dims.N * 8);
+  scatter_full(p, p->h_jv, vals_full, fill_constants);
+  return rc;
+}
+
+int gel_eval_batch(gel_problem* p, int32_t B, const double* x, double* res, double* jvar) {
+  if (!p || !x || B < 1 || (!res && !jvar)) return fail(GEL_ERR_ARG, "bad argument");
+  const int rc = run_host(p, B, x, res != nullptr, jvar != nullptr);
+  if (rc < 0) return rc;
+  if (res) std::memcpy(res, p->h_res, (size_t)B * 11 * p->dims.N * 8);
+  if (jvar) std::memcpy(jvar, p->h_jv, (size_t)B * p->dims.num_var_entries * 8);
+  return rc;
+}
+
+int gel_eval_batch_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar, void* stream) {
+  if (!p || !d_x || B < 1 || (!d_res && !d_jvar)) return fail(GEL_ERR_ARG, "bad argument");
+  HIPCHK(gel::launch_eval(p->dev, B, d_x, d_res, d_jvar, stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
+int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream) {
+  if (!p || !d_jvar || !d_jfull || B < 1) return fail(GEL_ERR_ARG, "bad argument");
+  HIPCHK(gel::launch_expand(p->dims.total_nnz, p->dims.num_var_entries, B, p->d_cval, p->d_src, d_jvar, d_jfull,
+                            stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
+int gel_sync(gel_problem* p, void* stream) {
+  if (!p) return fail(GEL_ERR_ARG, "null argument");
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  HIPCHK(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (*p->h_flag) {
+    HIPCHK(hipMemsetAsync(p->d_flag, 0, 4, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *p->h_flag = 0;
+    return GEL_NONFINITE;
+  }
+  return GEL_OK;
+}
+
+int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) {
+  if (!p || !x || !J || group < 0 || group >= GEL_NUM_GROUPS) return fail(GEL_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(p->device));
+  const int nv = p->dims.num_vars, nres = 11 * p->dims.N, nrows = p->dims.num_rows[group];
+  const int roff = (group == 0) ? 0 : (group == 1) ? p->dims.N : (group == 2) ? 4 * p->dims.N : 7 * p->dims.N;
+  double *d_x = nullptr, *d_Xp = nullptr, *d_res = nullptr, *d_J = nullptr;
+  int rc = GEL_OK;
+  auto cleanup = [&]() { hipFree(d_x); hipFree(d_Xp); hipFree(d_res); hipFree(d_J); };
+#define HIPCHK2(expr)                                                                                 \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess) { cleanup(); return fail(GEL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } \
+  } while (0)
+  HIPCHK2(hipMalloc((void**)&d_x, (size_t)nv * 8));
+  HIPCHK2(hipMalloc((void**)&d_Xp, (size_t)(nv + 1) * nv * 8));
+  HIPCHK2(hipMalloc((void**)&d_res, (size_t)(nv + 1) * nres * 8));
+  HIPCHK2(hipMalloc((void**)&d_J, (size_t)nrows * nv * 8));
+  HIPCHK2(hipMemcpyAsync(d_x, x, (size_t)nv * 8, hipMemcpyHostToDevice, p->stream));
+  HIPCHK2(gel::launch_perturb(nv, p->dx, d_x, d_Xp, p->stream));
+  HIPCHK2(gel::launch_eval(p->dev, nv + 1, d_Xp, d_res, nullptr, p->stream));
+  HIPCHK2(gel::launch_quotient(nv, nres, roff, nrows, p->dx, d_res, d_J, p->stream));
+  HIPCHK2(hipMemcpyAsync(J, d_J, (size_t)nrows * nv * 8, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK2(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK2(hipStreamSynchronize(p->stream));
+  if (*p->h_flag) { hipMemsetAsync(p->d_flag, 0, 4, p->stream); rc = GEL_NONFINITE; }
+  cleanup();
+#undef HIPCHK2
+  return rc;
+}
+
+// --------------------------- RHS / point hooks ---------------------------
+namespace {
+struct DevBuf {
+  double* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  int put(const double* h, size_t n) {
+    HIPCHK(hipMalloc((void**)&p, std::max<size_t>(1, n) * 8));
+    if (h && n) HIPCHK(hipMemcpy(p, h, n * 8, hipMemcpyHostToDevice));
+    return GEL_OK;
+  }
+};
+int need_device() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(GEL_ERR_HIP, "no HIP device: the engine has no CPU fallback");
+  return GEL_OK;
+}
+}  // namespace
+
+int gel_dynamics_velocity(int32_t n, const double* mass_e, const double* pos_e, const double* vel_e, const double* quat,
+                          const double* t, const double* param, const double* wind, int32_t Kw, const double* ca,
+                          int32_t Kc, const double* units, double barC20, double* out) {
+  if (n < 0 || !mass_e || !pos_e || !vel_e || !quat || !t || !param || !wind || !ca || !units || !out)
+    return fail(GEL_ERR_ARG, "null argument");
+  if (n == 0) return GEL_OK;
+  int rc = need_device();
+  if (rc) return rc;
+  std::vector<double> tables(44 + 3 * (size_t)Kw + 2 * (size_t)Kc);
+  gel::fill_atmosphere_table(tables.data());
+  std::memcpy(tables.data() + 44, wind, sizeof(double) * 3 * Kw);
+  std::memcpy(tables.data() + 44 + 3 * Kw, ca, sizeof(double) * 2 * Kc);
+  DevBuf m, r, v, q, tt, tb, o;
+  if ((rc = m.put(mass_e, n)) || (rc = r.put(pos_e, 3 * (size_t)n)) || (rc = v.put(vel_e, 3 * (size_t)n)) ||
+      (rc = q.put(quat, 4 * (size_t)n)) || (rc = tt.put(t, n)) || (rc = tb.put(tables.data(), tables.size())) ||
+      (rc = o.put(nullptr, 3 * (size_t)n)))
+    return rc;
+  if (barC20 == 0.0) barC20 = -0.484165371736e-3;
+  HIPCHK(gel::launch_rhs_vel(true, n, m.p, r.p, v.p, q.p, tt.p, tb.p, Kw, Kc, param[0], param[2], param[4], units[0],
+                             units[1], units[2], barC20, o.p, nullptr));
+  HIPCHK(hipMemcpy(out, o.p, 3 * (size_t)n * 8, hipMemcpyDeviceToHost));
+  return GEL_OK;
+}
+
+int gel_dynamics_velocity_NoAir(int32_t n, const double* mass_e, const double* pos_e, const double* quat,
+                                const double* param, const double* units, double barC20, double* out) {
+  if (n < 0 || !mass_e || !pos_e || !quat || !param || !units || !out) return fail(GEL_ERR_ARG, "null argument");
+  if (n == 0) return GEL_OK;
+  int rc = need_device();
+  if (rc) return rc;
+  DevBuf m, r, q, o;
+  if ((rc = m.put(mass_e, n)) || (rc = r.put(pos_e, 3 * (size_t)n)) || (rc = q.put(quat, 4 * (size_t)n)) ||
+      (rc = o.put(nullptr, 3 * (size_t)n)))
+    return rc;
+  if (barC20 == 0.0) barC20 = -0.484165371736e-3;
+  HIPCHK(gel::launch_rhs_vel(false, n, m.p, r.p, nullptr, q.p, nullptr, nullptr, 0, 0, param[0], 0.0, 0.0, units[0],
+                             units[1], units[2], barC20, o.p, nullptr));
+  HIPCHK(hipMemcpy(out, o.p, 3 * (size_t)n * 8, hipMemcpyDeviceToHost));
+  return GEL_OK;
+}
+
+int gel_dynamics_quaternion(int32_t n, const double* quat, const double* u_e, double unit_u, double* out) {
+  if (n < 0 || !quat || !u_e || !out) return fail(GEL_ERR_ARG, "null argument");
+  if (n == 0) return GEL_OK;
+  int rc = need_device();
+  if (rc) return rc;
+  DevBuf q, u, o;
+  if ((rc = q.put(quat, 4 * (size_t)n)) || (rc = u.put(u_e, 2 * (size_t)n)) || (rc = o.put(nullptr, 4 * (size_t)n))) return rc;
+  HIPCHK(gel::launch_rhs_quat(n, q.p, u.p, unit_u, o.p, nullptr));
+  HIPCHK(hipMemcpy(out, o.p, 4 * (size_t)n * 8, hipMemcpyDeviceToHost));
+  return GEL_OK;
+}
+
+int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux, int32_t aux_rows, double* out) {
+  static const int nin[7] = {1, 3, 3, 4, 7, 1, 1}, nout[7] = {5, 3, 3, 4, 3, 3, 1};
+  if (kind < 0 || kind > 6 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
+  if (n == 0) return GEL_OK;
+  int rc = need_device();
+  if (rc) return rc;
+  double atm[44];
+  size_t naux = 0;
+  const double* hax = aux;
+  if (kind == 0) { gel::fill_atmosphere_table(atm); hax = atm; naux = 44; aux_rows = 0; }
+  else if (kind == 2) { if (!aux) return fail(GEL_ERR_ARG, "kind 2 needs aux[0] = barC20"); naux = 1; aux_rows = 0; }
+  else if (kind == 5) { if (!aux || aux_rows < 2) return fail(GEL_ERR_ARG, "kind 5 needs a wind table"); naux = 3 * (size_t)aux_rows; }
+  else if (kind == 6) { if (!aux || aux_rows < 2) return fail(GEL_ERR_ARG, "kind 6 needs a table"); naux = 2 * (size_t)aux_rows; }
+  else { aux_rows = 0; }
+  DevBuf i, a, o;
+  if ((rc = i.put(in, (size_t)n * nin[kind])) || (rc = a.put(hax, naux)) || (rc = o.put(nullptr, (size_t)n * nout[kind]))) return rc;
+  HIPCHK(gel::launch_point(kind, n, i.p, a.p, aux_rows, o.p, nullptr));
+  HIPCHK(hipMemcpy(out, o.p, (size_t)n * nout[kind] * 8, hipMemcpyDeviceToHost));
+  return GEL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,309 @@
+// gel_kernels.hip -- HIP kernels (gfx950 / CDNA4, fp64) of the LGR defect-residual
+// and forward-difference-Jacobian hot path, plus their launchers.
+//
+// Kernel inventory
+//   eval_kernel<JAC>   one thread per (decision vector b, collocation node g):
+//                      D.X rows, centre RHS, every FD sweep, residual rows and the
+//                      x-dependent Jacobian entries of that node, fused.
+//   expand_kernel      compact Jacobian entries + constant template -> full COO values
+//   perturb_kernel / quotient_kernel   column-batched generic forward difference
+//   rhs_*_kernel, point_kernel         node-batched RHS / point-function hooks
+//
+// Data layout (HBM):
+//   x     [B][nvars]  packed xdict (AoS per node, as the boundary hands it over)
+//   res   [B][11N]    mass N | pos 3N | vel 3N | quat 4N
+//   jvar  [B][V]      per phase [slot][node]: consecutive lanes (nodes) write
+//                     consecutive doubles -> every store instruction is one
+//                     contiguous 512-byte segment per wavefront.
+//   Dt    per phase, transposed (Dt[i*n + j] = D[j][i]) so lane j reads
+//         consecutive addresses while all lanes share X[i][c] (broadcast).
+#include <hip/hip_runtime.h>
+
+#include "gel_device.h"
+#include "gel_launch.h"
+#include "gel_physics.h"
+
+namespace gel {
+
+constexpr int kBlock = 256;
+
+GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds) {
+  const int ntab = kAtmDoubles + 3 * P.Kw + 2 * P.Kc;
+  for (int i = threadIdx.x; i < ntab; i += blockDim.x) lds[i] = P.tables[i];
+  __syncthreads();
+  Tables tb;
+  tb.atm = lds;
+  tb.wind = lds + kAtmDoubles;
+  tb.ca = lds + kAtmDoubles + 3 * P.Kw;
+  tb.Kw = P.Kw;
+  tb.Kc = P.Kc;
+  return tb;
+}
+
+// acc/unit_vel = ((thrust_eci + aero)/m + g)/uv        src/pybind_dynamics.cpp:66-70
+GEL_DEV void accel(const double Td[3], const double F[3], double m, const double g[3], double uv, double out[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) out[c] = ((Td[c] + F[c]) / m + g[c]) / uv;
+}
+// NoAir: (thrust_eci/m + g)/uv                          src/pybind_dynamics.cpp:85-91
+GEL_DEV void accel_noair(const double Td[3], double m, const double g[3], double uv, double out[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) out[c] = (Td[c] / m + g[c]) / uv;
+}
+
+}  // namespace gel
+#include "gel_eval_kernel.h"
+namespace gel {
+
+// ---------------------------------------------------------------------------
+// compact -> full COO values.  src[i] < 0: constant cval[i]; else jvar[b][src[i]].
+// Two doubles (16 B) per lane: wide coalesced stores; the template (cval, src)
+// is shared by all b and stays in L2 / Infinity Cache.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void expand_kernel(long long nnz, long long V, const double* __restrict__ cval,
+                                                        const int32_t* __restrict__ src,
+                                                        const double* __restrict__ jvar, double* __restrict__ full) {
+  const int b = blockIdx.y;
+  const double* jv = jvar + (size_t)b * V;
+  double* out = full + (size_t)b * nnz;
+  const bool aligned = ((((size_t)b * nnz) & 1) == 0);
+  for (long long i = 2 * ((long long)blockIdx.x * kBlock + threadIdx.x); i < nnz; i += 2LL * gridDim.x * kBlock) {
+    const int s0 = src[i];
+    const double v0 = (s0 < 0) ? cval[i] : jv[s0];
+    if (i + 1 < nnz) {
+      const int s1 = src[i + 1];
+      const double v1 = (s1 < 0) ? cval[i + 1] : jv[s1];
+      if (aligned) {
+        *reinterpret_cast<double2*>(out + i) = make_double2(v0, v1);
+      } else {
+        out[i] = v0;
+        out[i + 1] = v1;
+      }
+    } else {
+      out[i] = v0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// generic column-batched forward difference (lib/jac_fd.py:29-62)
+// ---------------------------------------------------------------------------
+// Xp[0] = x; Xp[i+1] = x with element i += dx
+__global__ void perturb_kernel(int nvars, double dx, const double* __restrict__ x, double* __restrict__ Xp) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tot = (long long)(nvars + 1) * nvars;
+  if (t >= tot) return;
+  const int row = (int)(t / nvars), col = (int)(t - (long long)row * nvars);
+  double v = x[col];
+  if (row == col + 1) v += dx;
+  Xp[t] = v;
+}
+
+// J[r][i] = (res[i+1][roff + r] - res[0][roff + r]) / dx       (tiled transpose through LDS)
+__global__ void quotient_kernel(int nvars, int nres, int roff, int nrows, double dx, const double* __restrict__ res,
+                                double* __restrict__ J) {
+  __shared__ double tile[32][33];
+  const int i0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int k = threadIdx.y; k < 32; k += blockDim.y) {  // read: r fast
+    const int i = i0 + k, r = r0 + threadIdx.x;
+    if (i < nvars && r < nrows) tile[k][threadIdx.x] = res[(size_t)(i + 1) * nres + roff + r];
+  }
+  __syncthreads();
+  for (int k = threadIdx.y; k < 32; k += blockDim.y) {  // write: i fast
+    const int r = r0 + k, i = i0 + threadIdx.x;
+    if (i < nvars && r < nrows) J[(size_t)r * nvars + i] = (tile[threadIdx.x][k] - res[roff + r]) / dx;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// node-batched RHS hooks (dynamics_c replacements, src/pybind_dynamics.cpp:30-106)
+// ---------------------------------------------------------------------------
+struct RhsArgs {
+  int n, Kw, Kc;
+  const double *mass_e, *pos_e, *vel_e, *quat, *t, *tables;
+  double thrust, area, nozzle, um, up, uv, barC20;
+  double* out;
+};
+
+__global__ void rhs_vel_air_kernel(RhsArgs A) {
+  extern __shared__ double lds[];
+  ProblemDev P{};
+  P.Kw = A.Kw; P.Kc = A.Kc; P.tables = A.tables;
+  const Tables tb = stage_tables(P, lds);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.n) return;
+  const double m = A.mass_e[i] * A.um;
+  const double r[3] = {A.pos_e[3 * i] * A.up, A.pos_e[3 * i + 1] * A.up, A.pos_e[3 * i + 2] * A.up};
+  const double v[3] = {A.vel_e[3 * i] * A.uv, A.vel_e[3 * i + 1] * A.uv, A.vel_e[3 * i + 2] * A.uv};
+  const double q[4] = {A.quat[4 * i], A.quat[4 * i + 1], A.quat[4 * i + 2], A.quat[4 * i + 3]};
+  const PosPart pp = pos_part(r, tb, A.barC20);
+  const TimePart tp = time_part(r, A.t[i], pp.wn, pp.we);
+  double F[3], dir[3], f[3];
+  aero_force(r, v, pp, tp, A.area, tb, F);
+  thrust_dir(q, dir);
+  const double T = A.thrust - A.nozzle * pp.P;
+  const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
+  accel(Td, F, m, pp.g, A.uv, f);
+  for (int c = 0; c < 3; c++) A.out[3 * i + c] = f[c];
+}
+
+__global__ void rhs_vel_noair_kernel(RhsArgs A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.n) return;
+  const double m = A.mass_e[i] * A.um;
+  const double r[3] = {A.pos_e[3 * i] * A.up, A.pos_e[3 * i + 1] * A.up, A.pos_e[3 * i + 2] * A.up};
+  const double q[4] = {A.quat[4 * i], A.quat[4 * i + 1], A.quat[4 * i + 2], A.quat[4 * i + 3]};
+  double dir[3], g[3], f[3];
+  thrust_dir(q, dir);
+  gravity_eci(r, A.barC20, g);
+  const double Td[3] = {A.thrust * dir[0], A.thrust * dir[1], A.thrust * dir[2]};
+  accel_noair(Td, m, g, A.uv, f);
+  for (int c = 0; c < 3; c++) A.out[3 * i + c] = f[c];
+}
+
+__global__ void rhs_quat_kernel(int n, const double* quat, const double* u_e, double unit_u, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double q[4] = {quat[4 * i], quat[4 * i + 1], quat[4 * i + 2], quat[4 * i + 3]};
+  double dq[4];
+  quat_rate(q, u_e[2 * i], u_e[2 * i + 1], unit_u, dq);
+  for (int c = 0; c < 4; c++) out[4 * i + c] = dq[c];
+}
+
+__global__ void point_kernel(int kind, int n, const double* in, const double* aux, int aux_rows, double* out) {
+  extern __shared__ double lds[];
+  // aux table (wind [K][3] or generic [K][2]) and the atmosphere table are staged in LDS
+  const int naux = (kind == 5) ? 3 * aux_rows : (kind == 6) ? 2 * aux_rows : (kind == 0 ? kAtmDoubles : 0);
+  for (int i = threadIdx.x; i < naux; i += blockDim.x) lds[i] = aux[i];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (kind) {
+    case 0: {
+      const double h = geopotential_altitude(in[i]);
+      const Air a = atmosphere(h, lds);
+      out[5 * i] = h; out[5 * i + 1] = a.T; out[5 * i + 2] = a.P; out[5 * i + 3] = a.rho; out[5 * i + 4] = a.a;
+    } break;
+    case 1: {
+      double lat, lon, alt;
+      geodetic_full(in[3 * i], in[3 * i + 1], in[3 * i + 2], lat, lon, alt);
+      out[3 * i] = lat * 180.0 / kPi; out[3 * i + 1] = lon * 180.0 / kPi; out[3 * i + 2] = alt;
+    } break;
+    case 2: {
+      const double r[3] = {in[3 * i], in[3 * i + 1], in[3 * i + 2]};
+      double g[3];
+      gravity_eci(r, aux[0], g);
+      out[3 * i] = g[0]; out[3 * i + 1] = g[1]; out[3 * i + 2] = g[2];
+    } break;
+    case 3: {
+      // quat_nedg2eci = what time_part rotates the wind with; recover it by rotating the NED basis
+      const double r[3] = {in[4 * i], in[4 * i + 1], in[4 * i + 2]};
+      const double t = in[4 * i + 3];
+      // rebuild the quaternion exactly as time_part does
+      double s, c, sh, ch;
+      sincos(kOmega * t, &s, &c);
+      sincos(kOmega * t / 2.0, &sh, &ch);
+      const double px = r[0] * c + r[1] * s, py = -r[0] * s + r[1] * c, pz = r[2];
+      double lat, p;
+      geodetic_lat_p(px, py, pz, lat, p);
+      const double lon = atan2(py, px);
+      double s_hl, c_hl, s_hp, c_hp;
+      sincos(lon / 2.0, &s_hl, &c_hl);
+      sincos(lat / 2.0, &s_hp, &c_hp);
+      const double rt2 = 1.41421356237309514547;
+      const double bq[4] = {c_hl * (c_hp - s_hp) / rt2, s_hl * (c_hp + s_hp) / rt2, -c_hl * (c_hp + s_hp) / rt2,
+                            s_hl * (c_hp - s_hp) / rt2};
+      const double aq[4] = {ch, 0.0, 0.0, sh};
+      double ab[4];
+      quatmult(aq, bq, ab);
+      out[4 * i] = ab[0]; out[4 * i + 1] = -ab[1]; out[4 * i + 2] = -ab[2]; out[4 * i + 3] = -ab[3];
+    } break;
+    case 4: {
+      const double* a = in + 7 * i;  // vel[3], pos[3], t
+      double s, c;
+      sincos(kOmega * a[6], &s, &c);
+      const double d0 = a[0] - (0.0 * a[5] - kOmega * a[4]);
+      const double d1 = a[1] - (kOmega * a[3] - 0.0 * a[5]);
+      const double d2 = a[2] - (0.0 * a[4] - 0.0 * a[3]);
+      out[3 * i] = d0 * c + d1 * s; out[3 * i + 1] = -d0 * s + d1 * c; out[3 * i + 2] = d2;
+    } break;
+    case 5: {
+      double wn, we;
+      wind_ned2(in[i], lds, aux_rows, wn, we);
+      out[3 * i] = wn; out[3 * i + 1] = we; out[3 * i + 2] = 0.0;
+    } break;
+    case 6: out[i] = interp_tab(in[i], lds, aux_rows, 2, 1); break;
+    default: break;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static size_t table_lds_bytes(int Kw, int Kc) { return sizeof(double) * (size_t)(kAtmDoubles + 3 * Kw + 2 * Kc); }
+
+hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  const long long waves = (long long)B * P.nchunks;
+  const unsigned grid = (unsigned)((waves * 64 + kBlock - 1) / kBlock);
+  const size_t lds = table_lds_bytes(P.Kw, P.Kc);
+  if (d_jvar)
+    hipLaunchKernelGGL(eval_kernel<true>, dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+  else
+    hipLaunchKernelGGL(eval_kernel<false>, dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+  return hipGetLastError();
+}
+
+hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, const int32_t* src,
+                         const double* d_jvar, double* d_full, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  long long pairs = (nnz + 1) / 2;
+  unsigned gx = (unsigned)((pairs + kBlock - 1) / kBlock);
+  if (gx > 4096) gx = 4096;
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
+    hipLaunchKernelGGL(expand_kernel, dim3(gx, nb), dim3(kBlock), 0, s, nnz, V, cval, src,
+                       d_jvar + (size_t)b0 * V, d_full + (size_t)b0 * nnz);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_perturb(int nvars, double dx, const double* d_x, double* d_Xp, hipStream_t s) {
+  const long long tot = (long long)(nvars + 1) * nvars;
+  hipLaunchKernelGGL(perturb_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, nvars, dx, d_x, d_Xp);
+  return hipGetLastError();
+}
+
+hipError_t launch_quotient(int nvars, int nres, int roff, int nrows, double dx, const double* d_res, double* d_J,
+                           hipStream_t s) {
+  dim3 grid((nvars + 31) / 32, (nrows + 31) / 32);
+  hipLaunchKernelGGL(quotient_kernel, grid, dim3(32, 8), 0, s, nvars, nres, roff, nrows, dx, d_res, d_J);
+  return hipGetLastError();
+}
+
+hipError_t launch_rhs_vel(bool air, int n, const double* mass_e, const double* pos_e, const double* vel_e,
+                          const double* quat, const double* t, const double* tables, int Kw, int Kc, double thrust,
+                          double area, double nozzle, double um, double up, double uv, double barC20, double* out,
+                          hipStream_t s) {
+  RhsArgs A{n, Kw, Kc, mass_e, pos_e, vel_e, quat, t, tables, thrust, area, nozzle, um, up, uv, barC20, out};
+  const unsigned grid = (n + 63) / 64;
+  if (air)
+    hipLaunchKernelGGL(rhs_vel_air_kernel, dim3(grid), dim3(64), table_lds_bytes(Kw, Kc), s, A);
+  else
+    hipLaunchKernelGGL(rhs_vel_noair_kernel, dim3(grid), dim3(64), 0, s, A);
+  return hipGetLastError();
+}
+
+hipError_t launch_rhs_quat(int n, const double* quat, const double* u_e, double unit_u, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(rhs_quat_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, quat, u_e, unit_u, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_point(int kind, int n, const double* in, const double* aux, int aux_rows, double* out,
+                        hipStream_t s) {
+  const size_t lds = sizeof(double) * (size_t)(kAtmDoubles + 3 * (aux_rows > 0 ? aux_rows : 0));
+  hipLaunchKernelGGL(point_kernel, dim3((n + 63) / 64), dim3(64), lds, s, kind, n, in, aux, aux_rows, out);
+  return hipGetLastError();
+}
+
+}  // namespace gel

@@ -1,0 +1,27 @@
+// gel_launch.h -- host-callable launchers of the kernels in gel_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gel_device.h"
+
+namespace gel {
+
+hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s);
+hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, const int32_t* src,
+                         const double* d_jvar, double* d_full, hipStream_t s);
+hipError_t launch_perturb(int nvars, double dx, const double* d_x, double* d_Xp, hipStream_t s);
+hipError_t launch_quotient(int nvars, int nres, int roff, int nrows, double dx, const double* d_res, double* d_J,
+                           hipStream_t s);
+hipError_t launch_rhs_vel(bool air, int n, const double* mass_e, const double* pos_e, const double* vel_e,
+                          const double* quat, const double* t, const double* tables, int Kw, int Kc, double thrust,
+                          double area, double nozzle, double um, double up, double uv, double barC20, double* out,
+                          hipStream_t s);
+hipError_t launch_rhs_quat(int n, const double* quat, const double* u_e, double unit_u, double* out, hipStream_t s);
+hipError_t launch_point(int kind, int n, const double* in, const double* aux, int aux_rows, double* out,
+                        hipStream_t s);
+
+// US-1976 layer table as the kernels expect it: Lmb[11] | Tmb[11] | Pb[11] | R[11]
+void fill_atmosphere_table(double* atm44);
+
+}  // namespace gel

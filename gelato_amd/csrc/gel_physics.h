@@ -1,0 +1,302 @@
+// gel_physics.h -- fp64 device functions of the 3-DoF rocket RHS for gfx950.
+//
+// What is computed follows the reference's production (C++) path; each function
+// cites the reference lines whose arithmetic it reproduces.  How it is computed
+// is device-first: values that several finite-difference sweeps share (the
+// atmosphere at a position, sin/cos of the Earth angle, the wind vector in ECI,
+// thrust direction, gravity) are produced once per node and kept in registers,
+// instead of re-running the whole chain for every perturbed variable as the
+// reference does (lib/con_dynamics.py:353-474 -> src/pybind_dynamics.cpp:42-68).
+// Re-use is exact: a shared value is bit-identical to what a full re-evaluation
+// would produce, because the perturbed variable does not enter it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gel {
+
+#define GEL_DEV __device__ __forceinline__
+
+// src/Earth.cpp:41-47
+constexpr double kMu = 3.986004418e14;
+constexpr double kOmega = 7.2921151467e-5;
+constexpr double kRa = 6378137.0;
+constexpr double kF = 1.0 / 298.257223563;
+constexpr double kRb = kRa * (1.0 - kF);
+constexpr double kE2 = (kRa * kRa - kRb * kRb) / kRa / kRa;
+constexpr double kEp2 = (kRa * kRa - kRb * kRb) / kRb / kRb;
+constexpr double kPi = 3.14159265358979323846;
+
+// LDS-resident tables: US-1976 layers (src/Air.cpp:31-45) + wind + CA.
+// atm is [4][11]: Lmb, Tmb, Pb, R (= Rstar / mb, src/Air.cpp:67).
+struct Tables {
+  const double* atm;
+  const double* wind;  // [Kw][3]
+  const double* ca;    // [Kc][2]
+  int Kw, Kc;
+};
+constexpr int kAtmDoubles = 44;
+
+// ---------------------------------------------------------------------------
+// US Standard Atmosphere 1976.  One layer search serves T, P, rho and a; the
+// reference repeats it five times per node (src/Air.cpp:100-111).
+// ---------------------------------------------------------------------------
+GEL_DEV double geopotential_altitude(double z) {  // src/Air.cpp:47-54
+  return (z < 86000.0) ? 1.0 * (6356766.0 * z) / (6356766.0 + z) : z;
+}
+
+GEL_DEV int us76_layer(double h) {  // src/Air.cpp:56-61
+  int k = 0;
+  k = (h >= 11000.0) ? 1 : k;
+  k = (h >= 20000.0) ? 2 : k;
+  k = (h >= 32000.0) ? 3 : k;
+  k = (h >= 47000.0) ? 4 : k;
+  k = (h >= 51000.0) ? 5 : k;
+  k = (h >= 71000.0) ? 6 : k;
+  k = (h >= 86000.0) ? 7 : k;
+  k = (h >= 91000.0) ? 8 : k;
+  k = (h >= 110000.0) ? 9 : k;
+  k = (h >= 120000.0) ? 10 : k;
+  return k;
+}
+
+GEL_DEV double us76_hb(int k) {
+  const double hb[11] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0, 86000.0, 91000.0, 110000.0, 120000.0};
+  double v = 0.0;
+#pragma unroll
+  for (int i = 1; i < 11; i++) v = (k == i) ? hb[i] : v;
+  return v;
+}
+
+struct Air { double T, P, rho, a; };
+
+GEL_DEV Air atmosphere(double h, const double* atm) {
+  const int k = us76_layer(h);
+  const double Hb = us76_hb(k);
+  const double Lmb = atm[k], Tmb = atm[11 + k], Pb = atm[22 + k], R = atm[33 + k];
+  const double r0 = 6356766.0, g0 = 9.80665;
+  Air o;
+  // temperature: src/Air.cpp:71-88
+  if (h <= 91000.0) {
+    o.T = Tmb + Lmb * (h - Hb);
+  } else if (h <= 110000.0) {
+    const double Tc = 263.1905, A = -76.3232, a = -19942.9;
+    o.T = Tc + A * sqrt(1.0 - (h - 91000.0) * (h - 91000.0) / a / a);
+  } else if (h <= 120000.0) {
+    o.T = Tmb + Lmb * (h - Hb);
+  } else {
+    const double Tinf = 1000.0;
+    const double xi = (h - Hb) * (r0 + Hb) / (r0 + h);
+    o.T = Tinf - (Tinf - Tmb) * exp(-0.01875e-3 * xi);
+  }
+  // pressure: src/Air.cpp:90-98
+  if (fabs(Lmb) > 1.0e-6) {
+    o.P = Pb * pow((Tmb + Lmb * (h - Hb)) / Tmb, -g0 / Lmb / R);
+  } else {
+    o.P = Pb * exp(g0 / R * (Hb - h) / Tmb);
+  }
+  o.rho = o.P / R / o.T;        // src/Air.cpp:100-105
+  o.a = sqrt(1.4 * R * o.T);    // src/Air.cpp:107-111
+  return o;
+}
+
+// ---------------------------------------------------------------------------
+// geodesy: src/Earth.cpp:49-61 (Bowring one step)
+// ---------------------------------------------------------------------------
+GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p) {
+  p = sqrt(x * x + y * y);
+  const double theta = atan2(z * kRa, p * kRb);
+  double st, ct;
+  sincos(theta, &st, &ct);
+  lat = atan2(z + kEp2 * kRb * (st * st * st), p - kE2 * kRa * (ct * ct * ct));
+}
+
+GEL_DEV double geodetic_altitude(double x, double y, double z) {
+  double lat, p;
+  geodetic_lat_p(x, y, z, lat, p);
+  double sl, cl;
+  sincos(lat, &sl, &cl);
+  const double N = kRa / sqrt(1.0 - kE2 * sl * sl);
+  return p / cl - N;
+}
+
+GEL_DEV void geodetic_full(double x, double y, double z, double& lat, double& lon, double& alt) {
+  double p;
+  geodetic_lat_p(x, y, z, lat, p);
+  lon = atan2(y, x);
+  double sl, cl;
+  sincos(lat, &sl, &cl);
+  const double N = kRa / sqrt(1.0 - kE2 * sl * sl);
+  alt = p / cl - N;
+}
+
+// ---------------------------------------------------------------------------
+// J2 gravity: src/gravity.cpp:11-57
+// ---------------------------------------------------------------------------
+GEL_DEV void gravity_eci(const double r3[3], double barC20, double g[3]) {
+  const double a = 6378137.0, mu = kMu;
+  const double b = a * (1.0 - 1.0 / 298.257223563);
+  const double x = r3[0], y = r3[1], z = r3[2];
+  double r = sqrt(x * x + y * y + z * z);
+  double irx = 0.0, iry = 0.0, irz = 0.0;
+  if (r != 0.0) { irx = x / r; iry = y / r; irz = z / r; }
+  const double s5 = 2.23606797749978969641;  // sqrt(5.0)
+  const double barP20 = s5 * (3.0 * irz * irz - 1.0) * 0.5;
+  const double barP20d = s5 * 3.0 * irz;
+  if (r < b) r = b;
+  const double mur2 = mu / (r * r);
+  const double ar = a / r;
+  const double g_ir = -mur2 * (1.0 + barC20 * ar * ar * (3.0 * barP20 + irz * barP20d));
+  const double g_iz = mur2 * ar * ar * barC20 * barP20d;
+  g[0] = g_ir * irx;
+  g[1] = g_ir * iry;
+  g[2] = g_ir * irz + g_iz;
+}
+
+// ---------------------------------------------------------------------------
+// quaternions: src/wrapper_coordinate.hpp:50-78
+// ---------------------------------------------------------------------------
+GEL_DEV void quatmult(const double q[4], const double p[4], double o[4]) {
+  o[0] = q[0] * p[0] - q[1] * p[1] - q[2] * p[2] - q[3] * p[3];
+  o[1] = q[0] * p[1] + q[1] * p[0] + q[2] * p[3] - q[3] * p[2];
+  o[2] = q[0] * p[2] - q[1] * p[3] + q[2] * p[0] + q[3] * p[1];
+  o[3] = q[0] * p[3] + q[1] * p[2] - q[2] * p[1] + q[3] * p[0];
+}
+
+// quatrot(q, v) = vec( conj(q) * (0,v) * q )
+GEL_DEV void quatrot(const double q[4], const double v[3], double out[3]) {
+  const double vq[4] = {0.0, v[0], v[1], v[2]};
+  const double qc[4] = {q[0], -q[1], -q[2], -q[3]};
+  double t1[4], r[4];
+  quatmult(vq, q, t1);
+  quatmult(qc, t1, r);
+  out[0] = r[1]; out[1] = r[2]; out[2] = r[3];
+}
+
+// thrust direction = quatrot(conj(q), (1,0,0))   (src/pybind_dynamics.cpp:62-63)
+GEL_DEV void thrust_dir(const double q[4], double dir[3]) {
+  const double qc[4] = {q[0], -q[1], -q[2], -q[3]};
+  const double ex[3] = {1.0, 0.0, 0.0};
+  quatrot(qc, ex, dir);
+}
+
+// ---------------------------------------------------------------------------
+// clamped linear interpolation: src/wrapper_utils.hpp:51-80, with np.interp's
+// value at x == xp[0].  Tables live in LDS.
+// ---------------------------------------------------------------------------
+GEL_DEV double interp_tab(double x, const double* tab, int n, int stride, int ycol) {
+  if (x <= tab[0]) return tab[ycol];
+  if (x > tab[(n - 1) * stride]) return tab[(n - 1) * stride + ycol];
+  int lo = 0, hi = n;  // std::lower_bound
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (tab[mid * stride] < x) lo = mid + 1; else hi = mid;
+  }
+  const int idx = lo - 1;
+  const double xl = tab[idx * stride], xu = tab[(idx + 1) * stride];
+  const double yl = tab[idx * stride + ycol], yu = tab[(idx + 1) * stride + ycol];
+  const double alpha = (x - xl) / (xu - xl);
+  return yl + alpha * (yu - yl);
+}
+
+// both wind components share one bracket search (src/wrapper_utils.hpp:82-87 runs it twice)
+GEL_DEV void wind_ned2(double h, const double* tab, int n, double& wn, double& we) {
+  if (h <= tab[0]) { wn = tab[1]; we = tab[2]; return; }
+  if (h > tab[(n - 1) * 3]) { wn = tab[(n - 1) * 3 + 1]; we = tab[(n - 1) * 3 + 2]; return; }
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (tab[mid * 3] < h) lo = mid + 1; else hi = mid;
+  }
+  const int idx = lo - 1;
+  const double xl = tab[idx * 3], xu = tab[(idx + 1) * 3];
+  const double alpha = (h - xl) / (xu - xl);
+  wn = tab[idx * 3 + 1] + alpha * (tab[(idx + 1) * 3 + 1] - tab[idx * 3 + 1]);
+  we = tab[idx * 3 + 2] + alpha * (tab[(idx + 1) * 3 + 2] - tab[idx * 3 + 2]);
+}
+
+// ---------------------------------------------------------------------------
+// The air RHS split by what each piece depends on.
+// ---------------------------------------------------------------------------
+// depends on position only
+struct PosPart {
+  double rho, P, a;  // atmosphere at the node
+  double wn, we;     // wind, NED
+  double g[3];       // gravity, ECI
+};
+
+GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
+  PosPart o;
+  // the reference feeds the ECI position to ecef2geodetic for altitude (src/pybind_dynamics.cpp:43)
+  const double alt = geodetic_altitude(r[0], r[1], r[2]);
+  const double h = geopotential_altitude(alt);
+  const Air air = atmosphere(h, tb.atm);
+  o.rho = air.rho; o.P = air.P; o.a = air.a;
+  wind_ned2(h, tb.wind, tb.Kw, o.wn, o.we);  // wind looked up at geopotential altitude (:44,49)
+  gravity_eci(r, barC20, o.g);
+  return o;
+}
+
+// depends on (position, t, wind_ned): Earth angle and the wind vector in ECI
+struct TimePart {
+  double c, s;       // cos, sin(omega t)
+  double wind[3];    // wind in ECI
+};
+
+GEL_DEV TimePart time_part(const double r[3], double t, double wn, double we) {
+  TimePart o;
+  const double wt = kOmega * t;
+  sincos(wt, &o.s, &o.c);
+  double sh, ch;
+  sincos(kOmega * t / 2.0, &sh, &ch);                 // src/Coordinate.cpp:75-79
+  // eci2ecef(pos, t): src/Coordinate.cpp:51-59
+  const double px = r[0] * o.c + r[1] * o.s;
+  const double py = -r[0] * o.s + r[1] * o.c;
+  const double pz = r[2];
+  double lat, p;
+  geodetic_lat_p(px, py, pz, lat, p);
+  const double lon = atan2(py, px);
+  // quat_ecef2ned: src/Coordinate.cpp:85-98
+  double s_hl, c_hl, s_hp, c_hp;
+  sincos(lon / 2.0, &s_hl, &c_hl);
+  sincos(lat / 2.0, &s_hp, &c_hp);
+  const double rt2 = 1.41421356237309514547;  // sqrt(2.0)
+  const double b[4] = {c_hl * (c_hp - s_hp) / rt2, s_hl * (c_hp + s_hp) / rt2,
+                       -c_hl * (c_hp + s_hp) / rt2, s_hl * (c_hp - s_hp) / rt2};
+  const double a[4] = {ch, 0.0, 0.0, sh};
+  double ab[4];
+  quatmult(a, b, ab);                                  // quat_eci2ned, :104-106
+  const double qn2i[4] = {ab[0], -ab[1], -ab[2], -ab[3]};  // quat_ned2eci, :108-110
+  const double wned[3] = {wn, we, 0.0};
+  quatrot(qn2i, wned, o.wind);                         // src/pybind_dynamics.cpp:51-52
+  return o;
+}
+
+// aerodynamic force (ECI): src/pybind_dynamics.cpp:48-59 given the shared parts
+GEL_DEV void aero_force(const double r[3], const double v[3], const PosPart& pp, const TimePart& tp,
+                        double area, const Tables& tb, double F[3]) {
+  // vel_eci2ecef: src/Coordinate.cpp:69-73 (omega x r = (-w y, w x, 0))
+  const double d0 = v[0] - (0.0 * r[2] - kOmega * r[1]);
+  const double d1 = v[1] - (kOmega * r[0] - 0.0 * r[2]);
+  const double d2 = v[2] - (0.0 * r[1] - 0.0 * r[0]);
+  const double e0 = d0 * tp.c + d1 * tp.s;
+  const double e1 = -d0 * tp.s + d1 * tp.c;
+  // ecef2eci: src/Coordinate.cpp:41-49, minus wind
+  const double a0 = (e0 * tp.c - e1 * tp.s) - tp.wind[0];
+  const double a1 = (e0 * tp.s + e1 * tp.c) - tp.wind[1];
+  const double a2 = d2 - tp.wind[2];
+  const double vn = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  const double mach = vn / pp.a;
+  const double ca = interp_tab(mach, tb.ca, tb.Kc, 2, 1);
+  const double k = 0.5 * pp.rho * area * ca * vn;
+  F[0] = k * -a0; F[1] = k * -a1; F[2] = k * -a2;
+}
+
+// quaternion kinematics: src/pybind_dynamics.cpp:94-106
+GEL_DEV void quat_rate(const double q[4], double u0, double u1, double unit_u, double dq[4]) {
+  const double om[4] = {0.0 * kPi / 180.0, 0.0 * kPi / 180.0, (u0 * unit_u) * kPi / 180.0, (u1 * unit_u) * kPi / 180.0};
+  double qp[4];
+  quatmult(q, om, qp);
+  dq[0] = 0.5 * qp[0]; dq[1] = 0.5 * qp[1]; dq[2] = 0.5 * qp[2]; dq[3] = 0.5 * qp[3];
+}
+
+}  // namespace gel

@@ -1,0 +1,235 @@
+"""Engine: Python handle on a device-resident LGR defect/Jacobian problem.
+
+Thin wrapper over the C-ABI (include/gelato_amd.h).  Holds no numerics of its own.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import GelDims, GelProblemDesc, check, lib
+
+GROUPS = ["mass", "pos", "vel", "quat"]
+# funcs / funcsSens keys of the reference callbacks (Trajectory_Optimization.py:199-210,250-261)
+CON_NAMES = {"mass": "eqcon_dyn_mass", "pos": "eqcon_dyn_pos", "vel": "eqcon_dyn_vel", "quat": "eqcon_dyn_quat"}
+# Jacobian blocks in C-ABI order: (group, var); var order per group = the reference's dict order
+BLOCKS = [("mass", "mass"), ("mass", "t"),
+          ("pos", "position"), ("pos", "velocity"), ("pos", "t"),
+          ("vel", "mass"), ("vel", "position"), ("vel", "velocity"), ("vel", "quaternion"), ("vel", "t"),
+          ("quat", "quaternion"), ("quat", "u"), ("quat", "t")]
+XKEYS = ["mass", "position", "velocity", "quaternion", "u", "t"]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def pack_x(xdict):
+    """xdict (reference layout, Trajectory_Optimization.py:318-352) -> packed decision vector."""
+    return np.concatenate([np.asarray(xdict[k], dtype=np.float64).ravel() for k in XKEYS])
+
+
+class Engine:
+    """prob: dict with num_nodes, thrust, massflow, reference_area, nozzle_area, engine_on,
+    attitude_hold, units (mass, position, velocity, u, t), dx, wind_table [K,3], ca_table [K,2];
+    optional D / tau (lists per phase, e.g. pdict["ps_params"].D(i)); barC20 (0 -> C++ constant)."""
+
+    def __init__(self, prob, D=None, tau=None, barC20=0.0, device=0):
+        L = lib()
+        self._keep = []
+        nn = np.ascontiguousarray(prob["num_nodes"], dtype=np.int32)
+        S = len(nn)
+
+        def darr(key):
+            a = _f64(prob[key])
+            assert a.size == S, key
+            self._keep.append(a)
+            return _d(a)
+
+        def iarr(key):
+            a = np.ascontiguousarray(prob[key], dtype=np.int32)
+            assert a.size == S, key
+            self._keep.append(a)
+            return a.ctypes.data_as(_ip)
+
+        wind, ca = _f64(prob["wind_table"]), _f64(prob["ca_table"])
+        units = _f64(prob["units"])
+        d = GelProblemDesc()
+        d.num_sections = S
+        d.num_nodes = nn.ctypes.data_as(_ip)
+        d.thrust, d.massflow = darr("thrust"), darr("massflow")
+        d.reference_area, d.nozzle_area = darr("reference_area"), darr("nozzle_area")
+        d.engine_on, d.attitude_hold = iarr("engine_on"), iarr("attitude_hold")
+        d.unit_mass, d.unit_position, d.unit_velocity, d.unit_u, d.unit_t = [float(u) for u in units]
+        d.dx = float(prob["dx"])
+        d.barC20 = float(barC20)
+        d.wind_rows, d.wind_table = wind.shape[0], _d(wind)
+        d.ca_rows, d.ca_table = ca.shape[0], _d(ca)
+        if D is not None:
+            Dall = _f64(np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in D]))
+            tall = _f64(np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in tau]))
+            d.D, d.tau = _d(Dall), _d(tall)
+        else:
+            d.D, d.tau = None, None
+        d.device = device
+        h = C.c_void_p()
+        check(L.gel_problem_create(C.byref(d), C.byref(h)))
+        self._h = h
+        dims = GelDims()
+        check(L.gel_problem_dims(h, C.byref(dims)))
+        self.S, self.N, self.M, self.nvars = dims.S, dims.N, dims.M, dims.num_vars
+        self.num_nodes = nn.copy()
+        self.nrows = list(dims.num_rows)
+        self.nres = 11 * self.N
+        self.block_nnz = [int(v) for v in dims.block_nnz]
+        self.block_shape = [(int(s[0]), int(s[1])) for s in dims.block_shape]
+        self.total_nnz = int(dims.total_nnz)
+        self.V = int(dims.num_var_entries)
+        self.algorithmic_bytes = int(dims.algorithmic_bytes)
+        self.block_off = np.concatenate([[0], np.cumsum(self.block_nnz)]).astype(np.int64)
+        self.row_off = {"mass": 0, "pos": self.N, "vel": 4 * self.N, "quat": 7 * self.N}
+        self._pattern = None
+        self._vals = None      # persistent full COO values (constants pre-filled)
+        self._var_idx = None
+
+    # ------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gel_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def D(self, i):
+        n = int(self.num_nodes[i])
+        out = np.zeros((n, n + 1))
+        check(lib().gel_problem_D(self._h, i, _d(out)))
+        return out
+
+    def tau(self, i):
+        out = np.zeros(int(self.num_nodes[i]))
+        check(lib().gel_problem_tau(self._h, i, _d(out)))
+        return out
+
+    def pattern(self):
+        """[(rows int32, cols int32)] for the 13 blocks (fixed; depends only on the static problem)."""
+        if self._pattern is None:
+            pat = []
+            for b in range(13):
+                r = np.zeros(self.block_nnz[b], dtype=np.int32)
+                c = np.zeros(self.block_nnz[b], dtype=np.int32)
+                check(lib().gel_pattern(self._h, b, r.ctypes.data_as(_ip), c.ctypes.data_as(_ip)))
+                pat.append((r, c))
+            self._pattern = pat
+        return self._pattern
+
+    def const_values(self):
+        v = np.zeros(self.total_nnz)
+        check(lib().gel_const_values(self._h, _d(v)))
+        return v
+
+    def var_index(self):
+        if self._var_idx is None:
+            idx = np.zeros(self.V, dtype=np.int64)
+            check(lib().gel_var_index(self._h, idx.ctypes.data_as(_lp)))
+            self._var_idx = idx
+        return self._var_idx
+
+    # ------------------------------------------------------------------
+    def eval_residual(self, x):
+        """-> (res [11N], status)"""
+        x = _f64(x)
+        assert x.size == self.nvars
+        res = np.empty(self.nres)
+        rc = check(lib().gel_eval_residual(self._h, _d(x), _d(res)))
+        return res, rc
+
+    def eval_jacobian(self, x, out=None):
+        """-> (vals_full [total_nnz], status).  `out` (from a previous call) is updated in place:
+        only the x-dependent entries are rewritten."""
+        x = _f64(x)
+        assert x.size == self.nvars
+        fill = 0
+        if out is None:
+            out = np.empty(self.total_nnz)
+            fill = 1
+        rc = check(lib().gel_eval_jacobian(self._h, _d(x), _d(out), fill))
+        return out, rc
+
+    def eval(self, x, out=None):
+        x = _f64(x)
+        res = np.empty(self.nres)
+        fill = 0
+        if out is None:
+            out = np.empty(self.total_nnz)
+            fill = 1
+        rc = check(lib().gel_eval(self._h, _d(x), _d(res), _d(out), fill))
+        return res, out, rc
+
+    def eval_batch(self, X, want_res=True, want_jac=True):
+        """X [B, nvars] -> (res [B, 11N] | None, jvar [B, V] | None, status)"""
+        X = _f64(X).reshape(-1, self.nvars)
+        B = X.shape[0]
+        res = np.empty((B, self.nres)) if want_res else None
+        jv = np.empty((B, self.V)) if want_jac else None
+        rc = check(lib().gel_eval_batch(self._h, B, _d(X), _d(res) if want_res else None,
+                                        _d(jv) if want_jac else None))
+        return res, jv, rc
+
+    def expand(self, jvar):
+        """compact [.., V] -> full [.., total_nnz] on the host (numpy), using the constant template."""
+        jvar = np.asarray(jvar)
+        full = np.broadcast_to(self.const_values(), jvar.shape[:-1] + (self.total_nnz,)).copy()
+        full[..., self.var_index()] = jvar
+        return full
+
+    # device-pointer API (pointers are integers, e.g. torch.Tensor.data_ptr())
+    def eval_batch_device(self, B, d_x, d_res, d_jvar, stream=0):
+        check(lib().gel_eval_batch_device(self._h, B, d_x, d_res or None, d_jvar or None, stream or None))
+
+    def expand_full_device(self, B, d_jvar, d_jfull, stream=0):
+        check(lib().gel_expand_full_device(self._h, B, d_jvar, d_jfull, stream or None))
+
+    def sync(self, stream=0):
+        return check(lib().gel_sync(self._h, stream or None))
+
+    def jac_fd(self, group, x):
+        gi = GROUPS.index(group)
+        x = _f64(x)
+        J = np.empty((self.nrows[gi], self.nvars))
+        rc = check(lib().gel_jac_fd(self._h, gi, _d(x), _d(J)))
+        return J, rc
+
+    # ------------------------------------------------------------------
+    def split_x(self, x):
+        M, N, S = self.M, self.N, self.S
+        o = np.cumsum([0, M, 3 * M, 3 * M, 4 * M, 2 * N, S + 1])
+        return {k: x[o[i]:o[i + 1]] for i, k in enumerate(XKEYS)}
+
+    def split_res(self, res):
+        N = self.N
+        return {"mass": res[..., :N], "pos": res[..., N:4 * N], "vel": res[..., 4 * N:7 * N], "quat": res[..., 7 * N:]}
+
+    def jac_dicts(self, vals_full):
+        """full values -> {group: {var: {"coo": [rows, cols, vals], "shape": ...}}} (reference layout,
+        lib/con_dynamics.py:75-76,108-113)."""
+        pat = self.pattern()
+        out = {g: {} for g in GROUPS}
+        for b, (g, var) in enumerate(BLOCKS):
+            r, c = pat[b]
+            v = vals_full[self.block_off[b]:self.block_off[b + 1]]
+            out[g][var] = {"coo": [r, c, v], "shape": self.block_shape[b]}
+        return out

@@ -1,0 +1,142 @@
+"""Problem set-up for the example vehicle without pyoptsparse: restates the set-up block of the
+reference driver (Trajectory_Optimization.py:55-167) and its from-file initial guess
+(initialize.py:322-409) for an arbitrary choice of phases / knots / node counts, and builds the
+synthetic decision-vector batches of SURVEY.md 8(d).
+
+The vehicle data (gelato_amd/data/example_vehicle.json) are plain numbers derived from the
+reference's example/ directory by tests/golden/make_golden.py.
+"""
+import json
+import os
+
+import numpy as np
+
+from .SectionParameters import PSparams
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "example_vehicle.json")
+
+# the configurations of SURVEY.md 8(d): (event rows, knot times, nodes per phase)
+CONFIGS = {
+    # config 2: 3 phases x 32
+    "3x32": (["KICKTURN", "ZEROLIFT_START", "SEIG", "SIMEND"], [0.0, 20.0, 169.0, 597.0], [32] * 3),
+    # config 3: the 6-phase multi-stage vehicle, 64 nodes per phase; exercises every branch
+    "mixed-6x64": (["LIFTOFF", "KICKTURN", "ZEROLIFT_START", "ZEROLIFT_END", "MECO", "SEIG", "SIMEND"],
+                   [0.0, 10.0, 20.0, 90.0, 169.0, 179.0, 597.0], [64] * 6),
+    # maximum work: all six phases powered, aerodynamic, free attitude
+    "dense-6x64": (["ZEROLIFT_END"] * 6 + ["SIMEND"], [0.0, 10.0, 20.0, 90.0, 169.0, 179.0, 597.0], [64] * 6),
+}
+
+
+def load_vehicle(path=_DATA):
+    with open(path) as f:
+        return json.load(f)
+
+
+def example_config(vehicle):
+    ev = vehicle["events"]
+    return [e["name"] for e in ev], [e["time"] for e in ev], [e["num_nodes"] for e in ev[:-1]]
+
+
+def stress_config(vehicle, nodes=128):
+    """config 5: the example's 12 phases with `nodes` LGR nodes each."""
+    names, times, _ = example_config(vehicle)
+    return names, times, [nodes] * (len(names) - 1)
+
+
+def build_pdict(vehicle, rows, knots, nodes, ps_params=None):
+    """-> (pdict, unitdict, condition).  Phase i takes the parameters of event row rows[i]."""
+    wt = np.asarray(vehicle["wind_alt_speed_dir"], dtype=np.float64)
+    wind_table = np.column_stack([wt[:, 0], wt[:, 1] * -np.cos(np.radians(wt[:, 2])),
+                                  wt[:, 1] * -np.sin(np.radians(wt[:, 2]))])  # Trajectory_Optimization.py:55-59
+    ca_table = np.asarray(vehicle["ca_mach_ca"], dtype=np.float64)
+    events = {e["name"]: e for e in vehicle["events"]}
+    stages = vehicle["stages"]
+    params = []
+    for i, name in enumerate(rows):
+        ev = events[name]
+        st = stages[str(ev["rocketStage"])]
+        params.append({
+            "name": name, "time": float(knots[i]),
+            "timeFinishAt": float(knots[i + 1]) if i + 1 < len(knots) else float(knots[i]) + 9000.0,
+            "rocketStage": ev["rocketStage"], "engineOn": bool(ev["engineOn"]), "thrust": float(ev["thrust"]),
+            "nozzle_area": float(ev["nozzle_area"]), "attitude": ev["attitude"],
+            "reference_area": float(st["reference_area"]),
+            # Trajectory_Optimization.py:109-112
+            "massflow": float(ev["thrust"]) / st["Isp_vac"] / 9.80665 if ev["engineOn"] else 0.0,
+        })
+    S = len(rows) - 1
+    nodes = [int(n) for n in nodes]
+    assert len(nodes) == S
+    N = sum(nodes)
+    pdict = {
+        "params": params,
+        "ps_params": ps_params if ps_params is not None else PSparams(nodes),
+        "wind_table": wind_table, "ca_table": ca_table,
+        "N": N, "M": N + S, "num_sections": S, "dx": 1.0e-8,
+    }
+    m_init = sum(s["mass_dry"] + s["mass_propellant"] for s in stages.values())
+    if vehicle["OptimizationMode"] != "Payload":
+        m_init += vehicle["mass_payload"]
+    unitdict = {"mass": m_init, "position": 6378137, "velocity": 1000.0, "u": 1.0, "t": params[-1]["time"]}
+    condition = {"OptimizationMode": vehicle["OptimizationMode"]}
+    return pdict, unitdict, condition
+
+
+def _interp_cols(t, tab, cols, tq):
+    # linear interpolation with linear extrapolation, like scipy interp1d(fill_value="extrapolate")
+    out = np.empty((len(tq), len(cols)))
+    idx = np.clip(np.searchsorted(t, tq, side="right") - 1, 0, len(t) - 2)
+    w = (tq - t[idx]) / (t[idx + 1] - t[idx])
+    for k, c in enumerate(cols):
+        y = tab[:, c]
+        out[:, k] = y[idx] + w * (y[idx + 1] - y[idx])
+    return out
+
+
+def initial_xdict(vehicle, pdict, unitdict):
+    """initialize.py:322-409 (LGR mode): interpolate the reference trajectory at the node times."""
+    tab = np.asarray(vehicle["trajectory"], dtype=np.float64)
+    col = {c: i for i, c in enumerate(vehicle["trajectory_columns"])}
+    t = tab[:, col["time"]]
+    ps = pdict["ps_params"]
+    tn, txn = [], []
+    for i in range(pdict["num_sections"]):
+        to, tf = pdict["params"][i]["time"], pdict["params"][i]["timeFinishAt"]
+        tau = ps.tau(i)
+        tn.append(tau * (tf - to) / 2.0 + (tf + to) / 2.0)
+        txn.append(np.hstack((-1.0, tau)) * (tf - to) / 2.0 + (tf + to) / 2.0)
+    tn, txn = np.concatenate(tn), np.concatenate(txn)
+    x = {
+        "mass": _interp_cols(t, tab, [col["mass"]], txn).ravel() / unitdict["mass"],
+        "position": _interp_cols(t, tab, [col["pos_ECI_" + a] for a in "XYZ"], txn).ravel() / unitdict["position"],
+        "velocity": _interp_cols(t, tab, [col["vel_ECI_" + a] for a in "XYZ"], txn).ravel() / unitdict["velocity"],
+        "quaternion": _interp_cols(t, tab, [col["quat_ECI2BODY_%d" % k] for k in range(4)], txn).ravel(),
+        "u": _interp_cols(t, tab, [col["rate_BODY_Y"], col["rate_BODY_Z"]], tn).ravel() / unitdict["u"],
+        "t": np.array([p["time"] for p in pdict["params"]]) / unitdict["t"],
+    }
+    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in x.items()}
+
+
+def synthetic_batch(x0, M, B, seed=20260313):
+    """element 0 = x0; element b > 0 = x0 * (1 + 1e-6*noise), position outward only."""
+    x0 = np.asarray(x0, dtype=np.float64)
+    X = np.tile(x0, (B, 1))
+    for b in range(1, B):
+        rng = np.random.default_rng(seed + b)
+        z = rng.standard_normal(x0.size)
+        z[M:4 * M] = np.abs(z[M:4 * M])
+        X[b] *= 1.0 + 1e-6 * z
+    return X
+
+
+def make_problem(name="mixed-6x64", vehicle=None, ps_params=None):
+    """-> (pdict, unitdict, condition, xdict) for a named configuration."""
+    vehicle = vehicle or load_vehicle()
+    if name == "example":
+        rows, knots, nodes = example_config(vehicle)
+    elif name.startswith("stress-12x"):
+        rows, knots, nodes = stress_config(vehicle, int(name.split("x")[1]))
+    else:
+        rows, knots, nodes = CONFIGS[name]
+    pdict, unitdict, condition = build_pdict(vehicle, rows, knots, nodes, ps_params)
+    return pdict, unitdict, condition, initial_xdict(vehicle, pdict, unitdict)

@@ -1,0 +1,427 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
+inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes -- through
+size-independent properties.  Run with `-m gpu` on an MI355X.
+
+Tolerances (fp64):
+  point functions / RHS / residuals : |d| <= 1e-12 + 1e-10*|ref|   (GPU libm (ocml) vs glibc: 1-2 ulp)
+  Jacobian, x-dependent entries     : |d| <= 1e-5  + 1e-6*|ref|    (FD with dx = 1e-8 amplifies ulps by 1e8)
+  Jacobian, constant entries        : bit-exact (same D handed to both sides)
+  sparsity pattern (int32)          : bit-exact
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import D_tau_from_golden, load_golden, problem_from_golden
+
+pytestmark = pytest.mark.gpu
+
+TW = None
+
+
+def _setup():
+    global TW
+    import oracle
+    TW = oracle.BARC20_PY_TWIN
+    return oracle
+
+
+def close(a, b, rtol=1e-10, atol=1e-12, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    assert np.all(err <= 0), "%s: max excess %g (max abs diff %g)" % (what, np.nanmax(err), np.nanmax(np.abs(a - b)))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_pair(prob, D=None, tau=None, barC20=None):
+    """(engine, oracle problem) on the same static problem and the same D / tau."""
+    oracle = _setup()
+    from gelato_amd import Engine
+    bc = oracle.BARC20_CPP if barC20 is None else barC20
+    P = oracle.Problem(prob, barC20=bc, D=D, tau=tau)
+    if D is None:
+        D = [P.D(i) for i in range(P.S)]
+        tau = [P.tau(i) for i in range(P.S)]
+    E = Engine(prob, D=D, tau=tau, barC20=bc)
+    return E, P
+
+
+def named_problem(name):
+    from gelato_amd import con_dynamics, pack_x, problem
+    pdict, unitdict, condition, xdict = problem.make_problem(name)
+    return con_dynamics.problem_arrays(pdict, unitdict), pack_x(xdict), pdict
+
+
+# --------------------------------------------------------------------------
+# a4..a9: point functions
+# --------------------------------------------------------------------------
+def test_point_functions_vs_oracle_and_golden():
+    oracle = _setup()
+    from gelato_amd.dynamics import point_eval
+    g = load_golden("g2_g5_pointwise.npz")
+    alt = g["air_alt"]
+    out = point_eval(0, alt)
+    ref = np.array([[oracle.geopotential_altitude(z)] + [f(oracle.geopotential_altitude(z)) for f in
+                    (oracle.air_temperature, oracle.air_pressure, oracle.air_density, oracle.speed_of_sound)]
+                    for z in alt])
+    close(out, ref, what="atmosphere vs oracle")
+    # golden columns were evaluated at `alt` taken as the already-geopotential argument
+    out_g = point_eval(0, alt)  # same kernel; compare T/P/rho/a at h = geopot(alt) with the oracle only
+    assert np.array_equal(out, out_g)
+
+    pos, vel, t = g["fr_pos"], g["fr_vel"], g["fr_t"]
+    close(point_eval(1, pos), g["fr_geodetic"], atol=1e-9, what="ecef2geodetic")
+    close(point_eval(2, pos, aux=np.array([TW])), g["fr_gravity_twin"], what="gravity")
+    close(point_eval(2, pos, aux=np.array([oracle.BARC20_CPP])),
+          np.array([oracle.gravity(p, oracle.BARC20_CPP) for p in pos]), what="gravity cpp const")
+    close(point_eval(3, np.column_stack([pos, t])), g["fr_quat_nedg2eci"], atol=1e-15, what="quat_nedg2eci")
+    close(point_eval(4, np.column_stack([vel, pos, t])), g["fr_vel_eci2ecef"], atol=1e-10, what="vel_eci2ecef")
+    W, CA = g["prob_wind_table"], g["prob_ca_table"]
+    close(point_eval(5, g["wind_alt"], aux=W), g["wind_ned"], atol=1e-12, what="wind_ned")
+    close(point_eval(6, g["ca_mach"], aux=CA).ravel(), g["ca_val"], atol=1e-15, what="interp CA")
+    assert point_eval(6, np.array([0.0]), aux=CA)[0, 0] == CA[0, 1]      # appendix C-3: np.interp value at xp[0]
+
+
+def test_atmosphere_dense_sweep_vs_oracle():
+    oracle = _setup()
+    from gelato_amd.dynamics import point_eval
+    alt = np.concatenate([np.linspace(-500.0, 130e3, 4001), np.linspace(130e3, 900e3, 500)])
+    out = point_eval(0, alt)
+    h = np.array([oracle.geopotential_altitude(z) for z in alt])
+    ref = np.column_stack([h, [oracle.air_temperature(z) for z in h], [oracle.air_pressure(z) for z in h],
+                           [oracle.air_density(z) for z in h], [oracle.speed_of_sound(z) for z in h]])
+    close(out, ref, what="atmosphere sweep")
+
+
+# --------------------------------------------------------------------------
+# a1..a3: node-batched RHS
+# --------------------------------------------------------------------------
+def test_rhs_functions_vs_golden_and_oracle():
+    oracle = _setup()
+    from gelato_amd import dynamics
+    g = load_golden("g2_g5_pointwise.npz")
+    prob = problem_from_golden(g)
+    P = oracle.Problem(prob, barC20=TW)
+    X = P.split_x(g["rhs_x"])
+    units = prob["units"][:3]
+    rv, rn, rq, ov = [], [], [], []
+    xa = ua = 0
+    for i, n in enumerate(prob["num_nodes"]):
+        xb, ub = xa + n + 1, ua + n
+        param = np.array([prob["thrust"][i], prob["massflow"][i], prob["reference_area"][i], 0, prob["nozzle_area"][i]])
+        pa = param.copy()
+        if pa[2] == 0.0:
+            pa[2] = 2.21
+        m_ = X["mass"][xa:xb]
+        p_ = X["position"].reshape(-1, 3)[xa:xb]
+        v_ = X["velocity"].reshape(-1, 3)[xa:xb]
+        q_ = X["quaternion"].reshape(-1, 4)[xa:xb]
+        u_ = X["u"].reshape(-1, 2)[ua:ub]
+        tn = np.concatenate([[X["t"][i]], P.tau(i) * (X["t"][i + 1] - X["t"][i]) / 2 + (X["t"][i + 1] + X["t"][i]) / 2])
+        rv.append(dynamics.dynamics_velocity(m_, p_, v_, q_, tn, pa, prob["wind_table"], prob["ca_table"], units, TW))
+        ov.append(oracle.dynamics_velocity(m_, p_, v_, q_, tn, pa, prob["wind_table"], prob["ca_table"], units, TW))
+        rn.append(dynamics.dynamics_velocity_NoAir(m_, p_, q_, param, units, TW))
+        rq.append(dynamics.dynamics_quaternion(q_[1:], u_, prob["units"][3]))
+        xa, ua = xb, ub
+    close(np.concatenate(rv), np.concatenate(ov), what="dynamics_velocity vs oracle")
+    close(np.concatenate(rv), g["rhs_vel_air"], what="dynamics_velocity vs golden")
+    close(np.concatenate(rn), g["rhs_vel_noair"], what="dynamics_velocity_NoAir vs golden")
+    close(np.concatenate(rq), g["rhs_quat"], atol=1e-16, what="dynamics_quaternion vs golden")
+
+
+def test_rhs_shape_errors_like_pybind():
+    from gelato_amd import dynamics
+    with pytest.raises(TypeError):
+        dynamics.dynamics_quaternion(np.zeros((3, 4)), np.zeros((2, 2)), 1.0)
+    assert dynamics.dynamics_quaternion(np.zeros((0, 4)), np.zeros((0, 2)), 1.0).shape == (0, 4)
+
+
+# --------------------------------------------------------------------------
+# a12..a19: residuals and COO Jacobians
+# --------------------------------------------------------------------------
+def check_against_oracle(E, P, x, what):
+    oracle = _setup()
+    res, rc = E.eval_residual(x)
+    assert rc == 0
+    vals, rc = E.eval_jacobian(x)
+    assert rc == 0
+    R = E.split_res(res)
+    J = E.jac_dicts(vals)
+    var_mask = np.zeros(E.total_nnz, dtype=bool)
+    var_mask[E.var_index()] = True
+    b = 0
+    for grp in oracle.GROUPS:
+        close(R[grp], P.residual(grp, x), what="%s residual %s" % (what, grp))
+        Jo = P.jacobian(grp, x)
+        for var in oracle.BLOCK_VARS[grp]:
+            r, c, v = J[grp][var]["coo"]
+            ro, co, vo = Jo[var]["coo"]
+            assert r.dtype == np.int32 and c.dtype == np.int32 and v.dtype == np.float64
+            assert np.array_equal(r, ro) and np.array_equal(c, co), "%s pattern %s/%s" % (what, grp, var)
+            assert J[grp][var]["shape"] == Jo[var]["shape"]
+            m = var_mask[E.block_off[b]:E.block_off[b + 1]]
+            d = np.abs(v - vo)
+            assert np.all(d[m] <= 1e-5 + 1e-6 * np.abs(vo[m])), "%s %s/%s var max %g" % (what, grp, var, d[m].max())
+            assert np.array_equal(v[~m], vo[~m]), "%s %s/%s constants" % (what, grp, var)
+            b += 1
+    return res, vals
+
+
+@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64"])
+def test_residuals_jacobians_vs_golden_and_oracle(name):
+    oracle = _setup()
+    g = load_golden("g6_%s.npz" % name)
+    prob = problem_from_golden(g)
+    D, tau = D_tau_from_golden(g, prob)
+    E, P = make_pair(prob, D, tau, barC20=TW)
+    x = g["x"]
+    res, vals = check_against_oracle(E, P, x, name)
+    R = E.split_res(res)
+    J = E.jac_dicts(vals)
+    for grp in oracle.GROUPS:
+        close(R[grp], g["res_" + grp], what="golden residual " + grp)
+        for var in oracle.BLOCK_VARS[grp]:
+            key = "jac_%s_%s" % (grp, var)
+            r, c, v = J[grp][var]["coo"]
+            assert str(g[key + "_rows_sha"]) == sha(r) and str(g[key + "_cols_sha"]) == sha(c), key
+            assert tuple(g[key + "_shape"]) == J[grp][var]["shape"]
+            if key + "_vals" in g:
+                ref = g[key + "_vals"]
+                d = np.abs(v - ref)
+                assert np.all(d <= 1e-5 + 1e-6 * np.abs(ref)), (key, d.max())
+            elif "var_%s_%s_idx" % (grp, var) in g:
+                idx, ref = g["var_%s_%s_idx" % (grp, var)], g["var_%s_%s_vals" % (grp, var)]
+                d = np.abs(v[idx] - ref)
+                assert np.all(d <= 1e-5 + 1e-6 * np.abs(ref)), (key, d.max())
+
+
+@pytest.mark.parametrize("name", ["dense-6x64", "mixed-6x64", "stress-12x128"])
+def test_full_size_configs_vs_oracle(name):
+    prob, x, _ = named_problem(name)
+    E, P = make_pair(prob)
+    check_against_oracle(E, P, x, name)
+    if name == "dense-6x64":
+        assert E.total_nnz == 745728 and E.algorithmic_bytes == 320072
+    if name == "stress-12x128":
+        assert E.nvars == 20113 and E.nres == 16896
+
+
+def test_ragged_and_edge_phases():
+    """n = 2 phases, engine-off + free attitude, NoAir + hold, zero thrust with aero, and a
+    multi-chunk phase (n = 100 > 64) with a ragged tail."""
+    prob, x0, _ = named_problem("example")
+    rng = np.random.default_rng(7)
+    S = 7
+    prob = dict(prob)
+    prob["num_nodes"] = np.array([2, 3, 100, 2, 17, 64, 5], dtype=np.int32)
+    prob["thrust"] = np.array([420000.0, 0.0, 420000.0, 30700.0, 0.0, 30700.0, 1000.0])
+    prob["massflow"] = np.array([140.0, 0.0, 140.0, 9.8, 0.0, 9.8, 0.3])
+    prob["reference_area"] = np.array([2.21, 2.21, 2.21, 0.0, 0.0, 2.21, 0.0])
+    prob["nozzle_area"] = np.array([0.68, 0.0, 0.68, 0.0, 0.0, 0.1, 0.0])
+    prob["engine_on"] = np.array([1, 0, 1, 1, 0, 1, 1], dtype=np.int32)
+    prob["attitude_hold"] = np.array([1, 0, 0, 1, 1, 0, 0], dtype=np.int32)
+    E, P = make_pair(prob)
+    N, M = E.N, E.M
+    # physically sensible random state: radius 1.0..1.02 Earth radii, speeds up to 7 km/s
+    pos = rng.standard_normal((M, 3))
+    pos = pos / np.linalg.norm(pos, axis=1, keepdims=True) * (1.0 + 0.02 * rng.random((M, 1)))
+    vel = rng.standard_normal((M, 3)) * 3.0
+    quat = rng.standard_normal((M, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([0.2 + rng.random(M), pos.ravel(), vel.ravel(), quat.ravel(), rng.standard_normal(2 * N),
+                        np.sort(rng.random(S + 1))])
+    check_against_oracle(E, P, x, "ragged")
+
+
+def test_batch_matches_single_and_oracle():
+    prob, x0, pdict = named_problem("3x32")
+    from gelato_amd import problem
+    E, P = make_pair(prob)
+    X = problem.synthetic_batch(x0, E.M, 6)
+    res, jv, rc = E.eval_batch(X)
+    assert rc == 0 and res.shape == (6, E.nres) and jv.shape == (6, E.V)
+    ores, ovals = P.eval_batch(X)
+    close(res, ores, what="batch residual")
+    full = E.expand(jv)
+    vm = np.zeros(E.total_nnz, dtype=bool)
+    vm[E.var_index()] = True
+    d = np.abs(full - ovals)
+    assert np.all(d[:, vm] <= 1e-5 + 1e-6 * np.abs(ovals[:, vm]))
+    assert np.array_equal(full[:, ~vm], ovals[:, ~vm])
+    # element b of a batch == the single-vector call, bit for bit
+    for b in (0, 3, 5):
+        r1, _ = E.eval_residual(X[b])
+        v1, _ = E.eval_jacobian(X[b])
+        assert np.array_equal(r1, res[b]) and np.array_equal(v1, full[b])
+    # residual-only and fused launches agree bit for bit
+    r_only, _, _ = E.eval_batch(X, want_jac=False)
+    assert np.array_equal(r_only, res)
+
+
+def test_device_pointer_api_and_full_expansion():
+    import torch
+    prob, x0, _ = named_problem("mixed-6x64")
+    from gelato_amd import problem
+    E, P = make_pair(prob)
+    B = 5
+    X = problem.synthetic_batch(x0, E.M, B)
+    dev = torch.device("cuda:0")
+    dX = torch.from_numpy(X).to(dev)
+    dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    djv = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    dfull = torch.empty((B, E.total_nnz), dtype=torch.float64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), s)
+    E.expand_full_device(B, djv.data_ptr(), dfull.data_ptr(), s)
+    assert E.sync(s) == 0
+    res, jv, _ = E.eval_batch(X)
+    assert np.array_equal(dres.cpu().numpy(), res) and np.array_equal(djv.cpu().numpy(), jv)
+    assert np.array_equal(dfull.cpu().numpy(), E.expand(jv))
+
+
+def test_nonfinite_input_sets_status():
+    prob, x0, _ = named_problem("3x32")
+    E, _ = make_pair(prob)
+    x = x0.copy()
+    x[E.M + 5] = np.nan
+    res, rc = E.eval_residual(x)
+    assert rc == 1 and np.isnan(res).any()
+    res, rc = E.eval_residual(x0)      # the flag is cleared again
+    assert rc == 0 and np.isfinite(res).all()
+
+
+# --------------------------------------------------------------------------
+# a20: generic column-batched forward difference
+# --------------------------------------------------------------------------
+def test_jac_fd_vs_golden_oracle_and_structured():
+    oracle = _setup()
+    g6 = load_golden("g6_example.npz")
+    g7 = load_golden("g7_jacfd_example.npz")
+    prob = problem_from_golden(g6)
+    D, tau = D_tau_from_golden(g6, prob)
+    E, P = make_pair(prob, D, tau, barC20=TW)
+    x = g6["x"]
+    vals, _ = E.eval_jacobian(x)
+    Jd = E.jac_dicts(vals)
+    off = {"mass": 0, "position": E.M, "velocity": 4 * E.M, "quaternion": 7 * E.M, "u": 11 * E.M,
+           "t": 11 * E.M + 2 * E.N}
+    for grp in oracle.GROUPS:
+        J, rc = E.jac_fd(grp, x)
+        assert rc == 0
+        Xs = E.split_x(np.arange(E.nvars))
+        for k, idx in Xs.items():
+            ref = g7["%s_%s" % (grp, k)]
+            d = np.abs(J[:, idx] - ref)
+            assert np.all(d <= 1e-5 + 1e-6 * np.abs(ref)), (grp, k, d.max())
+        d = np.abs(J - P.jac_fd(grp, x))
+        assert d.max() <= 1e-5
+        dense = np.zeros_like(J)
+        for var, blk in Jd[grp].items():
+            r, c, v = blk["coo"]
+            dense[r, c + off[var]] += v
+        assert np.max(np.abs(dense - J)) <= 1e-5         # structured COO == generic FD
+
+
+# --------------------------------------------------------------------------
+# boundary: the pyoptsparse callback surface
+# --------------------------------------------------------------------------
+def test_callback_surface_like_reference():
+    oracle = _setup()
+    from gelato_amd import con_dynamics, driver, jac_fd, problem
+    g = load_golden("g6_example.npz")
+    prob_ref = problem_from_golden(g)
+    D, tau = D_tau_from_golden(g, prob_ref)
+
+    class RefPS:  # the D / tau the caller put in pdict are inputs of the path
+        def __init__(self, inner):
+            self._i = inner
+        def __getattr__(self, k):
+            return getattr(self._i, k)
+        def D(self, i):
+            return D[i]
+        def tau(self, i):
+            return tau[i]
+
+    pdict, unitdict, condition, xdict = problem.make_problem("example")
+    pdict["ps_params"] = RefPS(pdict["ps_params"])
+    pdict["barC20"] = TW
+    xd = oracle.Problem(prob_ref).split_x(g["x"])
+    xd = {k: v.copy() for k, v in xd.items()}
+    keep = {k: v.copy() for k, v in xd.items()}
+    objfunc, sens = driver.make_callbacks(pdict, unitdict, condition)
+    funcs, fail = objfunc(xd)
+    fs, fail2 = sens(xd, funcs)
+    assert fail is False and fail2 is False
+    assert all(np.array_equal(xd[k], keep[k]) for k in xd)            # xdict is never mutated
+    assert funcs["obj"] == -xd["mass"][0]
+    for grp, key in [("mass", "eqcon_dyn_mass"), ("pos", "eqcon_dyn_pos"), ("vel", "eqcon_dyn_vel"),
+                     ("quat", "eqcon_dyn_quat")]:
+        assert funcs[key].ndim == 1 and funcs[key].dtype == np.float64
+        close(funcs[key], g["res_" + grp], what=key)
+        assert list(fs[key].keys()) == driver.WRT[key]                 # wrt map, Trajectory_Optimization.py:361-364
+        for var, blk in fs[key].items():
+            r, c, v = blk["coo"]
+            assert np.array_equal(r, g["jac_%s_%s_rows" % (grp, var)])
+            assert np.array_equal(c, g["jac_%s_%s_cols" % (grp, var)])
+            ref = g["jac_%s_%s_vals" % (grp, var)]
+            assert np.all(np.abs(v - ref) <= 1e-5 + 1e-6 * np.abs(ref))
+            assert blk["shape"] == tuple(g["jac_%s_%s_shape" % (grp, var)])
+            assert len(set(zip(r.tolist(), c.tolist()))) == len(r)     # no duplicate (row, col)
+    # second call with the same x is served from the cache, a moved x is re-evaluated
+    f2, _ = objfunc(xd)
+    assert np.array_equal(f2["eqcon_dyn_vel"], funcs["eqcon_dyn_vel"])
+    xd2 = {k: v * (1 + 1e-9) for k, v in xd.items()}
+    f3, _ = objfunc(xd2)
+    assert not np.array_equal(f3["eqcon_dyn_vel"], funcs["eqcon_dyn_vel"])
+    # jac_fd front end
+    J = jac_fd.jac_fd(con_dynamics.equality_dynamics_mass, xd, pdict, unitdict, condition)
+    assert set(J) == set(xd) and J["mass"].shape == (pdict["N"], pdict["M"])
+    with pytest.raises(TypeError):
+        jac_fd.jac_fd(lambda *a: np.zeros(3), xd, pdict, unitdict, condition)
+    stats = driver.mock_optimizer_loop(objfunc, sens, xd, iterations=3)
+    assert stats["userObjCalls"] == 3 and stats["fails"] == 0
+
+
+# --------------------------------------------------------------------------
+# full-size properties (6 x 64, large batch): determinism, permutation, batch-position independence
+# --------------------------------------------------------------------------
+def test_full_size_batch_properties():
+    import torch
+    from gelato_amd import problem
+    prob, x0, _ = named_problem("mixed-6x64")
+    E, P = make_pair(prob)
+    B = 2048
+    X = problem.synthetic_batch(x0, E.M, 64)
+    X = np.tile(X, (B // 64, 1))
+    dev = torch.device("cuda:0")
+    dX = torch.from_numpy(X).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(dx):
+        r = torch.empty((dx.shape[0], E.nres), dtype=torch.float64, device=dev)
+        jv = torch.empty((dx.shape[0], E.V), dtype=torch.float64, device=dev)
+        E.eval_batch_device(dx.shape[0], dx.data_ptr(), r.data_ptr(), jv.data_ptr(), s)
+        assert E.sync(s) == 0
+        return r, jv
+
+    r1, j1 = run(dX)
+    r2, j2 = run(dX)
+    assert torch.equal(r1, r2) and torch.equal(j1, j2)                  # deterministic
+    assert torch.equal(r1[:64], r1[-64:]) and torch.equal(j1[:64], j1[-64:])   # independent of batch position
+    perm = torch.randperm(B, device=dev)
+    r3, j3 = run(dX[perm].contiguous())
+    assert torch.equal(r3, r1[perm]) and torch.equal(j3, j1[perm])      # permutation equivariance
+    # a sample of the big batch against the oracle
+    ores, ovals = P.eval_batch(X[[0, 17, 63]])
+    close(r1[[0, 17, 63]].cpu().numpy(), ores, what="full-size residual sample")
+    full = E.expand(j1[[0, 17, 63]].cpu().numpy())
+    vm = np.zeros(E.total_nnz, dtype=bool)
+    vm[E.var_index()] = True
+    d = np.abs(full - ovals)
+    assert np.all(d[:, vm] <= 1e-5 + 1e-6 * np.abs(ovals[:, vm]))
+    assert np.array_equal(full[:, ~vm], ovals[:, ~vm])

@@ -1,0 +1,146 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol
+include/gelato_amd.h declares, the C++ LGR generator matches the reference's goldens, the Python
+mirror of the reference interface has the right names/signatures, the problem builder reproduces
+the fixture inputs, and the engine refuses to run without a GPU (no CPU fallback)."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, problem_from_golden
+
+import gelato_amd
+from gelato_amd import _lib, con_dynamics, cost_gradient, problem
+from gelato_amd.PSfunctions import differentiation_matrix_LGR, nodes_LGR
+from gelato_amd.SectionParameters import PSparams
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "gelato_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gel_[a-zA-Z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 24
+    for s in syms:
+        assert hasattr(L, s), "libgelato_amd.so does not export %s" % s
+        assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
+    assert b"gfx950" in L.gel_version()
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 8, 16, 32, 64, 128])
+def test_lgr_generator_matches_reference(n):
+    g = load_golden("g1_lgr.npz")
+    tau, D = nodes_LGR(n), differentiation_matrix_LGR(n)
+    assert D.shape == (n, n + 1)
+    assert np.max(np.abs(tau - g["tau_%d" % n])) <= 1e-14
+    Dg = g["D_%d" % n]
+    rowmax = np.max(np.abs(Dg), axis=1, keepdims=True)
+    assert np.max(np.abs(D - Dg) / rowmax) <= 1e-11     # SURVEY.md 8c tolerance for D
+    assert np.max(np.abs(D.sum(axis=1))) <= 1e-12 * np.abs(D).max()
+    # D differentiates polynomials of degree <= n exactly: D @ tau_x = 1, D @ tau_x^2 = 2 tau
+    tx = np.concatenate([[-1.0], tau])
+    assert np.max(np.abs(D @ tx - 1.0)) <= 1e-11 * np.abs(D).max()
+    assert np.max(np.abs(D @ tx ** 2 - 2 * tau)) <= 1e-11 * np.abs(D).max()
+
+
+def test_lgr_rejects_small_n():
+    with pytest.raises(_lib.GelatoAmdError):
+        nodes_LGR(1)
+
+
+def test_psparams_interface():
+    ps = PSparams([5, 5, 16, 8, 2])
+    assert ps.num_sections() == 5 and ps.num_u() == 36 and ps.num_x() == 41
+    assert ps.get_index(0) == (0, 5, 0, 6, 5)
+    assert ps.get_index(2) == (10, 26, 12, 29, 16)      # SectionParameters.py:97-103
+    assert ps.index_start_x(3) == 29 and ps.index_end_x(3) == 38 and ps.index_end_u(3) == 34
+    t = ps.time_nodes(2, 0.25, 0.75)
+    assert t.shape == (17,) and t[0] == 0.25 and abs(t[-1] - 0.75) < 1e-15
+    assert ps[1]["nodes"] == 5 and ps[1]["D"].shape == (5, 6)
+    with pytest.raises(ValueError):
+        ps.D(5)
+    with pytest.raises(ValueError):
+        ps.tau(-1)
+
+
+def test_shim_mirrors_reference_signatures():
+    names = ["equality_dynamics_mass", "equality_jac_dynamics_mass", "equality_dynamics_position",
+             "equality_jac_dynamics_position", "equality_dynamics_velocity", "equality_jac_dynamics_velocity",
+             "equality_dynamics_quaternion", "equality_jac_dynamics_quaternion"]
+    for n in names:
+        fn = getattr(con_dynamics, n)
+        assert list(inspect.signature(fn).parameters) == ["xdict", "pdict", "unitdict", "condition"]
+    from gelato_amd import dynamics, jac_fd
+    assert list(inspect.signature(dynamics.dynamics_velocity).parameters)[:9] == [
+        "mass_e", "pos_eci_e", "vel_eci_e", "quat_eci2body", "t", "param", "wind_table", "CA_table", "units"]
+    assert list(inspect.signature(dynamics.dynamics_quaternion).parameters) == ["quat_eci2body", "u_e", "unit_u"]
+    assert list(inspect.signature(jac_fd.jac_fd).parameters) == ["con", "xdict", "pdict", "unitdict", "condition"]
+
+
+def test_cost_functions():
+    g6 = load_golden("g6_example.npz")
+    g8 = load_golden("g8_cost.npz")
+    M = int(problem_from_golden(g6)["num_nodes"].sum()) + len(problem_from_golden(g6)["num_nodes"])
+    x = g6["x"]
+    xd = {"mass": x[:M], "t": x[-13:]}
+    for mode, key in [("Payload", "mass"), ("Other", "t")]:
+        cond = {"OptimizationMode": mode}
+        assert cost_gradient.cost_6DoF(xd, cond) == float(g8["cost_" + mode])
+        jac = cost_gradient.cost_jac(xd, cond)
+        assert list(jac) == [key] and np.array_equal(jac[key], g8["costjac_%s_%s" % (mode, key)])
+
+
+@pytest.mark.parametrize("name,gname", [("example", "example"), ("3x32", "3x32"), ("mixed-6x64", "mixed6x64")])
+def test_problem_builder_reproduces_fixture_inputs(name, gname):
+    g = load_golden("g6_%s.npz" % gname)
+    prob_ref = problem_from_golden(g)
+    pdict, unitdict, condition, xdict = problem.make_problem(name)
+    prob = con_dynamics.problem_arrays(pdict, unitdict)
+    for k in ["num_nodes", "thrust", "reference_area", "nozzle_area", "engine_on", "attitude_hold", "units"]:
+        assert np.array_equal(prob[k], prob_ref[k]), k
+    assert np.allclose(prob["massflow"], prob_ref["massflow"], rtol=1e-15, atol=0)
+    assert np.allclose(prob["wind_table"], prob_ref["wind_table"], rtol=0, atol=1e-12)
+    assert np.array_equal(prob["ca_table"], prob_ref["ca_table"])
+    x = gelato_amd.pack_x(xdict)
+    assert x.shape == g["x"].shape
+    assert np.max(np.abs(x - g["x"])) <= 1e-12           # tau differs by <= 1e-14, interpolation is linear
+
+
+def test_synthetic_batch_is_deterministic_and_outward():
+    pdict, unitdict, _, xdict = problem.make_problem("3x32")
+    x0 = gelato_amd.pack_x(xdict)
+    M = pdict["M"]
+    X = problem.synthetic_batch(x0, M, 4)
+    assert np.array_equal(X[0], x0)
+    assert np.array_equal(X, problem.synthetic_batch(x0, M, 4))
+    pos0 = np.linalg.norm(x0[M:4 * M].reshape(-1, 3), axis=1)
+    for b in range(1, 4):
+        assert np.all(np.linalg.norm(X[b, M:4 * M].reshape(-1, 3), axis=1) >= pos0)
+        assert np.max(np.abs(X[b] / x0 - 1.0)[x0 != 0]) < 1e-5
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pdict, unitdict, _, xdict = problem.make_problem("3x32")
+    with pytest.raises(_lib.GelatoAmdError, match="no HIP device|HIP"):
+        con_dynamics.equality_dynamics_mass(xdict, pdict, unitdict, None)
+    from gelato_amd import dynamics
+    with pytest.raises(_lib.GelatoAmdError):
+        dynamics.dynamics_quaternion(np.zeros((2, 4)), np.zeros((2, 2)), 1.0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "gelato_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "gelato_oracle" not in txt, f
