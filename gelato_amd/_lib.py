@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libgelato_amd.so")
+# GELATO_AMD_LIB selects another build of the same C-ABI (profiling / ablation variants)
+SO_PATH = os.environ.get("GELATO_AMD_LIB") or os.path.join(_HERE, "libgelato_amd.so")
 _LIB = None
 
 GEL_OK, GEL_NONFINITE = 0, 1
@@ -86,6 +87,30 @@ def build(force=False):
     return SO_PATH
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as
+    /opt/rocm's).  Whichever copy is mapped first serves every later user of that SONAME, and torch
+    cannot initialise on top of a foreign copy ("No HIP GPUs are available").  Device pointers and
+    stream handles cross between torch and this library (plumbing: memory, streams, RCCL), so both must
+    sit on the SAME runtime: if torch is installed, map its copy before libgelato_amd.so is loaded."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -93,6 +118,7 @@ def lib():
             raise RuntimeError(
                 "gelato_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C gelato_amd/csrc`).  There is no CPU fallback." % SO_PATH)
+        _preload_torch_hip_runtime()
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = the library does not export a declared symbol

@@ -3,31 +3,37 @@
 // One wavefront = one (decision vector b, phase, 64-node chunk) work item; one
 // lane = one collocation node.  The phase is wave-uniform: its parameters sit in
 // SGPRs, every phase-type branch (air / NoAir, hold, engine off) is a scalar
-// branch, and the X rows of the D.X product are scalar (broadcast) loads.
+// branch, and the X rows of the D.X product are scalar (SMEM, broadcast) loads.
+//
+// Memory discipline: vector-memory operations retire in order (one vmcnt per
+// wave), so a global load issued after a store waits for that store to drain to
+// HBM.  Therefore EVERY global load happens before the first store: the D.X
+// product runs first, and what is needed again late (quaternion, velocity,
+// mass, rates, the D.X rows of the velocity/quaternion defects) is parked in LDS
+// (its own lgkmcnt) instead of being re-read or kept in VGPRs.
 //
 // Register discipline (fp64 = 2 VGPRs per value, 64-wide): the heavy chain
 // (geodetic -> atmosphere -> wind -> Earth-angle quaternion -> aero) has ONE
 // instance, in a loop whose LAST trip is the centre point and leaves through
-// `break`; nothing the later sweeps need is carried across a heavy trip.  Inputs
-// that are only needed again late (quaternion, velocity, mass) are re-read from
-// L1/L2 through a laundered pointer instead of being kept live.
+// `break`; nothing the later sweeps need is carried across a heavy trip.
 #pragma once
 
 namespace gel {
 
-// make the compiler forget what it knows about a (wave-uniform) pointer, so a
-// later load through it is a real (cached) load, not a value kept in registers
-template <class T>
-GEL_DEV const T* relaunder(const T* p) {
-  asm volatile("" : "+s"(p));
-  return p;
-}
+// per-lane LDS park: slot-major so that consecutive lanes hit consecutive banks
+enum ParkSlot { PK_Q0 = 0, PK_Q1, PK_Q2, PK_Q3, PK_V0, PK_V1, PK_V2, PK_ME, PK_U0, PK_U1, PK_DJJ,
+                PK_LV0, PK_LV1, PK_LV2, PK_LQ0, PK_LQ1, PK_LQ2, PK_LQ3, PK_COUNT };
+constexpr int kTablePad = 128;  // doubles reserved for the staged tables in front of the park (checked on host)
 
 template <bool JAC>
 __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   extern __shared__ double lds[];
   const Tables tb = stage_tables(P, lds);
+  // explicit LDS address space: ds_read/ds_write (lgkmcnt), never flat_* (which also ticks vmcnt)
+  typedef __attribute__((address_space(3))) double lds_double;
+  lds_double* park = (lds_double*)lds + P.park_off + threadIdx.x;
+#define PARK(slot) park[(slot) * kBlock]
 
   const int lane = threadIdx.x & 63;
   const long long item = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
@@ -44,6 +50,11 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
   const int M = P.M, N = P.N;
 
   const double* xb = x + (size_t)b * P.nvars;
+  const double* xm = xb;
+  const double* xr = xb + M;
+  const double* xv = xb + 4 * M;
+  const double* xq = xb + 7 * M;
+  const double* xu = xb + 11 * M;
   const double* xt = xb + 11 * M + 2 * N;
   const double to = xt[sec], tf = xt[sec + 1];
   const double dx = P.dx, ut = P.ut;
@@ -51,51 +62,118 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
 
   double* rb = res ? res + (size_t)b * 11 * N : nullptr;
   double* jb = JAC ? jvar + (size_t)b * P.V + ph.voff + j : nullptr;
-#define EMIT(slot, val)                  \
-  do {                                   \
-    const double _v = (val);             \
-    jb[(size_t)(slot) * n] = _v;         \
-    chk += _v;                           \
+#define EMIT(slot, val)                \
+  do {                                 \
+    const double _v = (val);           \
+    jb[(size_t)(slot) * n] = _v;       \
+    chk += _v;                         \
   } while (0)
-  // Jacobian entry from a perturbed/centre pair: -(f_p - f_c)/dx*(tf-to)*unit_t/2  (con_dynamics.py:372)
-#define FDQ(fp, fc) (-((fp) - (fc)) / dx * (tf - to) * ut / 2.0)
+  // Jacobian entry from a perturbed/centre pair: -(f_p - f_c)/dx*(tf-to)*unit_t/2  (con_dynamics.py:372),
+  // as (f_c - f_p) times the wave-uniform scale (tf-to)*unit_t/2/dx
+  const double inv_dx = 1.0 / dx;
+  const double fds = inv_dx * (tf - to) * ut / 2.0;
+  const double fdt = inv_dx * ut / 2.0;
+  const double inv_uv = 1.0 / P.uv;
+#define FDQ(fp, fc) (((fc) - (fp)) * fds)
+
+  // ======================= phase A: every global load =======================
+  const double me = xm[xj];
+  const double re[3] = {xr[3 * xj], xr[3 * xj + 1], xr[3 * xj + 2]};
+  const double tau = P.tau[ph.toff + j];
+  double dir[3];
+  {
+    const double q[4] = {xq[4 * xj], xq[4 * xj + 1], xq[4 * xj + 2], xq[4 * xj + 3]};
+    const double ve[3] = {xv[3 * xj], xv[3 * xj + 1], xv[3 * xj + 2]};
+    thrust_dir(q, dir);
+    PARK(PK_Q0) = q[0]; PARK(PK_Q1) = q[1]; PARK(PK_Q2) = q[2]; PARK(PK_Q3) = q[3];
+    PARK(PK_V0) = ve[0]; PARK(PK_V1) = ve[1]; PARK(PK_V2) = ve[2];
+    PARK(PK_ME) = me;
+    if (!ph.hold) { PARK(PK_U0) = xu[2 * g]; PARK(PK_U1) = xu[2 * g + 1]; }
+    if (JAC) PARK(PK_DJJ) = P.Dt[ph.doff + (size_t)(j + 1) * n + j];  // D[j][j+1]
+
+    // D.X rows (lib/con_dynamics.py:54,146,256,524): lane j reads consecutive Dt addresses,
+    // the X rows are wave-uniform -> scalar loads feeding v_fma_f64 as SGPR operands
+    if (rb) {
+      double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
+      const double* Dt = P.Dt + ph.doff + j;
+      const double* pm = xm + ph.xa;
+      const double* pr = xr + 3 * ph.xa;
+      const double* pv = xv + 3 * ph.xa;
+      const double* pq = xq + 4 * ph.xa;
+      for (int i = 0; i <= n; i++) {
+        const double d = Dt[(size_t)i * n];
+        lm += d * pm[i];
+#pragma unroll
+        for (int c = 0; c < 3; c++) lr[c] += d * pr[3 * i + c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) lv[c] += d * pv[3 * i + c];
+#pragma unroll
+        for (int c = 0; c < 4; c++) lq[c] += d * pq[4 * i + c];
+      }
+      PARK(PK_LV0) = lv[0]; PARK(PK_LV1) = lv[1]; PARK(PK_LV2) = lv[2];
+      PARK(PK_LQ0) = lq[0]; PARK(PK_LQ1) = lq[1]; PARK(PK_LQ2) = lq[2]; PARK(PK_LQ3) = lq[3];
+      const double m0 = ph.engine_on ? 0.0 : xm[ph.xa];
+      double q0[4] = {0, 0, 0, 0};
+      if (ph.hold) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) q0[c] = xq[4 * ph.xa + c];
+      }
+
+      // ---- first stores: mass, position (and hold-type quaternion) defects (:34-63,116-152,521-522) ----
+      double cm;
+      if (ph.engine_on) {
+        const double rh = -ph.massflow / P.um * (tf - to) * ut / 2.0;
+        cm = lm - rh;
+      } else {
+        cm = me - m0;
+      }
+      rb[g] = cm;
+      chk += cm;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const double rh = ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
+        const double cp = lr[c] - rh;
+        rb[N + 3 * g + c] = cp;
+        chk += cp;
+      }
+      if (ph.hold) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const double cq = q[c] - q0[c];
+          rb[7 * N + 4 * g + c] = cq;
+          chk += cq;
+        }
+      }
+    }
+  }
+  // ======================= from here on: no global loads =======================
+  // compiler barrier: parked values are re-read from LDS below, not forwarded through VGPRs
+  asm volatile("" ::: "memory");
 
   // ---------------- velocity RHS + FD Jacobian (lib/con_dynamics.py:216-496) ----------------
   double fc[3];
   {
-    const double* xm = xb;
-    const double* xr = xb + M;
-    const double* xv = xb + 4 * M;
-    const double* xq = xb + 7 * M;
-    const double me = xm[xj];
-    const double re[3] = {xr[3 * xj], xr[3 * xj + 1], xr[3 * xj + 2]};
-    const double tau = P.tau[ph.toff + j];
     const double tn = tau * (tf - to) / 2 + (tf + to) / 2;  // PSparams.time_nodes, SectionParameters.py:77-81
-    const double m = me * P.um;
-    double dir[3];
-    {
-      const double q[4] = {xq[4 * xj], xq[4 * xj + 1], xq[4 * xj + 2], xq[4 * xj + 3]};
-      thrust_dir(q, dir);
-    }
+    const double inv_m = 1.0 / (me * P.um);
 
     if (ph.air) {
-      const double v[3] = {xv[3 * xj] * P.uv, xv[3 * xj + 1] * P.uv, xv[3 * xj + 2] * P.uv};
+      const double v[3] = {PARK(PK_V0) * P.uv, PARK(PK_V1) * P.uv, PARK(PK_V2) * P.uv};
+      const EarthAngle ea = earth_angle(tn);  // position sweeps do not change it
       // Trips k = 0,1,2: position sweeps (pos_k + dx); trip k = 3: centre, leaves by break.
       double fp[3][3];
       PosPart pp;
-      TimePart tp;
-      double F[3], T;
+      double w[3], F[3], T;
 #pragma unroll 1
       for (int k = JAC ? 0 : 3;; k++) {
         double r[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
         pp = pos_part(r, tb, P.barC20);
-        tp = time_part(r, tn, pp.wn, pp.we);
-        aero_force(r, v, pp, tp, ph.area, tb, F);
+        wind_eci(r, ea, pp.lat, pp.wn, pp.we, w);
+        aero_force(r, v, pp.rho, pp.a, ea, w, ph.area, tb, F);
         T = ph.thrust - ph.nozzle * pp.P;
         const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
-        accel(Td, F, m, pp.g, P.uv, fc);
+        accel(Td, F, inv_m, pp.g, inv_uv, fc);
         if (k == 3) break;
 #pragma unroll
         for (int kk = 0; kk < 3; kk++)
@@ -104,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
             for (int c = 0; c < 3; c++) fp[kk][c] = fc[c];
           }
       }
-      // here pp, tp, F, T, fc are the centre values
+      // here pp, w, F, T, fc are the centre values
       if (JAC) {
 #pragma unroll
         for (int k = 0; k < 3; k++)
@@ -112,18 +190,18 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
           for (int c = 0; c < 3; c++) EMIT(12 + 3 * k + c, FDQ(fp[k][c], fc[c]));
 
         const double r[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
+        const double Tdc[3] = {T * dir[0], T * dir[1], T * dir[2]};
         double f[3];
         // velocity sweeps: only the aerodynamic force changes
         if (ph.air_fd) {
-          const double djj = P.Dt[ph.doff + (size_t)(j + 1) * n + j];  // D[j][j+1]
-          const double Tdc[3] = {T * dir[0], T * dir[1], T * dir[2]};
+          const double djj = PARK(PK_DJJ);
 #pragma unroll 1
           for (int k = 0; k < 3; k++) {
             double vp[3], Fp[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) vp[c] = ((k == c) ? (xv[3 * xj + c] + dx) : xv[3 * xj + c]) * P.uv;
-            aero_force(r, vp, pp, tp, ph.area, tb, Fp);
-            accel(Tdc, Fp, m, pp.g, P.uv, f);
+            for (int c = 0; c < 3; c++) vp[c] = ((k == c) ? (PARK(PK_V0 + c) + dx) : PARK(PK_V0 + c)) * P.uv;
+            aero_force(r, vp, pp.rho, pp.a, ea, w, ph.area, tb, Fp);
+            accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
             // submat_vel[3j+c, 3(j+1)+k] = D[j][j+1]*(c==k) + rh_vel   (con_dynamics.py:341-343,415-416)
 #pragma unroll
             for (int c = 0; c < 3; c++) EMIT(ph.s_vv + 3 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fc[c]));
@@ -131,8 +209,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
         }
         // quaternion sweeps: only the thrust direction changes
         {
-          const double* xq2 = relaunder(xq);
-          const double q[4] = {xq2[4 * xj], xq2[4 * xj + 1], xq2[4 * xj + 2], xq2[4 * xj + 3]};
+          const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
 #pragma unroll 1
           for (int k = 0; k < 4; k++) {
             double qp[4];
@@ -141,14 +218,13 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
             double dp[3];
             thrust_dir(qp, dp);
             const double Td[3] = {T * dp[0], T * dp[1], T * dp[2]};
-            accel(Td, F, m, pp.g, P.uv, f);
+            accel(Td, F, inv_m, pp.g, inv_uv, f);
 #pragma unroll
             for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
           }
         }
-        const double Tdc[3] = {T * dir[0], T * dir[1], T * dir[2]};
         // mass sweep: only the division by mass changes
-        accel(Tdc, F, (me + dx) * P.um, pp.g, P.uv, f);
+        accel(Tdc, F, 1.0 / ((me + dx) * P.um), pp.g, inv_uv, f);
 #pragma unroll
         for (int c = 0; c < 3; c++) EMIT(9 + c, FDQ(f[c], fc[c]));
         // t0 / tf sweeps (con_dynamics.py:452-480): only the Earth angle changes
@@ -158,13 +234,15 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
             const double to_p = (k == 0) ? to + dx : to;
             const double tf_p = (k == 1) ? tf + dx : tf;
             const double tnp = tau * (tf_p - to_p) / 2 + (tf_p + to_p) / 2;
-            const TimePart tq = time_part(r, tnp, pp.wn, pp.we);
-            double Fp[3];
-            aero_force(r, v, pp, tq, ph.area, tb, Fp);
-            accel(Tdc, Fp, m, pp.g, P.uv, f);
+            const EarthAngle eq = earth_angle(tnp);
+            double wq[3], Fp[3];
+            wind_eci(r, eq, pp.lat, pp.wn, pp.we, wq);
+            aero_force(r, v, pp.rho, pp.a, eq, wq, ph.area, tb, Fp);
+            accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
+            // -(f_p*(tf_p - to_p) - f_c*(tf - to))/dx*unit_t/2   (con_dynamics.py:463-477)
 #pragma unroll
             for (int c = 0; c < 3; c++)
-              EMIT(ph.s_vt + 3 * k + c, -(f[c] * (tf_p - to_p) - fc[c] * (tf - to)) / dx * ut / 2.0);
+              EMIT(ph.s_vt + 3 * k + c, (fc[c] * (tf - to) - f[c] * (tf_p - to_p)) * fdt);
           }
         } else {
 #pragma unroll
@@ -184,10 +262,10 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
         const double r[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
         gravity_eci(r, P.barC20, gc);
       }
-      accel_noair(Td, m, gc, P.uv, fc);
+      accel_noair(Td, inv_m, gc, inv_uv, fc);
       if (JAC) {
         double f[3];
-        accel_noair(Td, (me + dx) * P.um, gc, P.uv, f);
+        accel_noair(Td, 1.0 / ((me + dx) * P.um), gc, inv_uv, f);
 #pragma unroll
         for (int c = 0; c < 3; c++) EMIT(9 + c, FDQ(f[c], fc[c]));
 #pragma unroll 1
@@ -196,11 +274,11 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
 #pragma unroll
           for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
           gravity_eci(r, P.barC20, gp);
-          accel_noair(Td, m, gp, P.uv, f);
+          accel_noair(Td, inv_m, gp, inv_uv, f);
 #pragma unroll
           for (int c = 0; c < 3; c++) EMIT(12 + 3 * k + c, FDQ(f[c], fc[c]));
         }
-        const double q[4] = {xq[4 * xj], xq[4 * xj + 1], xq[4 * xj + 2], xq[4 * xj + 3]};
+        const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
           double qp[4];
@@ -209,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
           double dp[3];
           thrust_dir(qp, dp);
           const double Tp[3] = {T * dp[0], T * dp[1], T * dp[2]};
-          accel_noair(Tp, m, gc, P.uv, f);
+          accel_noair(Tp, inv_m, gc, inv_uv, f);
 #pragma unroll
           for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
         }
@@ -222,32 +300,44 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
       }
     }
   }
+  if (rb) {  // velocity defect (:216-289)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double rh = fc[c] * (tf - to) * ut / 2.0;
+      const double cv = PARK(PK_LV0 + c) - rh;
+      rb[4 * N + 3 * g + c] = cv;
+      chk += cv;
+    }
+  }
 
-  // from here on the node state is re-read (L1/L2 hits) rather than kept live above
-  const double* xb2 = relaunder(xb);
-  const double* xm = xb2;
-  const double* xr = xb2 + M;
-  const double* xv = xb2 + 4 * M;
-  const double* xq = xb2 + 7 * M;
-  const double* xu = xb2 + 11 * M;
-  const double ve[3] = {xv[3 * xj], xv[3 * xj + 1], xv[3 * xj + 2]};
-  const double q[4] = {xq[4 * xj], xq[4 * xj + 1], xq[4 * xj + 2], xq[4 * xj + 3]};
-
-  // ---------------- position / quaternion Jacobian entries (:155-213, :536-632) ----------------
+  // ---------------- position / quaternion Jacobian entries, quaternion defect (:155-213, :499-632) ----------------
   if (JAC) {
     const double rh_vel = -P.uv * (tf - to) * ut / 2.0 / P.up;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       EMIT(0 + c, rh_vel);
-      const double rh_to = ve[c] * P.uv * ut / 2.0 / P.up;
+      const double rh_to = PARK(PK_V0 + c) * P.uv * ut / 2.0 / P.up;
       EMIT(3 + c, rh_to);
       EMIT(6 + c, -rh_to);
     }
-    if (!ph.hold) {
-      const double u0 = xu[2 * g], u1 = xu[2 * g + 1];
-      double fq[4], f[4];
-      quat_rate(q, u0, u1, P.uu, fq);
-      const double djj = P.Dt[ph.doff + (size_t)(j + 1) * n + j];
+  }
+  if (!ph.hold) {
+    const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
+    const double u0 = PARK(PK_U0), u1 = PARK(PK_U1);
+    double fq[4];
+    quat_rate(q, u0, u1, P.uu, fq);
+    if (rb) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const double rh = fq[c] * (tf - to) * ut / 2.0;
+        const double cq = PARK(PK_LQ0 + c) - rh;
+        rb[7 * N + 4 * g + c] = cq;
+        chk += cq;
+      }
+    }
+    if (JAC) {
+      const double djj = PARK(PK_DJJ);
+      double f[4];
 #pragma unroll 1
       for (int k = 0; k < 4; k++) {
         double qp[4];
@@ -272,71 +362,9 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
       }
     }
   }
-
-  // ---------------- D.X rows and the four defect residuals (:34-63,116-152,216-289,499-533) ----------------
-  if (rb) {
-    double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
-    {
-      const double* Dt = P.Dt + ph.doff + j;  // lane j: consecutive addresses
-      const double* pm = xm + ph.xa;           // wave-uniform rows: scalar loads
-      const double* pr = xr + 3 * ph.xa;
-      const double* pv = xv + 3 * ph.xa;
-      const double* pq = xq + 4 * ph.xa;
-      for (int i = 0; i <= n; i++) {
-        const double d = Dt[(size_t)i * n];
-        lm += d * pm[i];
-#pragma unroll
-        for (int c = 0; c < 3; c++) lr[c] += d * pr[3 * i + c];
-#pragma unroll
-        for (int c = 0; c < 3; c++) lv[c] += d * pv[3 * i + c];
-#pragma unroll
-        for (int c = 0; c < 4; c++) lq[c] += d * pq[4 * i + c];
-      }
-    }
-    double cm;
-    if (ph.engine_on) {
-      const double rh = -ph.massflow / P.um * (tf - to) * ut / 2.0;
-      cm = lm - rh;
-    } else {
-      cm = xm[xj] - xm[ph.xa];
-    }
-    rb[g] = cm;
-    chk += cm;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const double rh = ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
-      const double cp = lr[c] - rh;
-      rb[N + 3 * g + c] = cp;
-      chk += cp;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const double rh = fc[c] * (tf - to) * ut / 2.0;
-      const double cv = lv[c] - rh;
-      rb[4 * N + 3 * g + c] = cv;
-      chk += cv;
-    }
-    if (ph.hold) {
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const double cq = q[c] - xq[4 * ph.xa + c];
-        rb[7 * N + 4 * g + c] = cq;
-        chk += cq;
-      }
-    } else {
-      double fq[4];
-      quat_rate(q, xu[2 * g], xu[2 * g + 1], P.uu, fq);
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const double rh = fq[c] * (tf - to) * ut / 2.0;
-        const double cq = lq[c] - rh;
-        rb[7 * N + 4 * g + c] = cq;
-        chk += cq;
-      }
-    }
-  }
 #undef EMIT
 #undef FDQ
+#undef PARK
   if (!(fabs(chk) <= 1.79769313486231570815e308)) atomicOr(P.flag, 1);
 }
 

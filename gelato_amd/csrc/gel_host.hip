@@ -452,6 +452,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   dv.phases = p->d_phases; dv.node_phase = p->d_node_phase; dv.Dt = p->d_Dt; dv.tau = p->d_tau; dv.tables = p->d_tables;
   dv.flag = p->d_flag;
   dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks;
+  dv.park_off = (int32_t)((tables.size() + 1) / 2 * 2);
   dv.um = p->um; dv.up = p->up; dv.uv = p->uv; dv.uu = p->uu; dv.ut = p->ut; dv.dx = p->dx; dv.barC20 = p->barC20;
   *out = p;
   return GEL_OK;
@@ -670,7 +671,7 @@ int gel_dynamics_quaternion(int32_t n, const double* quat, const double* u_e, do
 }
 
 int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux, int32_t aux_rows, double* out) {
-  static const int nin[7] = {1, 3, 3, 4, 7, 1, 1}, nout[7] = {5, 3, 3, 4, 3, 3, 1};
+  static const int nin[7] = {1, 3, 3, 6, 7, 1, 1}, nout[7] = {5, 3, 3, 3, 3, 3, 1};
   if (kind < 0 || kind > 6 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
   if (n == 0) return GEL_OK;
   int rc = need_device();

@@ -21,7 +21,7 @@
 
 #include "gel_device.h"
 #include "gel_launch.h"
-#include "gel_physics.h"
+#include "gel_rhs_parts.h"
 
 namespace gel {
 
@@ -38,17 +38,6 @@ GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds) {
   tb.Kw = P.Kw;
   tb.Kc = P.Kc;
   return tb;
-}
-
-// acc/unit_vel = ((thrust_eci + aero)/m + g)/uv        src/pybind_dynamics.cpp:66-70
-GEL_DEV void accel(const double Td[3], const double F[3], double m, const double g[3], double uv, double out[3]) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) out[c] = ((Td[c] + F[c]) / m + g[c]) / uv;
-}
-// NoAir: (thrust_eci/m + g)/uv                          src/pybind_dynamics.cpp:85-91
-GEL_DEV void accel_noair(const double Td[3], double m, const double g[3], double uv, double out[3]) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) out[c] = (Td[c] / m + g[c]) / uv;
 }
 
 }  // namespace gel
@@ -137,13 +126,14 @@ __global__ void rhs_vel_air_kernel(RhsArgs A) {
   const double v[3] = {A.vel_e[3 * i] * A.uv, A.vel_e[3 * i + 1] * A.uv, A.vel_e[3 * i + 2] * A.uv};
   const double q[4] = {A.quat[4 * i], A.quat[4 * i + 1], A.quat[4 * i + 2], A.quat[4 * i + 3]};
   const PosPart pp = pos_part(r, tb, A.barC20);
-  const TimePart tp = time_part(r, A.t[i], pp.wn, pp.we);
-  double F[3], dir[3], f[3];
-  aero_force(r, v, pp, tp, A.area, tb, F);
+  const EarthAngle ea = earth_angle(A.t[i]);
+  double w[3], F[3], dir[3], f[3];
+  wind_eci(r, ea, pp.lat, pp.wn, pp.we, w);
+  aero_force(r, v, pp.rho, pp.a, ea, w, A.area, tb, F);
   thrust_dir(q, dir);
   const double T = A.thrust - A.nozzle * pp.P;
   const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
-  accel(Td, F, m, pp.g, A.uv, f);
+  accel(Td, F, 1.0 / m, pp.g, 1.0 / A.uv, f);
   for (int c = 0; c < 3; c++) A.out[3 * i + c] = f[c];
 }
 
@@ -157,7 +147,7 @@ __global__ void rhs_vel_noair_kernel(RhsArgs A) {
   thrust_dir(q, dir);
   gravity_eci(r, A.barC20, g);
   const double Td[3] = {A.thrust * dir[0], A.thrust * dir[1], A.thrust * dir[2]};
-  accel_noair(Td, m, g, A.uv, f);
+  accel_noair(Td, 1.0 / m, g, 1.0 / A.uv, f);
   for (int c = 0; c < 3; c++) A.out[3 * i + c] = f[c];
 }
 
@@ -196,27 +186,14 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       out[3 * i] = g[0]; out[3 * i + 1] = g[1]; out[3 * i + 2] = g[2];
     } break;
     case 3: {
-      // quat_nedg2eci = what time_part rotates the wind with; recover it by rotating the NED basis
-      const double r[3] = {in[4 * i], in[4 * i + 1], in[4 * i + 2]};
-      const double t = in[4 * i + 3];
-      // rebuild the quaternion exactly as time_part does
-      double s, c, sh, ch;
-      sincos(kOmega * t, &s, &c);
-      sincos(kOmega * t / 2.0, &sh, &ch);
-      const double px = r[0] * c + r[1] * s, py = -r[0] * s + r[1] * c, pz = r[2];
-      double lat, p;
-      geodetic_lat_p(px, py, pz, lat, p);
-      const double lon = atan2(py, px);
-      double s_hl, c_hl, s_hp, c_hp;
-      sincos(lon / 2.0, &s_hl, &c_hl);
-      sincos(lat / 2.0, &s_hp, &c_hp);
-      const double rt2 = 1.41421356237309514547;
-      const double bq[4] = {c_hl * (c_hp - s_hp) / rt2, s_hl * (c_hp + s_hp) / rt2, -c_hl * (c_hp + s_hp) / rt2,
-                            s_hl * (c_hp - s_hp) / rt2};
-      const double aq[4] = {ch, 0.0, 0.0, sh};
-      double ab[4];
-      quatmult(aq, bq, ab);
-      out[4 * i] = ab[0]; out[4 * i + 1] = -ab[1]; out[4 * i + 2] = -ab[2]; out[4 * i + 3] = -ab[3];
+      // wind vector NED -> ECI exactly as the hot path does it: in = pos[3], t, wn, we
+      const double* a = in + 6 * i;
+      const double r[3] = {a[0], a[1], a[2]};
+      double lat, p, w[3];
+      geodetic_lat_p(r[0], r[1], r[2], lat, p);
+      const EarthAngle ea = earth_angle(a[3]);
+      wind_eci(r, ea, lat, a[4], a[5], w);
+      out[3 * i] = w[0]; out[3 * i + 1] = w[1]; out[3 * i + 2] = w[2];
     } break;
     case 4: {
       const double* a = in + 7 * i;  // vel[3], pos[3], t
@@ -246,7 +223,7 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
   if (B <= 0) return hipSuccess;
   const long long waves = (long long)B * P.nchunks;
   const unsigned grid = (unsigned)((waves * 64 + kBlock - 1) / kBlock);
-  const size_t lds = table_lds_bytes(P.Kw, P.Kc);
+  const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)PK_COUNT * kBlock);  // tables | per-lane park
   if (d_jvar)
     hipLaunchKernelGGL(eval_kernel<true>, dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
   else

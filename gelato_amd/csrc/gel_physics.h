@@ -172,13 +172,6 @@ GEL_DEV void quatrot(const double q[4], const double v[3], double out[3]) {
   out[0] = r[1]; out[1] = r[2]; out[2] = r[3];
 }
 
-// thrust direction = quatrot(conj(q), (1,0,0))   (src/pybind_dynamics.cpp:62-63)
-GEL_DEV void thrust_dir(const double q[4], double dir[3]) {
-  const double qc[4] = {q[0], -q[1], -q[2], -q[3]};
-  const double ex[3] = {1.0, 0.0, 0.0};
-  quatrot(qc, ex, dir);
-}
-
 // ---------------------------------------------------------------------------
 // clamped linear interpolation: src/wrapper_utils.hpp:51-80, with np.interp's
 // value at x == xp[0].  Tables live in LDS.
@@ -212,91 +205,6 @@ GEL_DEV void wind_ned2(double h, const double* tab, int n, double& wn, double& w
   const double alpha = (h - xl) / (xu - xl);
   wn = tab[idx * 3 + 1] + alpha * (tab[(idx + 1) * 3 + 1] - tab[idx * 3 + 1]);
   we = tab[idx * 3 + 2] + alpha * (tab[(idx + 1) * 3 + 2] - tab[idx * 3 + 2]);
-}
-
-// ---------------------------------------------------------------------------
-// The air RHS split by what each piece depends on.
-// ---------------------------------------------------------------------------
-// depends on position only
-struct PosPart {
-  double rho, P, a;  // atmosphere at the node
-  double wn, we;     // wind, NED
-  double g[3];       // gravity, ECI
-};
-
-GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
-  PosPart o;
-  // the reference feeds the ECI position to ecef2geodetic for altitude (src/pybind_dynamics.cpp:43)
-  const double alt = geodetic_altitude(r[0], r[1], r[2]);
-  const double h = geopotential_altitude(alt);
-  const Air air = atmosphere(h, tb.atm);
-  o.rho = air.rho; o.P = air.P; o.a = air.a;
-  wind_ned2(h, tb.wind, tb.Kw, o.wn, o.we);  // wind looked up at geopotential altitude (:44,49)
-  gravity_eci(r, barC20, o.g);
-  return o;
-}
-
-// depends on (position, t, wind_ned): Earth angle and the wind vector in ECI
-struct TimePart {
-  double c, s;       // cos, sin(omega t)
-  double wind[3];    // wind in ECI
-};
-
-GEL_DEV TimePart time_part(const double r[3], double t, double wn, double we) {
-  TimePart o;
-  const double wt = kOmega * t;
-  sincos(wt, &o.s, &o.c);
-  double sh, ch;
-  sincos(kOmega * t / 2.0, &sh, &ch);                 // src/Coordinate.cpp:75-79
-  // eci2ecef(pos, t): src/Coordinate.cpp:51-59
-  const double px = r[0] * o.c + r[1] * o.s;
-  const double py = -r[0] * o.s + r[1] * o.c;
-  const double pz = r[2];
-  double lat, p;
-  geodetic_lat_p(px, py, pz, lat, p);
-  const double lon = atan2(py, px);
-  // quat_ecef2ned: src/Coordinate.cpp:85-98
-  double s_hl, c_hl, s_hp, c_hp;
-  sincos(lon / 2.0, &s_hl, &c_hl);
-  sincos(lat / 2.0, &s_hp, &c_hp);
-  const double rt2 = 1.41421356237309514547;  // sqrt(2.0)
-  const double b[4] = {c_hl * (c_hp - s_hp) / rt2, s_hl * (c_hp + s_hp) / rt2,
-                       -c_hl * (c_hp + s_hp) / rt2, s_hl * (c_hp - s_hp) / rt2};
-  const double a[4] = {ch, 0.0, 0.0, sh};
-  double ab[4];
-  quatmult(a, b, ab);                                  // quat_eci2ned, :104-106
-  const double qn2i[4] = {ab[0], -ab[1], -ab[2], -ab[3]};  // quat_ned2eci, :108-110
-  const double wned[3] = {wn, we, 0.0};
-  quatrot(qn2i, wned, o.wind);                         // src/pybind_dynamics.cpp:51-52
-  return o;
-}
-
-// aerodynamic force (ECI): src/pybind_dynamics.cpp:48-59 given the shared parts
-GEL_DEV void aero_force(const double r[3], const double v[3], const PosPart& pp, const TimePart& tp,
-                        double area, const Tables& tb, double F[3]) {
-  // vel_eci2ecef: src/Coordinate.cpp:69-73 (omega x r = (-w y, w x, 0))
-  const double d0 = v[0] - (0.0 * r[2] - kOmega * r[1]);
-  const double d1 = v[1] - (kOmega * r[0] - 0.0 * r[2]);
-  const double d2 = v[2] - (0.0 * r[1] - 0.0 * r[0]);
-  const double e0 = d0 * tp.c + d1 * tp.s;
-  const double e1 = -d0 * tp.s + d1 * tp.c;
-  // ecef2eci: src/Coordinate.cpp:41-49, minus wind
-  const double a0 = (e0 * tp.c - e1 * tp.s) - tp.wind[0];
-  const double a1 = (e0 * tp.s + e1 * tp.c) - tp.wind[1];
-  const double a2 = d2 - tp.wind[2];
-  const double vn = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-  const double mach = vn / pp.a;
-  const double ca = interp_tab(mach, tb.ca, tb.Kc, 2, 1);
-  const double k = 0.5 * pp.rho * area * ca * vn;
-  F[0] = k * -a0; F[1] = k * -a1; F[2] = k * -a2;
-}
-
-// quaternion kinematics: src/pybind_dynamics.cpp:94-106
-GEL_DEV void quat_rate(const double q[4], double u0, double u1, double unit_u, double dq[4]) {
-  const double om[4] = {0.0 * kPi / 180.0, 0.0 * kPi / 180.0, (u0 * unit_u) * kPi / 180.0, (u1 * unit_u) * kPi / 180.0};
-  double qp[4];
-  quatmult(q, om, qp);
-  dq[0] = 0.5 * qp[0]; dq[1] = 0.5 * qp[1]; dq[2] = 0.5 * qp[2]; dq[3] = 0.5 * qp[3];
 }
 
 }  // namespace gel

@@ -1,0 +1,135 @@
+// gel_rhs_parts.h -- the air RHS split by what each piece depends on, so that every
+// finite-difference sweep recomputes only what its perturbed variable enters.
+//
+//   pos_part(r)            atmosphere, wind (NED), gravity, geodetic latitude   <- position only
+//   earth_angle(t)         cos/sin(omega t), cos/sin(omega t / 2)               <- time only
+//   wind_eci(r, ea, ...)   wind rotated NED -> ECI                              <- position, time
+//   aero_force(...)        axial aerodynamic force                               <- velocity + the above
+//   accel(...)             (thrust + aero)/m + g, normalised                     <- mass, thrust direction
+//
+// Arithmetic policy (fp64, no fast-math): each piece follows the reference's formulas; where
+// the reference's C++ divides by a loop-invariant (mass, unit_vel, sqrt(2), dx) the device
+// multiplies by its once-computed reciprocal.  That changes a result by <= 1 ulp -- the same
+// class of difference as ocml-vs-glibc libm -- and is applied identically to the centre and the
+// perturbed evaluations, so finite-difference quotients see no extra noise.
+#pragma once
+#include "gel_physics.h"
+
+namespace gel {
+
+// depends on position only
+struct PosPart {
+  double rho, P, a;  // atmosphere at the node
+  double wn, we;     // wind, NED
+  double g[3];       // gravity, ECI
+  double lat;        // geodetic latitude [rad] of the position
+};
+
+GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
+  PosPart o;
+  // the reference feeds the ECI position to ecef2geodetic for altitude (src/pybind_dynamics.cpp:43)
+  double p;
+  geodetic_lat_p(r[0], r[1], r[2], o.lat, p);
+  double sl, cl;
+  sincos(o.lat, &sl, &cl);
+  const double Nn = kRa / sqrt(1.0 - kE2 * sl * sl);
+  const double alt = p / cl - Nn;
+  const double h = geopotential_altitude(alt);
+  const Air air = atmosphere(h, tb.atm);
+  o.rho = air.rho; o.P = air.P; o.a = air.a;
+  wind_ned2(h, tb.wind, tb.Kw, o.wn, o.we);  // wind looked up at geopotential altitude (:44,49)
+  gravity_eci(r, barC20, o.g);
+  return o;
+}
+
+// depends on time only: src/Coordinate.cpp:41-59 (cos/sin(omega t)), :75-79 (half angle)
+struct EarthAngle { double c, s, ch, sh; };
+
+GEL_DEV EarthAngle earth_angle(double t) {
+  EarthAngle e;
+  sincos(kOmega * t, &e.s, &e.c);
+  sincos(kOmega * t / 2.0, &e.sh, &e.ch);
+  return e;
+}
+
+// Wind vector in ECI = quatrot(quat_nedg2eci(pos, t), wind_ned)  (src/pybind_dynamics.cpp:51-52).
+// quat_nedg2eci = conj( q_eci2ecef(t) * q_ecef2ned( Rz(-omega t) pos ) )  (src/Coordinate.cpp:75-110).
+// The reference re-runs the Bowring latitude on the rotated position (Coordinate.cpp:86); a rotation
+// about z leaves (sqrt(x^2+y^2), z) and therefore the latitude unchanged, so pos_part's latitude is
+// reused (equal to a recomputation up to rounding).  The longitude IS taken from the rotated position.
+GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double lat, double wn, double we, double w[3]) {
+  // eci2ecef(pos, t): src/Coordinate.cpp:51-59
+  const double px = r[0] * e.c + r[1] * e.s;
+  const double py = -r[0] * e.s + r[1] * e.c;
+  const double lon = atan2(py, px);
+  // quat_ecef2ned: src/Coordinate.cpp:85-98
+  double s_hl, c_hl, s_hp, c_hp;
+  sincos(lon / 2.0, &s_hl, &c_hl);
+  sincos(lat / 2.0, &s_hp, &c_hp);
+  const double irt2 = 0.70710678118654752440;  // 1/sqrt(2)
+  const double b0 = c_hl * (c_hp - s_hp) * irt2, b1 = s_hl * (c_hp + s_hp) * irt2;
+  const double b2 = -c_hl * (c_hp + s_hp) * irt2, b3 = s_hl * (c_hp - s_hp) * irt2;
+  // (ch,0,0,sh) * b, then conjugate  -> q = quat_ned2eci
+  const double q0 = e.ch * b0 - e.sh * b3;
+  const double q1 = -(e.ch * b1 - e.sh * b2);
+  const double q2 = -(e.ch * b2 + e.sh * b1);
+  const double q3 = -(e.ch * b3 + e.sh * b0);
+  // quatrot(q, (wn, we, 0)) = vec( conj(q) * ((0,wn,we,0) * q) )   (src/wrapper_coordinate.hpp:70-78)
+  const double t0 = -wn * q1 - we * q2;
+  const double t1 = wn * q0 + we * q3;
+  const double t2 = -wn * q3 + we * q0;
+  const double t3 = wn * q2 - we * q1;
+  w[0] = q0 * t1 - q1 * t0 - q2 * t3 + q3 * t2;
+  w[1] = q0 * t2 + q1 * t3 - q2 * t0 - q3 * t1;
+  w[2] = q0 * t3 - q1 * t2 + q2 * t1 - q3 * t0;
+}
+
+// aerodynamic force (ECI): src/pybind_dynamics.cpp:48-59 given the shared parts
+GEL_DEV void aero_force(const double r[3], const double v[3], double rho, double a_sound, const EarthAngle& e,
+                        const double w[3], double area, const Tables& tb, double F[3]) {
+  // vel_eci2ecef: src/Coordinate.cpp:69-73 (omega x r = (-w y, w x, 0)), then ecef2eci (:41-49), minus wind
+  const double d0 = v[0] + kOmega * r[1];
+  const double d1 = v[1] - kOmega * r[0];
+  const double e0 = d0 * e.c + d1 * e.s;
+  const double e1 = -d0 * e.s + d1 * e.c;
+  const double a0 = (e0 * e.c - e1 * e.s) - w[0];
+  const double a1 = (e0 * e.s + e1 * e.c) - w[1];
+  const double a2 = v[2] - w[2];
+  const double vn = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  const double mach = vn / a_sound;
+  const double ca = interp_tab(mach, tb.ca, tb.Kc, 2, 1);
+  const double k = 0.5 * rho * area * ca * vn;
+  F[0] = k * -a0; F[1] = k * -a1; F[2] = k * -a2;
+}
+
+// acc/unit_vel = ((thrust_eci + aero)/m + g)/uv        src/pybind_dynamics.cpp:66-70
+GEL_DEV void accel(const double Td[3], const double F[3], double inv_m, const double g[3], double inv_uv,
+                   double out[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) out[c] = ((Td[c] + F[c]) * inv_m + g[c]) * inv_uv;
+}
+// NoAir: (thrust_eci/m + g)/uv                          src/pybind_dynamics.cpp:85-91
+GEL_DEV void accel_noair(const double Td[3], double inv_m, const double g[3], double inv_uv, double out[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) out[c] = (Td[c] * inv_m + g[c]) * inv_uv;
+}
+
+// thrust direction = quatrot(conj(q), (1,0,0))   (src/pybind_dynamics.cpp:62-63), zero terms dropped
+GEL_DEV void thrust_dir(const double q[4], double dir[3]) {
+  dir[0] = q[0] * q[0] + q[1] * q[1] - q[2] * q[2] - q[3] * q[3];
+  dir[1] = q[0] * q[3] + q[1] * q[2] + q[2] * q[1] + q[3] * q[0];
+  dir[2] = -q[0] * q[2] + q[1] * q[3] - q[2] * q[0] + q[3] * q[1];
+}
+
+// quaternion kinematics: src/pybind_dynamics.cpp:94-106; om = u*unit_u*pi/180, zero terms dropped:
+// dq = 0.5 * q * (0, 0, oy, oz)
+GEL_DEV void quat_rate(const double q[4], double u0, double u1, double unit_u, double dq[4]) {
+  const double d2r = 0.017453292519943295769;  // pi/180
+  const double oy = (u0 * unit_u) * d2r, oz = (u1 * unit_u) * d2r;
+  dq[0] = 0.5 * (-q[2] * oy - q[3] * oz);
+  dq[1] = 0.5 * (q[2] * oz - q[3] * oy);
+  dq[2] = 0.5 * (q[0] * oy - q[1] * oz);
+  dq[3] = 0.5 * (q[0] * oz + q[1] * oy);
+}
+
+}  // namespace gel
