@@ -92,23 +92,16 @@ def _preload_torch_hip_runtime():
     /opt/rocm's).  Whichever copy is mapped first serves every later user of that SONAME, and torch
     cannot initialise on top of a foreign copy ("No HIP GPUs are available").  Device pointers and
     stream handles cross between torch and this library (plumbing: memory, streams, RCCL), so both must
-    sit on the SAME runtime: if torch is installed, map its copy before libgelato_amd.so is loaded."""
-    import importlib.util
-    import sys
-    if "torch" in sys.modules:
-        return
+    sit on the SAME runtime: if torch is installed, it is imported (and its runtime initialised) before
+    libgelato_amd.so is loaded, so the library binds to torch's copy."""
+    # Importing torch first (what bench.py does) is the load order that is known to be stable; a late
+    # torch.cuda initialisation on top of an already-initialised foreign mapping was seen to deadlock.
     try:
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
-        spec = None
-    if spec is None or not spec.origin:
-        return
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
 
 
 def lib():
