@@ -64,6 +64,10 @@ SIGNATURES = {
     "gel_eval_batch": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
     "gel_eval_batch_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gel_expand_full_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gel_eval_shard_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_void_p]),
+    "gel_num_chunks": (C.c_int, [C.c_void_p, _ip]),
+    "gel_chunk_phase": (C.c_int, [C.c_void_p, _ip]),
     "gel_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gel_jac_fd": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
     "gel_dynamics_velocity": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32,

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
   const long long item = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
   if (item >= (long long)B * P.nchunks) return;
   const int b = (int)(item / P.nchunks);
-  const int2 ck = P.chunks[(int)(item - (long long)b * P.nchunks)];
+  const int2 ck = P.chunks[P.chunk0 + (int)(item - (long long)b * P.nchunks)];
   const int sec = __builtin_amdgcn_readfirstlane(ck.x);
   const int j = __builtin_amdgcn_readfirstlane(ck.y) + lane;  // node inside the phase
   const PhaseDev& ph = P.phases[sec];

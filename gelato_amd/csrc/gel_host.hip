@@ -132,6 +132,7 @@ struct gel_problem {
   std::vector<double> cval;      // [total_nnz] constants (x-dependent entries 0)
   std::vector<int32_t> src;      // [total_nnz] -1 or compact slot
   std::vector<int64_t> var_idx;  // [V] compact slot -> full index
+  std::vector<int32_t> chunk_phase;  // [nchunks] phase of every 64-node work item
   // device buffers (static)
   gel::PhaseDev* d_phases = nullptr;
   int32_t* d_node_phase = nullptr;
@@ -252,7 +253,14 @@ int upload(T** d, const std::vector<T>& h) {
   return GEL_OK;
 }
 
+#define NEED_DEVICE(p)                                                                              \
+  do {                                                                                              \
+    if ((p)->device == GEL_DEVICE_NONE)                                                             \
+      return fail(GEL_ERR_HIP, "host-only handle: nothing can be evaluated without a GPU (no CPU fallback)"); \
+  } while (0)
+
 int ensure_capacity(gel_problem* p, int B) {
+  NEED_DEVICE(p);
   if (B <= p->capB) return GEL_OK;
   HIPCHK(hipSetDevice(p->device));
   if (p->d_x) { hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv); hipHostFree(p->h_x); hipHostFree(p->h_res); hipHostFree(p->h_jv); }
@@ -339,10 +347,14 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   if (!(d->dx > 0.0)) return fail(GEL_ERR_ARG, "dx must be positive");
   for (int i = 0; i < d->num_sections; i++)
     if (d->num_nodes[i] < 2) return fail(GEL_ERR_ARG, "every phase needs >= 2 LGR nodes (nodes_LGR requires n >= 2)");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(GEL_ERR_HIP, "no HIP device: the engine has no CPU fallback");
-  if (d->device < 0 || d->device >= ndev) return fail(GEL_ERR_ARG, "device ordinal out of range");
+  // device == GEL_DEVICE_NONE: a host-only handle (dims, LGR data, sparsity pattern, constant values,
+  // work partition) that can describe the problem but never evaluate it -- there is no CPU fallback.
+  if (d->device != GEL_DEVICE_NONE) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return fail(GEL_ERR_HIP, "no HIP device: the engine has no CPU fallback");
+    if (d->device < 0 || d->device >= ndev) return fail(GEL_ERR_ARG, "device ordinal out of range");
+  }
 
   gel_problem* p = new gel_problem();
   p->device = d->device;
@@ -409,6 +421,14 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   for (int64_t s = 0; s < V; s++)
     if (p->var_idx[(size_t)s] < 0) { delete p; return fail(GEL_ERR_ARG, "internal: compact slot without a COO entry"); }
 
+  for (int i = 0; i < S; i++)
+    for (int j0 = 0; j0 < p->ph[i].n; j0 += 64) p->chunk_phase.push_back(i);
+  if (p->device == GEL_DEVICE_NONE) {
+    p->dev.nchunks = (int32_t)p->chunk_phase.size();
+    *out = p;
+    return GEL_OK;
+  }
+
   // device side
   if (hipSetDevice(p->device) != hipSuccess) { delete p; return fail(GEL_ERR_HIP, "hipSetDevice failed"); }
   std::vector<gel::PhaseDev> dph(S);
@@ -460,6 +480,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
 
 int gel_problem_destroy(gel_problem* p) {
   if (!p) return GEL_OK;
+  if (p->device == GEL_DEVICE_NONE) { delete p; return GEL_OK; }
   hipSetDevice(p->device);
   if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
   hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
@@ -543,12 +564,40 @@ int gel_eval_batch(gel_problem* p, int32_t B, const double* x, double* res, doub
 
 int gel_eval_batch_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar, void* stream) {
   if (!p || !d_x || B < 1 || (!d_res && !d_jvar)) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
   HIPCHK(gel::launch_eval(p->dev, B, d_x, d_res, d_jvar, stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
+int gel_eval_shard_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar,
+                          int32_t chunk_begin, int32_t chunk_count, void* stream) {
+  if (!p || !d_x || B < 1 || (!d_res && !d_jvar)) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  if (chunk_begin < 0 || chunk_count < 0 || chunk_begin + chunk_count > p->dev.nchunks)
+    return fail(GEL_ERR_ARG, "work-item range out of bounds");
+  if (chunk_count == 0) return GEL_OK;
+  gel::ProblemDev dv = p->dev;
+  dv.chunk0 = chunk_begin;
+  dv.nchunks = chunk_count;
+  HIPCHK(gel::launch_eval(dv, B, d_x, d_res, d_jvar, stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
+int gel_num_chunks(const gel_problem* p, int32_t* nchunks) {
+  if (!p || !nchunks) return fail(GEL_ERR_ARG, "null argument");
+  *nchunks = (int32_t)p->chunk_phase.size();
+  return GEL_OK;
+}
+
+int gel_chunk_phase(const gel_problem* p, int32_t* phase) {
+  if (!p || !phase) return fail(GEL_ERR_ARG, "null argument");
+  std::memcpy(phase, p->chunk_phase.data(), p->chunk_phase.size() * sizeof(int32_t));
   return GEL_OK;
 }
 
 int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream) {
   if (!p || !d_jvar || !d_jfull || B < 1) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
   HIPCHK(gel::launch_expand(p->dims.total_nnz, p->dims.num_var_entries, B, p->d_cval, p->d_src, d_jvar, d_jfull,
                             stream ? (hipStream_t)stream : p->stream));
   return GEL_OK;
@@ -556,6 +605,7 @@ int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, doub
 
 int gel_sync(gel_problem* p, void* stream) {
   if (!p) return fail(GEL_ERR_ARG, "null argument");
+  NEED_DEVICE(p);
   hipStream_t s = stream ? (hipStream_t)stream : p->stream;
   HIPCHK(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -570,6 +620,7 @@ int gel_sync(gel_problem* p, void* stream) {
 
 int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) {
   if (!p || !x || !J || group < 0 || group >= GEL_NUM_GROUPS) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
   HIPCHK(hipSetDevice(p->device));
   const int nv = p->dims.num_vars, nres = 11 * p->dims.N, nrows = p->dims.num_rows[group];
   const int roff = (group == 0) ? 0 : (group == 1) ? p->dims.N : (group == 2) ? 4 * p->dims.N : 7 * p->dims.N;

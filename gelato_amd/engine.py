@@ -62,6 +62,8 @@ class Engine:
 
         wind, ca = _f64(prob["wind_table"]), _f64(prob["ca_table"])
         units = _f64(prob["units"])
+        self.prob = {k: np.array(prob[k]) for k in ("num_nodes", "thrust", "massflow", "reference_area", "nozzle_area",
+                                                    "engine_on", "attitude_hold")}
         d = GelProblemDesc()
         d.num_sections = S
         d.num_nodes = nn.ctypes.data_as(_ip)
@@ -205,6 +207,21 @@ class Engine:
 
     def sync(self, stream=0):
         return check(lib().gel_sync(self._h, stream or None))
+
+    # work items (one 64-node chunk of one phase each) for phase-sharded multi-GPU evaluation
+    def num_chunks(self):
+        n = C.c_int32()
+        check(lib().gel_num_chunks(self._h, C.byref(n)))
+        return n.value
+
+    def chunk_phase(self):
+        out = np.zeros(self.num_chunks(), dtype=np.int32)
+        check(lib().gel_chunk_phase(self._h, out.ctypes.data_as(_ip)))
+        return out
+
+    def eval_shard_device(self, B, d_x, d_res, d_jvar, chunk_begin, chunk_count, stream=0):
+        check(lib().gel_eval_shard_device(self._h, B, d_x, d_res or None, d_jvar or None, int(chunk_begin),
+                                          int(chunk_count), stream or None))
 
     def jac_fd(self, group, x):
         gi = GROUPS.index(group)

@@ -1,0 +1,208 @@
+"""CPU-only: (1) the engine's host-side sparsity pattern / constant values / compact index map against
+the reference goldens and the oracle (bit-exact for int32 indices and for constant entries), through a
+host-only handle (device = GEL_DEVICE_NONE, which can describe but never evaluate); (2) the multi-GPU
+plumbing (gelato_amd.parallel) in a real world_size-2 `gloo` run, with the oracle standing in for the
+GPU evaluator of each rank."""
+import hashlib
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import D_tau_from_golden, ROOT, load_golden, problem_from_golden
+
+import oracle
+from gelato_amd import Engine, _lib, parallel
+from gelato_amd.engine import BLOCKS
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def host_engine(prob, D=None, tau=None):
+    return Engine(prob, D=D, tau=tau, device=-1)
+
+
+@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64"])
+def test_pattern_bit_exact_vs_reference_golden(name):
+    g = load_golden("g6_%s.npz" % name)
+    prob = problem_from_golden(g)
+    D, tau = D_tau_from_golden(g, prob)
+    E = host_engine(prob, D, tau)
+    pat = E.pattern()
+    cv = E.const_values()
+    vidx = E.var_index()
+    is_var = np.zeros(E.total_nnz, dtype=bool)
+    is_var[vidx] = True
+    assert len(np.unique(vidx)) == E.V                                   # one COO entry per compact slot
+    for b, (grp, var) in enumerate(BLOCKS):
+        key = "jac_%s_%s" % (grp, var)
+        r, c = pat[b]
+        assert r.dtype == np.int32 and c.dtype == np.int32
+        assert int(g[key + "_nnz"]) == len(r) == E.block_nnz[b]
+        assert tuple(g[key + "_shape"]) == E.block_shape[b]
+        assert str(g[key + "_rows_sha"]) == sha(r) and str(g[key + "_cols_sha"]) == sha(c), key
+        if key + "_rows" in g:
+            assert np.array_equal(r, g[key + "_rows"]) and np.array_equal(c, g[key + "_cols"])
+        if key + "_vals" in g:                                          # constants: D / 0 / +-1 / massflow, bit for bit
+            ref = g[key + "_vals"]
+            m = ~is_var[E.block_off[b]:E.block_off[b + 1]]
+            assert np.array_equal(cv[E.block_off[b]:E.block_off[b + 1]][m], ref[m]), key
+    assert np.all(cv[is_var] == 0.0)
+
+
+def test_pattern_matches_oracle_on_ragged_problem():
+    g = load_golden("g6_example.npz")
+    prob = dict(problem_from_golden(g))
+    prob["num_nodes"] = np.array([2, 3, 100, 2, 17, 64, 5], dtype=np.int32)
+    prob["thrust"] = np.array([420000.0, 0.0, 420000.0, 30700.0, 0.0, 30700.0, 1000.0])
+    prob["massflow"] = np.array([140.0, 0.0, 140.0, 9.8, 0.0, 9.8, 0.3])
+    prob["reference_area"] = np.array([2.21, 2.21, 2.21, 0.0, 0.0, 2.21, 0.0])
+    prob["nozzle_area"] = np.array([0.68, 0.0, 0.68, 0.0, 0.0, 0.1, 0.0])
+    prob["engine_on"] = np.array([1, 0, 1, 1, 0, 1, 1], dtype=np.int32)
+    prob["attitude_hold"] = np.array([1, 0, 0, 1, 1, 0, 0], dtype=np.int32)
+    P = oracle.Problem(prob)
+    E = host_engine(prob, [P.D(i) for i in range(P.S)], [P.tau(i) for i in range(P.S)])
+    x = np.random.default_rng(3).random(P.nvars) + 0.5
+    pat = E.pattern()
+    b = 0
+    for grp in oracle.GROUPS:
+        Jo = P.jacobian(grp, x)
+        for var in oracle.BLOCK_VARS[grp]:
+            r, c = pat[b]
+            assert np.array_equal(r, Jo[var]["coo"][0]) and np.array_equal(c, Jo[var]["coo"][1]), (grp, var)
+            assert E.block_shape[b] == Jo[var]["shape"]
+            b += 1
+    assert E.num_chunks() == 1 + 1 + 2 + 1 + 1 + 1 + 1
+    assert list(E.chunk_phase()) == [0, 1, 2, 2, 3, 4, 5, 6]
+
+
+def test_host_only_handle_cannot_evaluate():
+    g = load_golden("g6_3x32.npz")
+    E = host_engine(problem_from_golden(g))
+    assert E.nvars == 1285 and E.nres == 1056 and E.algorithmic_bytes == 8 * (1285 + 1056 + E.V)
+    with pytest.raises(_lib.GelatoAmdError, match="host-only"):
+        E.eval_residual(g["x"])
+    with pytest.raises(_lib.GelatoAmdError, match="host-only"):
+        E.eval_batch_device(1, 1, 1, 1)
+    with pytest.raises(_lib.GelatoAmdError, match="host-only"):
+        E.jac_fd("mass", g["x"])
+
+
+def test_algorithmic_bytes_match_survey():
+    from gelato_amd import con_dynamics, problem
+    for name, a_min in [("dense-6x64", 320072), ("3x32", None)]:
+        pdict, unitdict, _, _ = problem.make_problem(name)
+        E = host_engine(con_dynamics.problem_arrays(pdict, unitdict))
+        if a_min:
+            assert E.algorithmic_bytes == a_min and E.total_nnz == 745728
+        assert E.algorithmic_bytes == 8 * (E.nvars + E.nres + E.V)
+
+
+# --------------------------------------------------------------------------
+def test_replica_and_chunk_partitions():
+    for total, world in [(4096, 8), (10, 3), (3, 8), (1, 1)]:
+        rs = [parallel.replica_range(total, r, world) for r in range(world)]
+        assert rs[0][0] == 0 and rs[-1][1] == total
+        assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in rs]
+        assert max(sizes) - min(sizes) <= 1
+    costs = np.array([10.5, 10.5, 10.5, 10.5, 10.0, 2.0])
+    for world in [1, 2, 3, 4, 6, 8]:
+        sh = parallel.shard_chunks(costs, world)
+        assert len(sh) == world and sh[0][0] == 0 and sum(c for _, c in sh) == len(costs)
+        assert all(sh[i][0] + sh[i][1] == sh[i + 1][0] for i in range(world - 1))
+    assert parallel.shard_chunks(costs, 2) == [(0, 3), (3, 3)]
+
+
+WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from conftest import load_golden, problem_from_golden
+import oracle
+from gelato_amd import Engine, parallel
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = load_golden("g6_3x32.npz")
+prob = problem_from_golden(g)
+P = oracle.Problem(prob)
+E = Engine(prob, D=[P.D(i) for i in range(P.S)], tau=[P.tau(i) for i in range(P.S)], device=-1)
+x = g["x"]
+
+# ---- phase-shard mode: each rank "evaluates" only its work items (oracle as the stand-in evaluator) ----
+ranges = parallel.shard_chunks(parallel.chunk_costs(E), world)
+full_res = np.concatenate([P.residual(grp, x) for grp in oracle.GROUPS])
+vals = np.concatenate([np.concatenate([b["coo"][2] for b in P.jacobian(grp, x).values()]) for grp in oracle.GROUPS])
+full_jv = vals[E.var_index()]
+ph_of_chunk = E.chunk_phase()
+nn = prob["num_nodes"]; ua = np.concatenate([[0], np.cumsum(nn)[:-1]])
+# recover the phase owning each compact slot from the COO row (= collocation node) of its entry
+pat = E.pattern()
+rows_all = np.concatenate([r // k for (r, c), k in zip(pat, [1,1,3,3,3,3,3,3,3,3,4,4,4])])
+node_of_slot = rows_all[E.var_index()]
+phase_of_node = np.repeat(np.arange(len(nn)), nn)
+
+def evaluate_range(begin, count, res, jvar):
+    mine = set(ph_of_chunk[begin:begin + count].tolist())
+    N = E.N
+    for grp, k, o in [("mass", 1, 0), ("pos", 3, N), ("vel", 3, 4 * N), ("quat", 4, 7 * N)]:
+        for i in mine:
+            lo, hi = o + k * ua[i], o + k * (ua[i] + nn[i])
+            res[lo:hi] = torch.from_numpy(full_res[lo:hi])
+    sel = np.isin(phase_of_node[node_of_slot], list(mine))
+    jvar[torch.from_numpy(sel)] = torch.from_numpy(full_jv[sel])
+
+res = torch.full((E.nres,), 7.0, dtype=torch.float64)
+jv = torch.full((E.V,), 7.0, dtype=torch.float64)
+parallel.phase_sharded_eval(evaluate_range, res, jv, ranges, rank)
+assert np.array_equal(res.numpy(), full_res), "residual after all-reduce"
+assert np.array_equal(jv.numpy(), full_jv), "jacobian after all-reduce"
+
+# ---- replica mode: vectors split across ranks, slowest rank defines the time ----
+B = 5
+lo, hi = parallel.replica_range(B, rank, world)
+X = np.tile(x, (B, 1)) * (1 + 1e-7 * np.arange(B))[:, None]
+mine, _ = P.eval_batch(X[lo:hi])
+gathered = [None] * world
+dist.all_gather_object(gathered, (lo, hi, mine))
+allres = np.concatenate([m for _, _, m in sorted(gathered, key=lambda t: t[0])])
+ref, _ = P.eval_batch(X)
+assert np.array_equal(allres, ref)
+tmax = parallel.max_over_ranks(1.0 + rank)
+assert tmax == float(world)
+dist.destroy_process_group()
+print("WORKER_OK", rank)
+"""
+
+
+def test_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "WORKER_OK %d" % r in out, out[-3000:]
