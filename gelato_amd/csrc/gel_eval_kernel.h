@@ -25,8 +25,12 @@ enum ParkSlot { PK_Q0 = 0, PK_Q1, PK_Q2, PK_Q3, PK_V0, PK_V1, PK_V2, PK_ME, PK_U
                 PK_LV0, PK_LV1, PK_LV2, PK_LQ0, PK_LQ1, PK_LQ2, PK_LQ3, PK_COUNT };
 constexpr int kTablePad = 128;  // doubles reserved for the staged tables in front of the park (checked on host)
 
+#ifndef GEL_MIN_WAVES_PER_SIMD
+#define GEL_MIN_WAVES_PER_SIMD 3  // 147 VGPRs fit 3 waves/SIMD without spilling; 4 would spill to scratch
+#endif
+
 template <bool JAC>
-__global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
+__global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   extern __shared__ double lds[];
   const Tables tb = stage_tables(P, lds);
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
 #pragma unroll
         for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
         pp = pos_part(r, tb, P.barC20);
-        wind_eci(r, ea, pp.lat, pp.wn, pp.we, w);
+        wind_eci(r, ea, pp.shp, pp.chp, pp.wn, pp.we, w);
         aero_force(r, v, pp.rho, pp.a, ea, w, ph.area, tb, F);
         T = ph.thrust - ph.nozzle * pp.P;
         const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(ProblemDev P, int B, const
             const double tnp = tau * (tf_p - to_p) / 2 + (tf_p + to_p) / 2;
             const EarthAngle eq = earth_angle(tnp);
             double wq[3], Fp[3];
-            wind_eci(r, eq, pp.lat, pp.wn, pp.we, wq);
+            wind_eci(r, eq, pp.shp, pp.chp, pp.wn, pp.we, wq);
             aero_force(r, v, pp.rho, pp.a, eq, wq, ph.area, tb, Fp);
             accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
             // -(f_p*(tf_p - to_p) - f_c*(tf - to))/dx*unit_t/2   (con_dynamics.py:463-477)

@@ -316,6 +316,10 @@ void fill_atmosphere_table(double* atm) {
     atm[11 + k] = tmb[k];
     atm[22 + k] = pb[k];
     atm[33 + k] = 8314.32 / mb[k];  // Rstar / mb[k], src/Air.cpp:67
+    // the two per-layer constants of Air::pressure (src/Air.cpp:93-97), reference operation order
+    const double R = atm[33 + k], g0 = 9.80665;
+    atm[44 + k] = (std::fabs(lmb[k]) > 1.0e-6) ? (-g0 / lmb[k] / R) : 0.0;
+    atm[55 + k] = g0 / R;
   }
 }
 }  // namespace gel
@@ -446,10 +450,10 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     tau.insert(tau.end(), h.tau.begin(), h.tau.end());
     for (int j = 0; j < h.n; j++) node_phase[h.ua + j] = i;
   }
-  std::vector<double> tables(44 + 3 * (size_t)d->wind_rows + 2 * (size_t)d->ca_rows);
+  std::vector<double> tables(gel::kAtmTableDoubles + 3 * (size_t)d->wind_rows + 2 * (size_t)d->ca_rows);
   gel::fill_atmosphere_table(tables.data());
-  std::memcpy(tables.data() + 44, d->wind_table, sizeof(double) * 3 * d->wind_rows);
-  std::memcpy(tables.data() + 44 + 3 * d->wind_rows, d->ca_table, sizeof(double) * 2 * d->ca_rows);
+  std::memcpy(tables.data() + gel::kAtmTableDoubles, d->wind_table, sizeof(double) * 3 * d->wind_rows);
+  std::memcpy(tables.data() + gel::kAtmTableDoubles + 3 * d->wind_rows, d->ca_table, sizeof(double) * 2 * d->ca_rows);
   std::vector<int2> chunks;
   for (int i = 0; i < S; i++)
     for (int j0 = 0; j0 < p->ph[i].n; j0 += 64) chunks.push_back(make_int2(i, j0));
@@ -676,10 +680,10 @@ int gel_dynamics_velocity(int32_t n, const double* mass_e, const double* pos_e, 
   if (n == 0) return GEL_OK;
   int rc = need_device();
   if (rc) return rc;
-  std::vector<double> tables(44 + 3 * (size_t)Kw + 2 * (size_t)Kc);
+  std::vector<double> tables(gel::kAtmTableDoubles + 3 * (size_t)Kw + 2 * (size_t)Kc);
   gel::fill_atmosphere_table(tables.data());
-  std::memcpy(tables.data() + 44, wind, sizeof(double) * 3 * Kw);
-  std::memcpy(tables.data() + 44 + 3 * Kw, ca, sizeof(double) * 2 * Kc);
+  std::memcpy(tables.data() + gel::kAtmTableDoubles, wind, sizeof(double) * 3 * Kw);
+  std::memcpy(tables.data() + gel::kAtmTableDoubles + 3 * Kw, ca, sizeof(double) * 2 * Kc);
   DevBuf m, r, v, q, tt, tb, o;
   if ((rc = m.put(mass_e, n)) || (rc = r.put(pos_e, 3 * (size_t)n)) || (rc = v.put(vel_e, 3 * (size_t)n)) ||
       (rc = q.put(quat, 4 * (size_t)n)) || (rc = tt.put(t, n)) || (rc = tb.put(tables.data(), tables.size())) ||
@@ -727,10 +731,10 @@ int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux,
   if (n == 0) return GEL_OK;
   int rc = need_device();
   if (rc) return rc;
-  double atm[44];
+  double atm[gel::kAtmTableDoubles];
   size_t naux = 0;
   const double* hax = aux;
-  if (kind == 0) { gel::fill_atmosphere_table(atm); hax = atm; naux = 44; aux_rows = 0; }
+  if (kind == 0) { gel::fill_atmosphere_table(atm); hax = atm; naux = gel::kAtmTableDoubles; aux_rows = 0; }
   else if (kind == 2) { if (!aux) return fail(GEL_ERR_ARG, "kind 2 needs aux[0] = barC20"); naux = 1; aux_rows = 0; }
   else if (kind == 5) { if (!aux || aux_rows < 2) return fail(GEL_ERR_ARG, "kind 5 needs a wind table"); naux = 3 * (size_t)aux_rows; }
   else if (kind == 6) { if (!aux || aux_rows < 2) return fail(GEL_ERR_ARG, "kind 6 needs a table"); naux = 2 * (size_t)aux_rows; }

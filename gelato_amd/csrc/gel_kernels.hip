@@ -26,6 +26,7 @@
 namespace gel {
 
 constexpr int kBlock = 256;
+static_assert(kAtmDoubles == kAtmTableDoubles, "atmosphere table size mismatch between host and device");
 
 GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds) {
   const int ntab = kAtmDoubles + 3 * P.Kw + 2 * P.Kc;
@@ -128,7 +129,7 @@ __global__ void rhs_vel_air_kernel(RhsArgs A) {
   const PosPart pp = pos_part(r, tb, A.barC20);
   const EarthAngle ea = earth_angle(A.t[i]);
   double w[3], F[3], dir[3], f[3];
-  wind_eci(r, ea, pp.lat, pp.wn, pp.we, w);
+  wind_eci(r, ea, pp.shp, pp.chp, pp.wn, pp.we, w);
   aero_force(r, v, pp.rho, pp.a, ea, w, A.area, tb, F);
   thrust_dir(q, dir);
   const double T = A.thrust - A.nozzle * pp.P;
@@ -192,7 +193,9 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       double lat, p, w[3];
       geodetic_lat_p(r[0], r[1], r[2], lat, p);
       const EarthAngle ea = earth_angle(a[3]);
-      wind_eci(r, ea, lat, a[4], a[5], w);
+      double shp, chp;
+      sincos(lat / 2.0, &shp, &chp);
+      wind_eci(r, ea, shp, chp, a[4], a[5], w);
       out[3 * i] = w[0]; out[3 * i + 1] = w[1]; out[3 * i + 2] = w[2];
     } break;
     case 4: {

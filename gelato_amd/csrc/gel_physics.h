@@ -27,14 +27,16 @@ constexpr double kEp2 = (kRa * kRa - kRb * kRb) / kRb / kRb;
 constexpr double kPi = 3.14159265358979323846;
 
 // LDS-resident tables: US-1976 layers (src/Air.cpp:31-45) + wind + CA.
-// atm is [4][11]: Lmb, Tmb, Pb, R (= Rstar / mb, src/Air.cpp:67).
+// atm is [6][11]: Lmb, Tmb, Pb, R (= Rstar / mb, src/Air.cpp:67), and the two per-layer constants of the
+// pressure formula (src/Air.cpp:93-97) precomputed on the host with the reference's own operation
+// order: pexp = -g0 / Lmb / R (lapse layers), gR = g0 / R (isothermal layers).
 struct Tables {
   const double* atm;
   const double* wind;  // [Kw][3]
   const double* ca;    // [Kc][2]
   int Kw, Kc;
 };
-constexpr int kAtmDoubles = 44;
+constexpr int kAtmDoubles = 66;
 
 // ---------------------------------------------------------------------------
 // US Standard Atmosphere 1976.  One layer search serves T, P, rho and a; the
@@ -73,7 +75,7 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
   const int k = us76_layer(h);
   const double Hb = us76_hb(k);
   const double Lmb = atm[k], Tmb = atm[11 + k], Pb = atm[22 + k], R = atm[33 + k];
-  const double r0 = 6356766.0, g0 = 9.80665;
+  const double r0 = 6356766.0;
   Air o;
   // temperature: src/Air.cpp:71-88
   if (h <= 91000.0) {
@@ -90,11 +92,11 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
   }
   // pressure: src/Air.cpp:90-98
   if (fabs(Lmb) > 1.0e-6) {
-    o.P = Pb * pow((Tmb + Lmb * (h - Hb)) / Tmb, -g0 / Lmb / R);
+    o.P = Pb * pow((Tmb + Lmb * (h - Hb)) / Tmb, atm[44 + k]);   // exponent -g0/Lmb/R from the table
   } else {
-    o.P = Pb * exp(g0 / R * (Hb - h) / Tmb);
+    o.P = Pb * exp(atm[55 + k] * (Hb - h) / Tmb);                 // g0/R from the table
   }
-  o.rho = o.P / R / o.T;        // src/Air.cpp:100-105
+  o.rho = o.P / (R * o.T);      // src/Air.cpp:100-105 (P/R/T)
   o.a = sqrt(1.4 * R * o.T);    // src/Air.cpp:107-111
   return o;
 }
@@ -102,12 +104,22 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
 // ---------------------------------------------------------------------------
 // geodesy: src/Earth.cpp:49-61 (Bowring one step)
 // ---------------------------------------------------------------------------
+// theta = atan2(z Ra, p Rb) is only used through sin(theta), cos(theta): they are formed algebraically
+// (a/h, b/h with h = hypot(a, b)), identical up to rounding to sincos(atan2(a, b)).
 GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p) {
   p = sqrt(x * x + y * y);
-  const double theta = atan2(z * kRa, p * kRb);
-  double st, ct;
-  sincos(theta, &st, &ct);
+  const double a = z * kRa, b = p * kRb;
+  const double h = sqrt(a * a + b * b);
+  const double ih = 1.0 / h;
+  const double st = (h > 0.0) ? a * ih : 0.0;
+  const double ct = (h > 0.0) ? b * ih : 1.0;
   lat = atan2(z + kEp2 * kRb * (st * st * st), p - kE2 * kRa * (ct * ct * ct));
+}
+
+// altitude from (p, sin lat, cos lat): src/Earth.cpp:58-59
+GEL_DEV double geodetic_alt_from(double p, double sl, double cl) {
+  const double N = kRa / sqrt(1.0 - kE2 * sl * sl);
+  return p / cl - N;
 }
 
 GEL_DEV double geodetic_altitude(double x, double y, double z) {
@@ -115,8 +127,7 @@ GEL_DEV double geodetic_altitude(double x, double y, double z) {
   geodetic_lat_p(x, y, z, lat, p);
   double sl, cl;
   sincos(lat, &sl, &cl);
-  const double N = kRa / sqrt(1.0 - kE2 * sl * sl);
-  return p / cl - N;
+  return geodetic_alt_from(p, sl, cl);
 }
 
 GEL_DEV void geodetic_full(double x, double y, double z, double& lat, double& lon, double& alt) {
@@ -138,13 +149,14 @@ GEL_DEV void gravity_eci(const double r3[3], double barC20, double g[3]) {
   const double x = r3[0], y = r3[1], z = r3[2];
   double r = sqrt(x * x + y * y + z * z);
   double irx = 0.0, iry = 0.0, irz = 0.0;
-  if (r != 0.0) { irx = x / r; iry = y / r; irz = z / r; }
+  double inv_r = 1.0 / r;  // one reciprocal serves x/r, y/r, z/r, a/r, mu/r^2 (each <= 1 ulp from the division)
+  if (r != 0.0) { irx = x * inv_r; iry = y * inv_r; irz = z * inv_r; }
   const double s5 = 2.23606797749978969641;  // sqrt(5.0)
   const double barP20 = s5 * (3.0 * irz * irz - 1.0) * 0.5;
   const double barP20d = s5 * 3.0 * irz;
-  if (r < b) r = b;
-  const double mur2 = mu / (r * r);
-  const double ar = a / r;
+  if (r < b) { r = b; inv_r = 1.0 / b; }
+  const double mur2 = mu * (inv_r * inv_r);
+  const double ar = a * inv_r;
   const double g_ir = -mur2 * (1.0 + barC20 * ar * ar * (3.0 * barP20 + irz * barP20d));
   const double g_iz = mur2 * ar * ar * barC20 * barP20d;
   g[0] = g_ir * irx;

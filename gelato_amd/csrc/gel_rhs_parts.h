@@ -22,18 +22,23 @@ struct PosPart {
   double rho, P, a;  // atmosphere at the node
   double wn, we;     // wind, NED
   double g[3];       // gravity, ECI
-  double lat;        // geodetic latitude [rad] of the position
+  double shp, chp;   // sin, cos of half the geodetic latitude (for the NED quaternion)
 };
 
 GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
   PosPart o;
   // the reference feeds the ECI position to ecef2geodetic for altitude (src/pybind_dynamics.cpp:43)
-  double p;
-  geodetic_lat_p(r[0], r[1], r[2], o.lat, p);
+  double lat, p;
+  geodetic_lat_p(r[0], r[1], r[2], lat, p);
+  // sin/cos(lat) at full libm accuracy for the altitude (p/cos(lat) - N cancels 6.4e6 m down to the
+  // altitude, and that round-off is what the position sweeps difference); the half-angle pair of the
+  // NED quaternion (src/Coordinate.cpp:89-90) only rotates the <= 30 m/s wind, so it is derived from
+  // them algebraically: cos(lat/2) = sqrt((1+cos lat)/2) (cos lat >= 0), sin(lat/2) = sin lat/(2 cos(lat/2)).
   double sl, cl;
-  sincos(o.lat, &sl, &cl);
-  const double Nn = kRa / sqrt(1.0 - kE2 * sl * sl);
-  const double alt = p / cl - Nn;
+  sincos(lat, &sl, &cl);
+  o.chp = sqrt(0.5 * (1.0 + cl));
+  o.shp = 0.5 * sl / o.chp;
+  const double alt = geodetic_alt_from(p, sl, cl);
   const double h = geopotential_altitude(alt);
   const Air air = atmosphere(h, tb.atm);
   o.rho = air.rho; o.P = air.P; o.a = air.a;
@@ -57,15 +62,15 @@ GEL_DEV EarthAngle earth_angle(double t) {
 // The reference re-runs the Bowring latitude on the rotated position (Coordinate.cpp:86); a rotation
 // about z leaves (sqrt(x^2+y^2), z) and therefore the latitude unchanged, so pos_part's latitude is
 // reused (equal to a recomputation up to rounding).  The longitude IS taken from the rotated position.
-GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double lat, double wn, double we, double w[3]) {
+GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double s_hp, double c_hp, double wn, double we,
+                      double w[3]) {
   // eci2ecef(pos, t): src/Coordinate.cpp:51-59
   const double px = r[0] * e.c + r[1] * e.s;
   const double py = -r[0] * e.s + r[1] * e.c;
   const double lon = atan2(py, px);
   // quat_ecef2ned: src/Coordinate.cpp:85-98
-  double s_hl, c_hl, s_hp, c_hp;
+  double s_hl, c_hl;
   sincos(lon / 2.0, &s_hl, &c_hl);
-  sincos(lat / 2.0, &s_hp, &c_hp);
   const double irt2 = 0.70710678118654752440;  // 1/sqrt(2)
   const double b0 = c_hl * (c_hp - s_hp) * irt2, b1 = s_hl * (c_hp + s_hp) * irt2;
   const double b2 = -c_hl * (c_hp + s_hp) * irt2, b3 = s_hl * (c_hp - s_hp) * irt2;
