@@ -20,37 +20,49 @@
 
 namespace gel {
 
-// per-lane LDS park: slot-major so that consecutive lanes hit consecutive banks
+// per-lane LDS park, one region per wavefront ([slot][lane]: consecutive lanes hit consecutive banks).
+// The MFMA D.X path first uses the wave's region as the 64 x 17 staging tile of its result.
 enum ParkSlot { PK_Q0 = 0, PK_Q1, PK_Q2, PK_Q3, PK_V0, PK_V1, PK_V2, PK_ME, PK_U0, PK_U1, PK_DJJ,
                 PK_LV0, PK_LV1, PK_LV2, PK_LQ0, PK_LQ1, PK_LQ2, PK_LQ3, PK_COUNT };
-constexpr int kTablePad = 128;  // doubles reserved for the staged tables in front of the park (checked on host)
+constexpr int kStageLd = 17;                     // padded row of the staging tile: conflict-free row reads
+constexpr int kWaveLds = PK_COUNT * 64;          // doubles per wavefront
+static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wave's park region");
 
 #ifndef GEL_MIN_WAVES_PER_SIMD
-#define GEL_MIN_WAVES_PER_SIMD 3  // 147 VGPRs fit 3 waves/SIMD without spilling; 4 would spill to scratch
+#define GEL_MIN_WAVES_PER_SIMD 3  // ~150 VGPRs fit 3 waves/SIMD without spilling; forcing 4 spills and is slower
 #endif
 
-template <bool JAC>
+typedef double gel_double4 __attribute__((ext_vector_type(4)));
+
+// JAC: also the FD Jacobian.  MFMA: D.X on the matrix pipe (v_mfma_f64_16x16x4_f64) instead of VALU FMAs.
+template <bool JAC, bool MFMA>
 __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   extern __shared__ double lds[];
   const Tables tb = stage_tables(P, lds);
+  const int lane = threadIdx.x & 63;
   // explicit LDS address space: ds_read/ds_write (lgkmcnt), never flat_* (which also ticks vmcnt)
   typedef __attribute__((address_space(3))) double lds_double;
-  lds_double* park = (lds_double*)lds + P.park_off + threadIdx.x;
-#define PARK(slot) park[(slot) * kBlock]
+  lds_double* wave_lds = (lds_double*)lds + P.park_off + (threadIdx.x >> 6) * kWaveLds;
+  lds_double* park = wave_lds + lane;
+#define PARK(slot) park[(slot) * 64]
 
-  const int lane = threadIdx.x & 63;
   const long long item = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
   if (item >= (long long)B * P.nchunks) return;
   const int b = (int)(item / P.nchunks);
   const int2 ck = P.chunks[P.chunk0 + (int)(item - (long long)b * P.nchunks)];
   const int sec = __builtin_amdgcn_readfirstlane(ck.x);
-  const int j = __builtin_amdgcn_readfirstlane(ck.y) + lane;  // node inside the phase
+  const int j0 = __builtin_amdgcn_readfirstlane(ck.y);
+  const int j = j0 + lane;  // node inside the phase
   const PhaseDev& ph = P.phases[sec];
   const int n = ph.n;
-  if (j >= n) return;
+  // the matrix pipe reads all 64 lanes: lanes past the end of a ragged phase stay alive (with zero
+  // operands and clamped addresses) until the D.X product is done
+  const bool active = j < n;
+  if (!MFMA && !active) return;
+  const int jc = active ? j : n - 1;  // clamped node for address formation
   const int g = ph.ua + j;       // global collocation node
-  const int xj = ph.xa + 1 + j;  // its state row (x-node j+1)
+  const int xj = ph.xa + 1 + jc;  // its state row (x-node j+1)
   const int M = P.M, N = P.N;
 
   const double* xb = x + (size_t)b * P.nvars;
@@ -83,37 +95,91 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   // ======================= phase A: every global load =======================
   const double me = xm[xj];
   const double re[3] = {xr[3 * xj], xr[3 * xj + 1], xr[3 * xj + 2]};
-  const double tau = P.tau[ph.toff + j];
+  const double tau = P.tau[ph.toff + jc];
   double dir[3];
   {
     const double q[4] = {xq[4 * xj], xq[4 * xj + 1], xq[4 * xj + 2], xq[4 * xj + 3]};
     const double ve[3] = {xv[3 * xj], xv[3 * xj + 1], xv[3 * xj + 2]};
     thrust_dir(q, dir);
+    double u0 = 0.0, u1 = 0.0;
+    if (!ph.hold) { u0 = xu[2 * (ph.ua + jc)]; u1 = xu[2 * (ph.ua + jc) + 1]; }
+    const double djj = JAC ? P.Dt[ph.doff + (size_t)(jc + 1) * n + jc] : 0.0;  // D[j][j+1]
+
+    // D.X rows (lib/con_dynamics.py:54,146,256,524)
+    double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
+    if (rb) {
+      if (MFMA) {
+        // [64 x (n+1)] . [(n+1) x 11] per wavefront as 4 row tiles of v_mfma_f64_16x16x4_f64.
+        // Operand layout (cdna_hip_programming.md section 3): A lane l = A[row l&15][k l>>4],
+        // B lane l = B[k l>>4][col l&15], C/D reg i of lane l = C[row (l>>4)+4i][col l&15].
+        const int c16 = lane & 15, kq = lane >> 4;
+        // column c16 of X = one of the 11 interleaved state columns (mass | pos xyz | vel xyz | quat wxyz)
+        const double* bp = xm + ph.xa;
+        int bs = 1;
+        if (c16 >= 1 && c16 < 4) { bp = xr + 3 * ph.xa + (c16 - 1); bs = 3; }
+        if (c16 >= 4 && c16 < 7) { bp = xv + 3 * ph.xa + (c16 - 4); bs = 3; }
+        if (c16 >= 7) { bp = xq + 4 * ph.xa + ((c16 < 11) ? (c16 - 7) : 0); bs = 4; }
+        gel_double4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = gel_double4{0.0, 0.0, 0.0, 0.0};
+        const double* Dt = P.Dt + ph.doff;
+        // Only the B operand is zeroed for k > n: rows of nodes >= n and columns >= 11 are computed on
+        // clamped (finite) data and never read back, so A needs no masking at all.
+        unsigned offA[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) offA[t] = (unsigned)min(j0 + 16 * t + c16, n - 1);
+        const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4)
+        const unsigned un = (unsigned)n, ubs = (unsigned)bs;
+        for (int ks = 0; ks < ksteps; ks++) {
+          const unsigned k = 4u * ks + kq;
+          const bool kv = k <= un;
+          const unsigned kc = kv ? k : un;
+          const double bl = bp[kc * ubs];
+          const double bv = kv ? bl : 0.0;
+          const unsigned ko = kc * un;
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Dt[ko + offA[t]], bv, acc[t], 0, 0, 0);
+        }
+        // transpose through the wave's LDS region: tile -> one row (node) per lane
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) wave_lds[(16 * t + kq + 4 * i) * kStageLd + c16] = acc[t][i];
+        lds_double* row = wave_lds + lane * kStageLd;
+        lm = row[0];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
+#pragma unroll
+        for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
+      } else {
+        // lane j reads consecutive Dt addresses; the X rows are wave-uniform -> scalar loads feeding
+        // v_fma_f64 as SGPR operands
+        const double* Dt = P.Dt + ph.doff + j;
+        const double* pm = xm + ph.xa;
+        const double* pr = xr + 3 * ph.xa;
+        const double* pv = xv + 3 * ph.xa;
+        const double* pq = xq + 4 * ph.xa;
+        for (int i = 0; i <= n; i++) {
+          const double d = Dt[(size_t)i * n];
+          lm += d * pm[i];
+#pragma unroll
+          for (int c = 0; c < 3; c++) lr[c] += d * pr[3 * i + c];
+#pragma unroll
+          for (int c = 0; c < 3; c++) lv[c] += d * pv[3 * i + c];
+#pragma unroll
+          for (int c = 0; c < 4; c++) lq[c] += d * pq[4 * i + c];
+        }
+      }
+    }
+    if (MFMA && !active) return;  // ragged tail: nothing to write
+    // the staging tile has been consumed: the region now becomes the park
     PARK(PK_Q0) = q[0]; PARK(PK_Q1) = q[1]; PARK(PK_Q2) = q[2]; PARK(PK_Q3) = q[3];
     PARK(PK_V0) = ve[0]; PARK(PK_V1) = ve[1]; PARK(PK_V2) = ve[2];
     PARK(PK_ME) = me;
-    if (!ph.hold) { PARK(PK_U0) = xu[2 * g]; PARK(PK_U1) = xu[2 * g + 1]; }
-    if (JAC) PARK(PK_DJJ) = P.Dt[ph.doff + (size_t)(j + 1) * n + j];  // D[j][j+1]
-
-    // D.X rows (lib/con_dynamics.py:54,146,256,524): lane j reads consecutive Dt addresses,
-    // the X rows are wave-uniform -> scalar loads feeding v_fma_f64 as SGPR operands
+    if (!ph.hold) { PARK(PK_U0) = u0; PARK(PK_U1) = u1; }
+    if (JAC) PARK(PK_DJJ) = djj;
     if (rb) {
-      double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
-      const double* Dt = P.Dt + ph.doff + j;
-      const double* pm = xm + ph.xa;
-      const double* pr = xr + 3 * ph.xa;
-      const double* pv = xv + 3 * ph.xa;
-      const double* pq = xq + 4 * ph.xa;
-      for (int i = 0; i <= n; i++) {
-        const double d = Dt[(size_t)i * n];
-        lm += d * pm[i];
-#pragma unroll
-        for (int c = 0; c < 3; c++) lr[c] += d * pr[3 * i + c];
-#pragma unroll
-        for (int c = 0; c < 3; c++) lv[c] += d * pv[3 * i + c];
-#pragma unroll
-        for (int c = 0; c < 4; c++) lq[c] += d * pq[4 * i + c];
-      }
       PARK(PK_LV0) = lv[0]; PARK(PK_LV1) = lv[1]; PARK(PK_LV2) = lv[2];
       PARK(PK_LQ0) = lq[0]; PARK(PK_LQ1) = lq[1]; PARK(PK_LQ2) = lq[2]; PARK(PK_LQ3) = lq[3];
       const double m0 = ph.engine_on ? 0.0 : xm[ph.xa];

@@ -477,6 +477,14 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   dv.flag = p->d_flag;
   dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks;
   dv.park_off = (int32_t)((tables.size() + 1) / 2 * 2);
+  {
+    // D.X path: the matrix pipe runs beside the fp64 VALU pipe that bounds this kernel, so the MFMA form
+    // is the default; GEL_FLAG_DX_VALU forces the wavefront dot-product form (kept for n < 16 phases,
+    // where a 16-row tile is mostly padding, and for A/B measurements)
+    int nmax = 0;
+    for (int i = 0; i < S; i++) nmax = std::max(nmax, p->ph[i].n);
+    dv.use_mfma = (d->flags & GEL_FLAG_DX_VALU) ? 0 : ((d->flags & GEL_FLAG_DX_MFMA) ? 1 : (nmax >= 16));
+  }
   dv.um = p->um; dv.up = p->up; dv.uv = p->uv; dv.uu = p->uu; dv.ut = p->ut; dv.dx = p->dx; dv.barC20 = p->barC20;
   *out = p;
   return GEL_OK;

@@ -2,7 +2,7 @@
 // and forward-difference-Jacobian hot path, plus their launchers.
 //
 // Kernel inventory
-//   eval_kernel<JAC>   one thread per (decision vector b, collocation node g):
+//   eval_kernel<JAC,MFMA>  one wavefront per (decision vector, phase, 64-node chunk), one lane per node:
 //                      D.X rows, centre RHS, every FD sweep, residual rows and the
 //                      x-dependent Jacobian entries of that node, fused.
 //   expand_kernel      compact Jacobian entries + constant template -> full COO values
@@ -227,10 +227,16 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
   const long long waves = (long long)B * P.nchunks;
   const unsigned grid = (unsigned)((waves * 64 + kBlock - 1) / kBlock);
   const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)PK_COUNT * kBlock);  // tables | per-lane park
-  if (d_jvar)
-    hipLaunchKernelGGL(eval_kernel<true>, dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+  // D.X on the matrix pipe only when residual rows are requested at all (d_res) and the problem asks for it
+  const bool mfma = P.use_mfma && d_res;
+  if (d_jvar && mfma)
+    hipLaunchKernelGGL((eval_kernel<true, true>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+  else if (d_jvar)
+    hipLaunchKernelGGL((eval_kernel<true, false>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+  else if (mfma)
+    hipLaunchKernelGGL((eval_kernel<false, true>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
   else
-    hipLaunchKernelGGL(eval_kernel<false>, dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+    hipLaunchKernelGGL((eval_kernel<false, false>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
   return hipGetLastError();
 }
 

@@ -42,7 +42,7 @@ class Engine:
     attitude_hold, units (mass, position, velocity, u, t), dx, wind_table [K,3], ca_table [K,2];
     optional D / tau (lists per phase, e.g. pdict["ps_params"].D(i)); barC20 (0 -> C++ constant)."""
 
-    def __init__(self, prob, D=None, tau=None, barC20=0.0, device=0):
+    def __init__(self, prob, D=None, tau=None, barC20=0.0, device=0, flags=0):
         L = lib()
         self._keep = []
         nn = np.ascontiguousarray(prob["num_nodes"], dtype=np.int32)
@@ -82,6 +82,7 @@ class Engine:
         else:
             d.D, d.tau = None, None
         d.device = device
+        d.flags = int(flags)  # 0, or GEL_FLAG_DX_MFMA (1) / GEL_FLAG_DX_VALU (2) to force the D.X path
         h = C.c_void_p()
         check(L.gel_problem_create(C.byref(d), C.byref(h)))
         self._h = h

@@ -481,3 +481,31 @@ def test_phase_shards_compose_to_the_full_evaluation():
             tot_r += r
             tot_j += jv
         assert torch.equal(tot_r, ref_r) and torch.equal(tot_j, ref_j)
+
+
+# --------------------------------------------------------------------------
+# D.X on the matrix pipe (v_mfma_f64_16x16x4_f64) vs wavefront dot-products (VALU)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["example", "mixed-6x64", "stress-12x128"])
+def test_dx_mfma_and_valu_paths_agree(name):
+    oracle = _setup()
+    from gelato_amd import Engine
+    prob, x, _ = named_problem(name)
+    P = oracle.Problem(prob)
+    D = [P.D(i) for i in range(P.S)]
+    tau = [P.tau(i) for i in range(P.S)]
+    Em = Engine(prob, D=D, tau=tau, flags=1)   # GEL_FLAG_DX_MFMA
+    Ev = Engine(prob, D=D, tau=tau, flags=2)   # GEL_FLAG_DX_VALU
+    rm, vm_, rc1 = Em.eval(x)
+    rv, vv_, rc2 = Ev.eval(x)
+    assert rc1 == 0 and rc2 == 0
+    assert np.array_equal(vm_, vv_)                      # the Jacobian does not go through D.X
+    bound = dx_roundoff_bound(Em, x)
+    for grp, a, b in zip(oracle.GROUPS, Em.split_res(rm).values(), Ev.split_res(rv).values()):
+        assert np.all(np.abs(a - b) <= 1e-15 + 2 * bound[grp]), grp
+        close(a, P.residual(grp, x), atol=1e-12 + bound[grp], what="mfma residual " + grp)
+        close(b, P.residual(grp, x), atol=1e-12 + bound[grp], what="valu residual " + grp)
+    # residual-only launches (the jac_fd path) as well
+    r1, _ = Em.eval_residual(x)
+    r2, _ = Ev.eval_residual(x)
+    assert np.array_equal(r1, rm) and np.array_equal(r2, rv)

@@ -10,7 +10,7 @@ def run(workload, Bs, reps=10):
     pdict, unitdict, condition, xdict = problem.make_problem(workload)
     prob = con_dynamics.problem_arrays(pdict, unitdict)
     S = pdict["num_sections"]; ps = pdict["ps_params"]
-    E = Engine(prob, D=[ps.D(i) for i in range(S)], tau=[ps.tau(i) for i in range(S)])
+    E = Engine(prob, D=[ps.D(i) for i in range(S)], tau=[ps.tau(i) for i in range(S)], flags=int(os.environ.get("GEL_FLAGS", "0")))
     x0 = pack_x(xdict)
     dev = torch.device("cuda:0")
     Bmax = max(Bs)
