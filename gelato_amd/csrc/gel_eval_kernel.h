@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 #pragma unroll
         for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
         pp = pos_part(r, tb, P.barC20);
-        wind_eci(r, ea, pp.shp, pp.chp, pp.wn, pp.we, w);
+        wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
         aero_force(r, v, pp.rho, pp.a, ea, w, ph.area, tb, F);
         T = ph.thrust - ph.nozzle * pp.P;
         const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
             const double tnp = tau * (tf_p - to_p) / 2 + (tf_p + to_p) / 2;
             const EarthAngle eq = earth_angle(tnp);
             double wq[3], Fp[3];
-            wind_eci(r, eq, pp.shp, pp.chp, pp.wn, pp.we, wq);
+            wind_eci(r, eq, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, wq);
             aero_force(r, v, pp.rho, pp.a, eq, wq, ph.area, tb, Fp);
             accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
             // -(f_p*(tf_p - to_p) - f_c*(tf - to))/dx*unit_t/2   (con_dynamics.py:463-477)

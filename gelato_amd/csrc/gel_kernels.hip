@@ -129,7 +129,7 @@ __global__ void rhs_vel_air_kernel(RhsArgs A) {
   const PosPart pp = pos_part(r, tb, A.barC20);
   const EarthAngle ea = earth_angle(A.t[i]);
   double w[3], F[3], dir[3], f[3];
-  wind_eci(r, ea, pp.shp, pp.chp, pp.wn, pp.we, w);
+  wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
   aero_force(r, v, pp.rho, pp.a, ea, w, A.area, tb, F);
   thrust_dir(q, dir);
   const double T = A.thrust - A.nozzle * pp.P;
@@ -176,9 +176,13 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       out[5 * i] = h; out[5 * i + 1] = a.T; out[5 * i + 2] = a.P; out[5 * i + 3] = a.rho; out[5 * i + 4] = a.a;
     } break;
     case 1: {
-      double lat, lon, alt;
-      geodetic_full(in[3 * i], in[3 * i + 1], in[3 * i + 2], lat, lon, alt);
-      out[3 * i] = lat * 180.0 / kPi; out[3 * i + 1] = lon * 180.0 / kPi; out[3 * i + 2] = alt;
+      // latitude and altitude exactly as pos_part forms them; angles reported in degrees
+      double lat, sl, cl, p;
+      geodetic_lat_p(in[3 * i], in[3 * i + 1], in[3 * i + 2], lat, p);
+      sincos(lat, &sl, &cl);
+      const double lon = atan2(in[3 * i + 1], in[3 * i]);
+      out[3 * i] = lat * 180.0 / kPi; out[3 * i + 1] = lon * 180.0 / kPi;
+      out[3 * i + 2] = geodetic_alt_from(p, sl, cl);
     } break;
     case 2: {
       const double r[3] = {in[3 * i], in[3 * i + 1], in[3 * i + 2]};
@@ -190,12 +194,12 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       // wind vector NED -> ECI exactly as the hot path does it: in = pos[3], t, wn, we
       const double* a = in + 6 * i;
       const double r[3] = {a[0], a[1], a[2]};
-      double lat, p, w[3];
+      double lat, sl, cl, p, w[3];
       geodetic_lat_p(r[0], r[1], r[2], lat, p);
+      sincos(lat, &sl, &cl);
       const EarthAngle ea = earth_angle(a[3]);
-      double shp, chp;
-      sincos(lat / 2.0, &shp, &chp);
-      wind_eci(r, ea, shp, chp, a[4], a[5], w);
+      const double chp = sqrt(0.5 * (1.0 + cl)), shp = 0.5 * sl / chp;
+      wind_eci(r, ea, shp, chp, 1.0 / p, a[4], a[5], w);
       out[3 * i] = w[0]; out[3 * i + 1] = w[1]; out[3 * i + 2] = w[2];
     } break;
     case 4: {

@@ -23,19 +23,38 @@ struct PosPart {
   double wn, we;     // wind, NED
   double g[3];       // gravity, ECI
   double shp, chp;   // sin, cos of half the geodetic latitude (for the NED quaternion)
+  double inv_p;      // 1 / sqrt(x^2 + y^2)
 };
+
+// Bowring's one-step geodetic latitude (src/Earth.cpp:49-57) delivered as (sin lat, cos lat): the
+// reference forms lat = atan2(zz, pp) and then only ever uses sin/cos of it (and of lat/2), so the pair is
+// taken directly as zz/hypot, pp/hypot -- the same two numbers up to rounding, without the atan2 -> sincos
+// round trip.  Likewise sin/cos(theta) of theta = atan2(z Ra, p Rb).
+GEL_DEV void geodetic_sincos(double x, double y, double z, double& sl, double& cl, double& p) {
+  p = sqrt(x * x + y * y);
+  const double a = z * kRa, b = p * kRb;
+  const double ih = 1.0 / sqrt(a * a + b * b);
+  const double st = a * ih, ct = b * ih;
+  const double zz = z + kEp2 * kRb * (st * st * st);
+  const double pp = p - kE2 * kRa * (ct * ct * ct);
+  const double ihy = 1.0 / sqrt(zz * zz + pp * pp);
+  sl = zz * ihy;
+  cl = pp * ihy;
+}
 
 GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
   PosPart o;
   // the reference feeds the ECI position to ecef2geodetic for altitude (src/pybind_dynamics.cpp:43)
-  double lat, p;
+  // The altitude p/cos(lat) - N cancels 6.4e6 m down to the altitude and the position sweeps difference
+  // exactly that round-off, so sin/cos(lat) are taken the reference's way (atan2, then sincos): measured,
+  // the algebraic pair of geodetic_sincos() is equally accurate but decorrelates the FD noise from the
+  // reference's (3e-4 on vel/position entries of a polar, high-dynamic-pressure test state).
+  double lat, p, sl, cl;
   geodetic_lat_p(r[0], r[1], r[2], lat, p);
-  // sin/cos(lat) at full libm accuracy for the altitude (p/cos(lat) - N cancels 6.4e6 m down to the
-  // altitude, and that round-off is what the position sweeps difference); the half-angle pair of the
-  // NED quaternion (src/Coordinate.cpp:89-90) only rotates the <= 30 m/s wind, so it is derived from
-  // them algebraically: cos(lat/2) = sqrt((1+cos lat)/2) (cos lat >= 0), sin(lat/2) = sin lat/(2 cos(lat/2)).
-  double sl, cl;
   sincos(lat, &sl, &cl);
+  o.inv_p = 1.0 / p;
+  // half-angle pair of the NED quaternion (src/Coordinate.cpp:89-90): cos(lat/2) = sqrt((1+cos lat)/2)
+  // (cos lat >= 0), sin(lat/2) = sin lat / (2 cos(lat/2))
   o.chp = sqrt(0.5 * (1.0 + cl));
   o.shp = 0.5 * sl / o.chp;
   const double alt = geodetic_alt_from(p, sl, cl);
@@ -61,16 +80,21 @@ GEL_DEV EarthAngle earth_angle(double t) {
 // quat_nedg2eci = conj( q_eci2ecef(t) * q_ecef2ned( Rz(-omega t) pos ) )  (src/Coordinate.cpp:75-110).
 // The reference re-runs the Bowring latitude on the rotated position (Coordinate.cpp:86); a rotation
 // about z leaves (sqrt(x^2+y^2), z) and therefore the latitude unchanged, so pos_part's latitude is
-// reused (equal to a recomputation up to rounding).  The longitude IS taken from the rotated position.
-GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double s_hp, double c_hp, double wn, double we,
-                      double w[3]) {
+// reused (equal to a recomputation up to rounding).  The longitude IS taken from the rotated position;
+// the reference forms lon = atan2(py, px) and uses only cos/sin(lon/2) (Coordinate.cpp:87-88): they are
+// obtained from (cos lon, sin lon) = (px, py)/p by the half-angle identities, on the branch that has no
+// cancellation (lon/2 in (-pi/2, pi/2], so cos(lon/2) >= 0).
+GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double s_hp, double c_hp, double inv_p, double wn,
+                      double we, double w[3]) {
   // eci2ecef(pos, t): src/Coordinate.cpp:51-59
   const double px = r[0] * e.c + r[1] * e.s;
   const double py = -r[0] * e.s + r[1] * e.c;
-  const double lon = atan2(py, px);
+  const double clon = px * inv_p, slon = py * inv_p;
+  const double th = sqrt(0.5 * (1.0 + fabs(clon)));  // |cos| or |sin| of lon/2, whichever is >= 0.707
+  const double uh = 0.5 * slon / th;
+  const double c_hl = (clon >= 0.0) ? th : fabs(uh);
+  const double s_hl = (clon >= 0.0) ? uh : copysign(th, slon);
   // quat_ecef2ned: src/Coordinate.cpp:85-98
-  double s_hl, c_hl;
-  sincos(lon / 2.0, &s_hl, &c_hl);
   const double irt2 = 0.70710678118654752440;  // 1/sqrt(2)
   const double b0 = c_hl * (c_hp - s_hp) * irt2, b1 = s_hl * (c_hp + s_hp) * irt2;
   const double b2 = -c_hl * (c_hp + s_hp) * irt2, b3 = s_hl * (c_hp - s_hp) * irt2;
