@@ -25,7 +25,10 @@
 
 namespace gel {
 
-constexpr int kBlock = 256;
+#ifndef GEL_BLOCK
+#define GEL_BLOCK 256
+#endif
+constexpr int kBlock = GEL_BLOCK;  // threads per workgroup of the fused kernel (a multiple of 64)
 static_assert(kAtmDoubles == kAtmTableDoubles, "atmosphere table size mismatch between host and device");
 
 GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds) {

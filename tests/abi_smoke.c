@@ -1,0 +1,89 @@
+/* Plain-C consumer of the C-ABI (include/gelato_amd.h): proves the boundary needs nothing but a C compiler.
+ * Builds a small 2-phase problem, checks dims / pattern on a host-only handle, and -- when a GPU is
+ * present (argv[1] == "gpu") -- evaluates residual + Jacobian and checks a few structural invariants.
+ *   gcc -std=c11 -I include tests/abi_smoke.c -o abi_smoke -L gelato_amd -lgelato_amd -Wl,-rpath,$PWD/gelato_amd -lm
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gelato_amd.h"
+
+#define CHECK(c)                                                                     \
+  do {                                                                               \
+    if (!(c)) { fprintf(stderr, "FAIL %s:%d: %s (%s)\n", __FILE__, __LINE__, #c, gel_last_error()); return 1; } \
+  } while (0)
+
+int main(int argc, char** argv) {
+  const int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
+  int32_t nodes[2] = {5, 70};
+  double thrust[2] = {420000.0, 30700.0}, mdot[2] = {140.9, 9.88}, area[2] = {2.21, 0.0}, nozzle[2] = {0.68, 0.0};
+  int32_t eng[2] = {1, 1}, hold[2] = {1, 0};
+  double wind[3][3] = {{-1e8, 0, 0}, {3000.0, 0.0, 10.0}, {1e10, 0, 0}};
+  double ca[3][2] = {{0.0, 0.3}, {1.0, 0.65}, {100.0, 0.3}};
+  gel_problem_desc d;
+  memset(&d, 0, sizeof d);
+  d.num_sections = 2; d.num_nodes = nodes; d.thrust = thrust; d.massflow = mdot; d.reference_area = area;
+  d.nozzle_area = nozzle; d.engine_on = eng; d.attitude_hold = hold;
+  d.unit_mass = 27442.0; d.unit_position = 6378137.0; d.unit_velocity = 1000.0; d.unit_u = 1.0; d.unit_t = 600.0;
+  d.dx = 1e-8; d.wind_rows = 3; d.wind_table = &wind[0][0]; d.ca_rows = 3; d.ca_table = &ca[0][0];
+  d.device = gpu ? 0 : GEL_DEVICE_NONE;
+
+  gel_problem* p = NULL;
+  CHECK(gel_problem_create(&d, &p) == GEL_OK);
+  gel_dims dm;
+  CHECK(gel_problem_dims(p, &dm) == GEL_OK);
+  CHECK(dm.S == 2 && dm.N == 75 && dm.M == 77 && dm.num_vars == 11 * 77 + 2 * 75 + 3);
+  /* phase 0: air + hold (48 slots/node), phase 1: NoAir + free (71 slots/node) */
+  CHECK(dm.num_var_entries == 48 * 5 + 71 * 70);
+  CHECK(dm.algorithmic_bytes == 8 * ((int64_t)dm.num_vars + 11 * 75 + dm.num_var_entries));
+  int32_t nch = 0;
+  CHECK(gel_num_chunks(p, &nch) == GEL_OK && nch == 3); /* 5 -> 1 item, 70 -> 2 items */
+
+  /* pattern: in-range, no duplicate (row, col) inside a block */
+  for (int b = 0; b < GEL_NUM_BLOCKS; b++) {
+    int64_t nnz = dm.block_nnz[b];
+    int32_t* r = malloc(sizeof(int32_t) * (nnz ? nnz : 1));
+    int32_t* c = malloc(sizeof(int32_t) * (nnz ? nnz : 1));
+    CHECK(gel_pattern(p, b, r, c) == GEL_OK);
+    for (int64_t k = 0; k < nnz; k++)
+      CHECK(r[k] >= 0 && r[k] < dm.block_shape[b][0] && c[k] >= 0 && c[k] < dm.block_shape[b][1]);
+    free(r); free(c);
+  }
+  double D5[5 * 6], tau5[5];
+  CHECK(gel_problem_D(p, 0, D5) == GEL_OK && gel_problem_tau(p, 0, tau5) == GEL_OK && tau5[4] == 1.0);
+  for (int j = 0; j < 5; j++) { double s = 0; for (int i = 0; i < 6; i++) s += D5[j * 6 + i]; CHECK(fabs(s) < 1e-12); }
+
+  double* x = malloc(sizeof(double) * dm.num_vars);
+  double* res = malloc(sizeof(double) * 11 * dm.N);
+  double* vals = malloc(sizeof(double) * dm.total_nnz);
+  if (!gpu) {
+    CHECK(gel_eval_residual(p, x, res) == GEL_ERR_HIP); /* host-only handles never evaluate */
+    CHECK(gel_problem_destroy(p) == GEL_OK);
+    printf("abi_smoke host OK\n");
+    return 0;
+  }
+  /* a plausible state: 200 km circular-ish positions, unit quaternion, 25 t mass */
+  int M = dm.M, N = dm.N;
+  for (int i = 0; i < M; i++) {
+    double th = 0.7 + 0.001 * i;
+    x[i] = 0.9 - 0.005 * i;
+    x[M + 3 * i] = 1.03 * cos(th); x[M + 3 * i + 1] = 1.03 * sin(th) * 0.8; x[M + 3 * i + 2] = 1.03 * sin(th) * 0.6;
+    x[4 * M + 3 * i] = -7.0 * sin(th); x[4 * M + 3 * i + 1] = 7.0 * cos(th) * 0.8; x[4 * M + 3 * i + 2] = 7.0 * cos(th) * 0.6;
+    x[7 * M + 4 * i] = 0.5; x[7 * M + 4 * i + 1] = 0.5; x[7 * M + 4 * i + 2] = -0.5; x[7 * M + 4 * i + 3] = 0.5;
+  }
+  for (int i = 0; i < 2 * N; i++) x[11 * M + i] = 0.01 * (i % 7);
+  x[11 * M + 2 * N] = 0.0; x[11 * M + 2 * N + 1] = 0.3; x[11 * M + 2 * N + 2] = 1.0;
+  CHECK(gel_eval(p, x, res, vals, 1) == GEL_OK);
+  for (int i = 0; i < 11 * N; i++) CHECK(isfinite(res[i]));
+  for (int64_t k = 0; k < dm.total_nnz; k++) CHECK(isfinite(vals[k]));
+  /* phase 0 is a hold phase: its quaternion defect is q[j+1] - q[0] = 0 for this constant attitude */
+  for (int j = 0; j < 5 * 4; j++) CHECK(res[7 * N + j] == 0.0);
+  /* a NaN in x is reported, not swallowed */
+  x[M + 4] = NAN;
+  CHECK(gel_eval_residual(p, x, res) == GEL_NONFINITE);
+  CHECK(gel_problem_destroy(p) == GEL_OK);
+  printf("abi_smoke gpu OK\n");
+  return 0;
+}
