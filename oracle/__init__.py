@@ -269,6 +269,48 @@ class Problem:
         lib().orc_eval_batch(self._h, B, _d(X), _d(res), _d(vals), int(nthreads))
         return res, vals
 
+    # ---- aero path constraints (lib/con_aero.py) ----
+    AERO_KINDS = ["alpha", "q", "qalpha"]
+    AERO_VARS = ["position", "velocity", "quaternion", "t"]
+
+    def aero_configure(self, kind, spec):
+        """spec: rows of (phase, range_all, limit) with limit = units[3] of con_aero.py."""
+        L = lib()
+        L.orc_aero_configure.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _dp]
+        spec = np.asarray(spec, dtype=np.float64).reshape(-1, 3)
+        ph = np.ascontiguousarray(spec[:, 0], dtype=np.int32)
+        ra = np.ascontiguousarray(spec[:, 1], dtype=np.int32)
+        lim = _f64(spec[:, 2])
+        assert L.orc_aero_configure(self._h, self.AERO_KINDS.index(kind), len(ph), _i(ph), _i(ra), _d(lim)) == 0
+
+    def aero_residual(self, kind, x):
+        L = lib()
+        L.orc_aero_rows.argtypes = [C.c_void_p, C.c_int]
+        L.orc_aero_residual.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        k = self.AERO_KINDS.index(kind)
+        out = np.zeros(L.orc_aero_rows(self._h, k))
+        L.orc_aero_residual(self._h, k, _d(_f64(x)), _d(out))
+        return out
+
+    def aero_jacobian(self, kind, x):
+        L = lib()
+        L.orc_aero_rows.argtypes = [C.c_void_p, C.c_int]
+        L.orc_aero_nnz.restype = C.c_int64
+        L.orc_aero_nnz.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_aero_jacobian.argtypes = [C.c_void_p, C.c_int, _dp, _ip, _ip, _dp]
+        k = self.AERO_KINDS.index(kind)
+        nrow = L.orc_aero_rows(self._h, k)
+        nn = [int(L.orc_aero_nnz(self._h, k, v)) for v in range(4)]
+        tot = sum(nn)
+        rows, cols, vals = np.zeros(tot, np.int32), np.zeros(tot, np.int32), np.zeros(tot)
+        L.orc_aero_jacobian(self._h, k, _d(_f64(x)), _i(rows), _i(cols), _d(vals))
+        shapes = [(nrow, 3 * self.M), (nrow, 3 * self.M), (nrow, 4 * self.M), (nrow, self.S + 1)]
+        out, off = {}, 0
+        for v, var in enumerate(self.AERO_VARS):
+            out[var] = {"coo": [rows[off:off + nn[v]], cols[off:off + nn[v]], vals[off:off + nn[v]]], "shape": shapes[v]}
+            off += nn[v]
+        return out
+
     def split_x(self, x):
         M, N, S = self.M, self.N, self.S
         o = np.cumsum([0, M, 3 * M, 3 * M, 4 * M, 2 * N, S + 1])

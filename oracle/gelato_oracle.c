@@ -949,3 +949,170 @@ void orc_eval_batch(const orc_problem* p, int B, const double* x, double* res, d
     }
   }
 }
+
+/* ================================================================== */
+/* aerodynamic path constraints                   */
+/* (lib/con_aero.py; src/wrapper_utils.hpp:89-206)                     */
+/* ================================================================== */
+static void air_velocity_eci(const double pos[3], const double vel[3], double t, const double* wind, int Kw,
+                             double vair[3], double* altitude_out) {
+  /* the chain shared by the three functions, wrapper_utils.hpp:93-100,165-172 */
+  double llh[3], vel_ecef[3], wned[3], qn2i[4], wind_eci[3];
+  orc_ecef2geodetic(pos[0], pos[1], pos[2], llh);
+  double altitude = orc_geopotential_altitude(llh[2]);
+  orc_vel_eci2ecef(vel, pos, t, vel_ecef);
+  orc_wind_ned(altitude, wind, Kw, wned);
+  orc_quat_nedg2eci(pos, t, qn2i);
+  orc_quatrot(qn2i, wned, wind_eci);
+  orc_ecef2eci(vel_ecef, t, vair);
+  vair[0] -= wind_eci[0]; vair[1] -= wind_eci[1]; vair[2] -= wind_eci[2];
+  *altitude_out = altitude;
+}
+
+double orc_angle_of_attack_all_rad(const double pos[3], const double vel[3], const double quat[4], double t,
+                                   const double* wind, int Kw) { /* wrapper_utils.hpp:89-111 */
+  double qc[4], ex[3] = {1.0, 0.0, 0.0}, dir[3], vair[3], alt;
+  quat_conj(quat, qc);
+  orc_quatrot(qc, ex, dir);
+  air_velocity_eci(pos, vel, t, wind, Kw, vair, &alt);
+  double nv = sqrt(vair[0] * vair[0] + vair[1] * vair[1] + vair[2] * vair[2]);
+  double nd = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+  double c_alpha = (vair[0] / nv) * (dir[0] / nd) + (vair[1] / nv) * (dir[1] / nd) + (vair[2] / nv) * (dir[2] / nd);
+  if (c_alpha > 1.0) return 0.0;
+  else if (nv < 1e-6) return 0.0;
+  else return acos(c_alpha);
+}
+
+double orc_dynamic_pressure_pa(const double pos[3], const double vel[3], double t, const double* wind, int Kw) {
+  /* wrapper_utils.hpp:163-175 */
+  double vair[3], alt;
+  air_velocity_eci(pos, vel, t, wind, Kw, vair, &alt);
+  double rho = orc_air_density(alt);
+  double nv = sqrt(vair[0] * vair[0] + vair[1] * vair[1] + vair[2] * vair[2]);
+  return 0.5 * rho * nv * nv;
+}
+
+double orc_q_alpha_pa_rad(const double pos[3], const double vel[3], const double quat[4], double t,
+                          const double* wind, int Kw) { /* wrapper_utils.hpp:190-195 */
+  double alpha = orc_angle_of_attack_all_rad(pos, vel, quat, t, wind, Kw);
+  double q = orc_dynamic_pressure_pa(pos, vel, t, wind, Kw);
+  return q * alpha;
+}
+
+/* constraint specs: kind 0 = AOA_max, 1 = dynamic_pressure_max, 2 = Q_alpha_max (condition[...] of con_aero.py) */
+typedef struct { int phase, all; double limit; } aero_spec;
+#define ORC_MAX_AERO 64
+static aero_spec g_unused_spec; /* silence unused warnings on some compilers */
+
+typedef struct { int n; aero_spec s[ORC_MAX_AERO]; } aero_list;
+/* stored beside the problem (kept out of struct orc_problem's original layout) */
+typedef struct aero_store { const orc_problem* p; aero_list k[3]; struct aero_store* next; } aero_store;
+static aero_store* g_aero = NULL;
+
+static aero_store* aero_of(const orc_problem* p, int create) {
+  for (aero_store* a = g_aero; a; a = a->next) if (a->p == p) return a;
+  if (!create) return NULL;
+  aero_store* a = (aero_store*)calloc(1, sizeof(aero_store));
+  a->p = p; a->next = g_aero; g_aero = a;
+  (void)g_unused_spec;
+  return a;
+}
+
+int orc_aero_configure(const orc_problem* p, int kind, int nspec, const int32_t* phase, const int32_t* range_all,
+                       const double* limit) {
+  if (kind < 0 || kind > 2 || nspec > ORC_MAX_AERO) return -1;
+  aero_store* a = aero_of(p, 1);
+  a->k[kind].n = nspec;
+  for (int i = 0; i < nspec; i++) { a->k[kind].s[i].phase = phase[i]; a->k[kind].s[i].all = range_all[i]; a->k[kind].s[i].limit = limit[i]; }
+  return 0;
+}
+
+static int aero_nk(const orc_problem* p, const aero_spec* s) { return s->all ? p->n[s->phase] + 1 : 1; }
+
+int orc_aero_rows(const orc_problem* p, int kind) { /* inequality_length_max_*: con_aero.py:254-309 */
+  aero_store* a = aero_of(p, 0);
+  int r = 0;
+  if (a) for (int i = 0; i < a->k[kind].n; i++) r += aero_nk(p, &a->k[kind].s[i]);
+  return r;
+}
+
+/* the *_array_dimless helpers, con_aero.py:39-87: scale, evaluate, divide by units[3] */
+static double aero_value(const orc_problem* p, int kind, const double* pos_e, const double* vel_e, const double* q,
+                         double t_e, double limit) {
+  double pos[3] = {pos_e[0] * p->up, pos_e[1] * p->up, pos_e[2] * p->up};
+  double vel[3] = {vel_e[0] * p->uv, vel_e[1] * p->uv, vel_e[2] * p->uv};
+  double t = t_e * p->ut;
+  double f = kind == 0 ? orc_angle_of_attack_all_rad(pos, vel, q, t, p->wind, p->Kw)
+           : kind == 1 ? orc_dynamic_pressure_pa(pos, vel, t, p->wind, p->Kw)
+                       : orc_q_alpha_pa_rad(pos, vel, q, t, p->wind, p->Kw);
+  return f / limit;
+}
+
+static double time_node(const orc_problem* p, int i, int k, double to, double tf) { /* SectionParameters.py:77-81 */
+  return k == 0 ? to : p->tau[i][k - 1] * (tf - to) / 2 + (tf + to) / 2;
+}
+
+void orc_aero_residual(const orc_problem* p, int kind, const double* x, double* out) {
+  /* inequality_max_alpha / _q / _qalpha: con_aero.py:90-252 */
+  aero_store* a = aero_of(p, 0);
+  if (!a) return;
+  xview X = view(p, x);
+  int row = 0;
+  for (int s = 0; s < a->k[kind].n; s++) {
+    const aero_spec* sp = &a->k[kind].s[s];
+    int i = sp->phase, xa = p->ua[i] + i, nk = aero_nk(p, sp);
+    double to = X.t[i], tf = X.t[i + 1];
+    for (int k = 0; k < nk; k++)
+      out[row++] = 1.0 - aero_value(p, kind, X.pos + 3 * (xa + k), X.vel + 3 * (xa + k), X.quat + 4 * (xa + k),
+                                    time_node(p, i, k, to, tf), sp->limit);
+  }
+}
+
+int64_t orc_aero_nnz(const orc_problem* p, int kind, int var) { /* var: 0 position, 1 velocity, 2 quaternion, 3 t */
+  int64_t rows = orc_aero_rows(p, kind);
+  static const int w[4] = {3, 3, 4, 2};
+  if (var == 2 && kind == 1) return 0;
+  return rows * w[var];
+}
+
+void orc_aero_jacobian(const orc_problem* p, int kind, const double* x_in, int32_t* rows, int32_t* cols, double* vals) {
+  /* inequality_jac_max_*: con_aero.py:311-471 (+ the q and q-alpha twins); blocks concatenated in key order
+   * position, velocity, quaternion, t.  Gradients by forward differences with the reference's in-place
+   * "+= dx ... -= dx" on copies (con_aero.py:324-371 fancy-indexes, i.e. copies, the node rows). */
+  aero_store* a = aero_of(p, 0);
+  if (!a) return;
+  xview X = view(p, x_in);
+  const double dx = p->dx;
+  coo o[4];
+  int64_t off = 0;
+  for (int v = 0; v < 4; v++) {
+    o[v].r = rows ? rows + off : NULL; o[v].c = cols ? cols + off : NULL; o[v].v = vals + off; o[v].k = 0;
+    off += orc_aero_nnz(p, kind, v);
+  }
+  int iRow = 0;
+  for (int s = 0; s < a->k[kind].n; s++) {
+    const aero_spec* sp = &a->k[kind].s[s];
+    int i = sp->phase, xa = p->ua[i] + i, nk = aero_nk(p, sp);
+    double to = X.t[i], tf = X.t[i + 1];
+    double* gp = (double*)malloc(sizeof(double) * nk * 12);
+    for (int k = 0; k < nk; k++) {
+      double r[3], v[3], q[4];
+      memcpy(r, X.pos + 3 * (xa + k), 24); memcpy(v, X.vel + 3 * (xa + k), 24); memcpy(q, X.quat + 4 * (xa + k), 32);
+      double tk = time_node(p, i, k, to, tf);
+      double fc = aero_value(p, kind, r, v, q, tk, sp->limit);
+      for (int j = 0; j < 3; j++) { r[j] += dx; gp[k * 12 + j] = (aero_value(p, kind, r, v, q, tk, sp->limit) - fc) / dx; r[j] -= dx; }
+      for (int j = 0; j < 3; j++) { v[j] += dx; gp[k * 12 + 3 + j] = (aero_value(p, kind, r, v, q, tk, sp->limit) - fc) / dx; v[j] -= dx; }
+      for (int j = 0; j < 4; j++) { q[j] += dx; gp[k * 12 + 6 + j] = (aero_value(p, kind, r, v, q, tk, sp->limit) - fc) / dx; q[j] -= dx; }
+      gp[k * 12 + 10] = (aero_value(p, kind, r, v, q, time_node(p, i, k, to + dx, tf), sp->limit) - fc) / dx;
+      gp[k * 12 + 11] = (aero_value(p, kind, r, v, q, time_node(p, i, k, to, tf + dx), sp->limit) - fc) / dx;
+    }
+    for (int j = 0; j < 3; j++) for (int k = 0; k < nk; k++) put(&o[0], iRow + k, (xa + k) * 3 + j, -gp[k * 12 + j]);
+    for (int j = 0; j < 3; j++) for (int k = 0; k < nk; k++) put(&o[1], iRow + k, (xa + k) * 3 + j, -gp[k * 12 + 3 + j]);
+    if (kind != 1)
+      for (int j = 0; j < 4; j++) for (int k = 0; k < nk; k++) put(&o[2], iRow + k, (xa + k) * 4 + j, -gp[k * 12 + 6 + j]);
+    for (int k = 0; k < nk; k++) put(&o[3], iRow + k, i, -gp[k * 12 + 10]);
+    for (int k = 0; k < nk; k++) put(&o[3], iRow + k, i + 1, -gp[k * 12 + 11]);
+    iRow += nk;
+    free(gp);
+  }
+}
