@@ -70,6 +70,10 @@ SIGNATURES = {
     "gel_chunk_phase": (C.c_int, [C.c_void_p, _ip]),
     "gel_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gel_jac_fd": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+    "gel_aero_configure": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _ip, _ip, _dp]),
+    "gel_aero_dims": (C.c_int, [C.c_void_p, C.c_int32, _ip, _lp]),
+    "gel_aero_pattern": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _ip, _ip]),
+    "gel_eval_aero": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "gel_dynamics_velocity": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32,
                                          _dp, C.c_double, _dp]),
     "gel_dynamics_velocity_NoAir": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]),

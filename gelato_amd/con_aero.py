@@ -1,0 +1,125 @@
+"""Aerodynamic path constraints (angle of attack, dynamic pressure, q-alpha) and their forward-
+difference Jacobians on the GPU.  Drop-in for the reference's lib/con_aero.py:
+
+  inequality_max_alpha / _q / _qalpha            -> 1-D float64 ndarray or None   (con_aero.py:90-252)
+  inequality_length_max_alpha / _q / _qalpha     -> int                           (:254-309)
+  inequality_jac_max_alpha / _q / _qalpha        -> {"position","velocity","quaternion","t": COO} or None
+                                                                                   (:311-471 and twins)
+
+Same ``(xdict, pdict, unitdict, condition)`` signature; ``condition["AOA_max"]``,
+``condition["dynamic_pressure_max"]``, ``condition["Q_alpha_max"]`` are read exactly like the reference
+does: keyed by section name, ``{"value": ..., "range": "all" | "initial"}``; sections are visited in order
+and the last one is never constrained (``range(num_sections - 1)``).
+"""
+import numpy as np
+
+from . import con_dynamics
+from .engine import pack_x
+
+_KINDS = {"alpha": "AOA_max", "q": "dynamic_pressure_max", "qalpha": "Q_alpha_max"}
+
+
+def _spec(pdict, condition, kind):
+    cond = condition.get(_KINDS[kind], {}) or {}
+    rows = []
+    for i in range(pdict["num_sections"] - 1):                      # con_aero.py:108
+        name = pdict["params"][i]["name"]
+        if name in cond:
+            c = cond[name]
+            if c["range"] not in ("all", "initial"):
+                continue
+            limit = c["value"] * np.pi / 180.0 if kind in ("alpha", "qalpha") else c["value"]   # :119,232,173
+            rows.append((i, 1 if c["range"] == "all" else 0, float(limit)))
+    return np.array(rows, dtype=np.float64).reshape(-1, 3)
+
+
+def _configured(pdict, unitdict, condition, kind):
+    st = con_dynamics._state(pdict, unitdict)
+    spec = _spec(pdict, condition, kind)
+    key = spec.tobytes()
+    cache = st.__dict__.setdefault("aero_spec", {})
+    if cache.get(kind) != key:
+        st.engine.aero_configure(kind, spec)
+        cache[kind] = key
+        st.__dict__.setdefault("aero_pattern", {}).pop(kind, None)
+    return st, len(spec)
+
+
+def _values(xdict, pdict, unitdict, condition, kind):
+    st, nspec = _configured(pdict, unitdict, condition, kind)
+    if nspec == 0:
+        return None
+    con, _, rc = st.engine.eval_aero(kind, pack_x(xdict), want_jac=False)
+    st.status = rc
+    return con[0]
+
+
+def _length(pdict, unitdict, condition, kind):
+    st, nspec = _configured(pdict, unitdict, condition, kind)
+    return st.engine.aero_dims(kind)[0] if nspec else 0
+
+
+def _jacobian(xdict, pdict, unitdict, condition, kind):
+    st, nspec = _configured(pdict, unitdict, condition, kind)
+    if nspec == 0:
+        return None
+    eng = st.engine
+    pats = st.__dict__.setdefault("aero_pattern", {})
+    if kind not in pats:
+        pats[kind] = eng.aero_pattern(kind)
+    nrow, nnz = eng.aero_dims(kind)
+    _, jv, rc = eng.eval_aero(kind, pack_x(xdict), want_jac=True)
+    st.status = rc
+    shapes = [(nrow, pdict["M"] * 3), (nrow, pdict["M"] * 3), (nrow, pdict["M"] * 4),
+              (nrow, pdict["num_sections"] + 1)]
+    jac, off = {}, 0
+    for v, var in enumerate(eng.AERO_VARS):
+        r, c = pats[kind][v]
+        jac[var] = {"coo": [r, c, jv[0, off:off + nnz[v]].copy()], "shape": shapes[v]}
+        off += nnz[v]
+    return jac
+
+
+def inequality_max_alpha(xdict, pdict, unitdict, condition):
+    """Inequality constraint about maximum angle of attack."""
+    return _values(xdict, pdict, unitdict, condition, "alpha")
+
+
+def inequality_max_q(xdict, pdict, unitdict, condition):
+    """Inequality constraint about maximum dynamic pressure."""
+    return _values(xdict, pdict, unitdict, condition, "q")
+
+
+def inequality_max_qalpha(xdict, pdict, unitdict, condition):
+    """Inequality constraint about maximum Q-alpha."""
+    return _values(xdict, pdict, unitdict, condition, "qalpha")
+
+
+def inequality_length_max_alpha(xdict, pdict, unitdict, condition):
+    """Length of inequality_max_alpha."""
+    return _length(pdict, unitdict, condition, "alpha")
+
+
+def inequality_length_max_q(xdict, pdict, unitdict, condition):
+    """Length of inequality_max_q."""
+    return _length(pdict, unitdict, condition, "q")
+
+
+def inequality_length_max_qalpha(xdict, pdict, unitdict, condition):
+    """Length of inequality_max_qalpha."""
+    return _length(pdict, unitdict, condition, "qalpha")
+
+
+def inequality_jac_max_alpha(xdict, pdict, unitdict, condition):
+    """Jacobian of inequality_max_alpha."""
+    return _jacobian(xdict, pdict, unitdict, condition, "alpha")
+
+
+def inequality_jac_max_q(xdict, pdict, unitdict, condition):
+    """Jacobian of inequality_max_q."""
+    return _jacobian(xdict, pdict, unitdict, condition, "q")
+
+
+def inequality_jac_max_qalpha(xdict, pdict, unitdict, condition):
+    """Jacobian of inequality_max_qalpha."""
+    return _jacobian(xdict, pdict, unitdict, condition, "qalpha")

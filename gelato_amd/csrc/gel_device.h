@@ -21,6 +21,12 @@ struct PhaseDev {
   double thrust, massflow, area, nozzle;
 };
 
+// one aero path-constraint row = one state node of a constrained phase (lib/con_aero.py)
+struct AeroRowDev {
+  int32_t phase, k, nk, row0;  // phase, node 0..nk-1 inside it, rows of its spec, first row of its spec
+  double limit;                // units[3] of con_aero.py
+};
+
 struct ProblemDev {
   int32_t S, N, M, nvars;
   int32_t Kw, Kc;

@@ -133,6 +133,9 @@ struct gel_problem {
   std::vector<int32_t> src;      // [total_nnz] -1 or compact slot
   std::vector<int64_t> var_idx;  // [V] compact slot -> full index
   std::vector<int32_t> chunk_phase;  // [nchunks] phase of every 64-node work item
+  // aero path constraints: kind 0 = AOA_max, 1 = dynamic_pressure_max, 2 = Q_alpha_max
+  std::vector<gel::AeroRowDev> aero_rows[3];
+  gel::AeroRowDev* d_aero_rows[3] = {nullptr, nullptr, nullptr};
   // device buffers (static)
   gel::PhaseDev* d_phases = nullptr;
   int32_t* d_node_phase = nullptr;
@@ -497,6 +500,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
   hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag);
+  for (int k = 0; k < 3; k++) hipFree(p->d_aero_rows[k]);
   hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv);
   if (p->h_x) hipHostFree(p->h_x);
   if (p->h_res) hipHostFree(p->h_res);
@@ -730,6 +734,91 @@ int gel_dynamics_quaternion(int32_t n, const double* quat, const double* u_e, do
   if ((rc = q.put(quat, 4 * (size_t)n)) || (rc = u.put(u_e, 2 * (size_t)n)) || (rc = o.put(nullptr, 4 * (size_t)n))) return rc;
   HIPCHK(gel::launch_rhs_quat(n, q.p, u.p, unit_u, o.p, nullptr));
   HIPCHK(hipMemcpy(out, o.p, 4 * (size_t)n * 8, hipMemcpyDeviceToHost));
+  return GEL_OK;
+}
+
+// ------------------ aero path constraints (lib/con_aero.py) ------------------
+int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_t* phase, const int32_t* range_all,
+                       const double* limit) {
+  if (!p || kind < 0 || kind > 2 || nspec < 0 || (nspec && (!phase || !range_all || !limit)))
+    return fail(GEL_ERR_ARG, "bad argument");
+  std::vector<gel::AeroRowDev> rows;
+  int prev = -1;
+  for (int s = 0; s < nspec; s++) {
+    // the reference walks range(num_sections - 1) in order (con_aero.py:108): the last phase is never constrained
+    if (phase[s] < 0 || phase[s] >= (int)p->ph.size() - 1 || phase[s] <= prev)
+      return fail(GEL_ERR_ARG, "aero specs must name increasing phases in [0, num_sections - 1)");
+    if (!(limit[s] != 0.0)) return fail(GEL_ERR_ARG, "aero limit must be non-zero");
+    prev = phase[s];
+    const int nk = range_all[s] ? p->ph[phase[s]].n + 1 : 1;
+    const int row0 = (int)rows.size();
+    for (int k = 0; k < nk; k++) rows.push_back(gel::AeroRowDev{phase[s], k, nk, row0, limit[s]});
+  }
+  p->aero_rows[kind] = rows;
+  if (p->device != GEL_DEVICE_NONE) {
+    HIPCHK(hipSetDevice(p->device));
+    if (p->d_aero_rows[kind]) { hipFree(p->d_aero_rows[kind]); p->d_aero_rows[kind] = nullptr; }
+    if (!rows.empty()) {
+      HIPCHK(hipMalloc((void**)&p->d_aero_rows[kind], rows.size() * sizeof(gel::AeroRowDev)));
+      HIPCHK(hipMemcpy(p->d_aero_rows[kind], rows.data(), rows.size() * sizeof(gel::AeroRowDev), hipMemcpyHostToDevice));
+    }
+  }
+  return GEL_OK;
+}
+
+int gel_aero_dims(const gel_problem* p, int32_t kind, int32_t* nrows, int64_t* nnz4) {
+  if (!p || kind < 0 || kind > 2 || !nrows || !nnz4) return fail(GEL_ERR_ARG, "bad argument");
+  const int64_t R = (int64_t)p->aero_rows[kind].size();
+  *nrows = (int32_t)R;
+  nnz4[0] = 3 * R; nnz4[1] = 3 * R; nnz4[2] = (kind == 1) ? 0 : 4 * R; nnz4[3] = 2 * R;
+  return GEL_OK;
+}
+
+int gel_aero_pattern(const gel_problem* p, int32_t kind, int32_t var, int32_t* rows, int32_t* cols) {
+  // emission order of inequality_jac_max_*: con_aero.py:437-463
+  if (!p || kind < 0 || kind > 2 || var < 0 || var > 3 || !rows || !cols) return fail(GEL_ERR_ARG, "bad argument");
+  const auto& A = p->aero_rows[kind];
+  int64_t o = 0;
+  for (size_t r0 = 0; r0 < A.size(); r0 += A[r0].nk) {
+    const int nk = A[r0].nk, i = A[r0].phase, xa = p->ph[i].xa, iRow = (int)r0;
+    if (var == 3) {
+      for (int k = 0; k < nk; k++) { rows[o] = iRow + k; cols[o++] = i; }
+      for (int k = 0; k < nk; k++) { rows[o] = iRow + k; cols[o++] = i + 1; }
+    } else if (!(var == 2 && kind == 1)) {
+      const int w = (var == 2) ? 4 : 3;
+      for (int j = 0; j < w; j++)
+        for (int k = 0; k < nk; k++) { rows[o] = iRow + k; cols[o++] = (xa + k) * w + j; }
+    }
+  }
+  return GEL_OK;
+}
+
+int gel_eval_aero(gel_problem* p, int32_t kind, int32_t B, const double* x, double* con, double* jac_vals) {
+  if (!p || kind < 0 || kind > 2 || B < 1 || !x || !con) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  const int R = (int)p->aero_rows[kind].size();
+  if (R == 0) return GEL_OK;
+  HIPCHK(hipSetDevice(p->device));
+  const size_t nx = (size_t)B * p->dims.num_vars, nc = (size_t)B * R, nj = (size_t)B * R * ((kind == 1) ? 8 : 12);
+  double *d_x = nullptr, *d_c = nullptr, *d_j = nullptr;
+  auto cleanup = [&]() { hipFree(d_x); hipFree(d_c); hipFree(d_j); };
+#define HIPCHK3(expr)                                                                                          \
+  do {                                                                                                         \
+    hipError_t _e = (expr);                                                                                    \
+    if (_e != hipSuccess) { cleanup(); return fail(GEL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } \
+  } while (0)
+  HIPCHK3(hipMalloc((void**)&d_x, nx * 8));
+  HIPCHK3(hipMalloc((void**)&d_c, nc * 8));
+  if (jac_vals) HIPCHK3(hipMalloc((void**)&d_j, nj * 8));
+  HIPCHK3(hipMemcpyAsync(d_x, x, nx * 8, hipMemcpyHostToDevice, p->stream));
+  HIPCHK3(gel::launch_aero(p->dev, kind, R, p->d_aero_rows[kind], B, d_x, d_c, d_j, p->stream));
+  HIPCHK3(hipMemcpyAsync(con, d_c, nc * 8, hipMemcpyDeviceToHost, p->stream));
+  if (jac_vals) HIPCHK3(hipMemcpyAsync(jac_vals, d_j, nj * 8, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK3(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK3(hipStreamSynchronize(p->stream));
+#undef HIPCHK3
+  cleanup();
+  if (*p->h_flag) { hipMemsetAsync(p->d_flag, 0, 4, p->stream); return GEL_NONFINITE; }
   return GEL_OK;
 }
 

@@ -225,6 +225,110 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
 }
 
 // ---------------------------------------------------------------------------
+// Aero path constraints: lib/con_aero.py:90-252 (values) and :311-756 (forward-
+// difference gradients), device functions of src/wrapper_utils.hpp:89-206.  One lane = one constraint
+// row (a state node of a constrained phase); the 12 perturbed evaluations of its gradient re-run the
+// whole (cheap) chain, like the reference.  kind 0 = angle of attack, 1 = dynamic pressure, 2 = q*alpha.
+// ---------------------------------------------------------------------------
+GEL_DEV double aero_value(int kind, const double re[3], const double ve[3], const double q[4], double t_e,
+                          const ProblemDev& P, const Tables& tb, double limit) {
+  // con_aero.py:39-87: scale, evaluate, divide by units[3]
+  const double r[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
+  const double v[3] = {ve[0] * P.uv, ve[1] * P.uv, ve[2] * P.uv};
+  const double t = t_e * P.ut;
+  // air-relative velocity in ECI: wrapper_utils.hpp:93-100 (same chain as the RHS)
+  double lat, p, sl, cl;
+  geodetic_lat_p(r[0], r[1], r[2], lat, p);
+  sincos(lat, &sl, &cl);
+  const double h = geopotential_altitude(geodetic_alt_from(p, sl, cl));
+  double wn, we, w[3];
+  wind_ned2(h, tb.wind, tb.Kw, wn, we);
+  const EarthAngle ea = earth_angle(t);
+  const double chp = sqrt(0.5 * (1.0 + cl)), shp = 0.5 * sl / chp;
+  wind_eci(r, ea, shp, chp, 1.0 / p, wn, we, w);
+  const double d0 = v[0] + kOmega * r[1], d1 = v[1] - kOmega * r[0];
+  const double e0 = d0 * ea.c + d1 * ea.s, e1 = -d0 * ea.s + d1 * ea.c;
+  const double a0 = (e0 * ea.c - e1 * ea.s) - w[0], a1 = (e0 * ea.s + e1 * ea.c) - w[1], a2 = v[2] - w[2];
+  const double nv = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  double alpha = 0.0, qdyn = 0.0;
+  if (kind != 1) {  // wrapper_utils.hpp:89-111
+    double dir[3];
+    thrust_dir(q, dir);
+    const double nd = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    const double c_alpha = (a0 / nv) * (dir[0] / nd) + (a1 / nv) * (dir[1] / nd) + (a2 / nv) * (dir[2] / nd);
+    alpha = (c_alpha > 1.0) ? 0.0 : ((nv < 1e-6) ? 0.0 : acos(c_alpha));
+  }
+  if (kind != 0) {  // wrapper_utils.hpp:163-175
+    const Air air = atmosphere(h, tb.atm);
+    qdyn = 0.5 * air.rho * nv * nv;
+  }
+  const double f = (kind == 0) ? alpha : (kind == 1) ? qdyn : qdyn * alpha;
+  return f / limit;
+}
+
+__global__ void aero_kernel(ProblemDev P, int kind, int nrows, const AeroRowDev* __restrict__ rows, int B,
+                            const double* __restrict__ x, double* __restrict__ con, double* __restrict__ jac) {
+  extern __shared__ double lds[];
+  const Tables tb = stage_tables(P, lds);
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long long)B * nrows) return;
+  const int b = (int)(tid / nrows), row = (int)(tid - (long long)b * nrows);
+  const AeroRowDev R = rows[row];
+  const PhaseDev& ph = P.phases[R.phase];
+  const double* xb = x + (size_t)b * P.nvars;
+  const int M = P.M, N = P.N, xi = ph.xa + R.k;
+  const double* pr = xb + M + 3 * xi;
+  const double* pv = xb + 4 * M + 3 * xi;
+  const double* pq = xb + 7 * M + 4 * xi;
+  const double to = xb[11 * M + 2 * N + R.phase], tf = xb[11 * M + 2 * N + R.phase + 1];
+  const double tau = (R.k == 0) ? 0.0 : P.tau[ph.toff + R.k - 1];
+  // PSparams.time_nodes (SectionParameters.py:77-81): node 0 is t0 itself
+#define TNODE(a, bb) ((R.k == 0) ? (a) : (tau * ((bb) - (a)) / 2 + ((bb) + (a)) / 2))
+  const double re[3] = {pr[0], pr[1], pr[2]}, ve[3] = {pv[0], pv[1], pv[2]}, q[4] = {pq[0], pq[1], pq[2], pq[3]};
+  const double dx = P.dx;
+  const double fc = aero_value(kind, re, ve, q, TNODE(to, tf), P, tb, R.limit);
+  double chk = 1.0 - fc;
+  con[(size_t)b * nrows + row] = 1.0 - fc;  // con_aero.py:127-139
+  if (jac) {
+    const int nq = (kind == 1) ? 0 : 4;
+    double* jb = jac + (size_t)b * nrows * (8 + nq);
+    double* jp = jb + 3 * R.row0 + R.k;                         // position block, [j][k] per spec
+    double* jv = jb + 3 * nrows + 3 * R.row0 + R.k;             // velocity block
+    double* jq = jb + 6 * nrows + 4 * R.row0 + R.k;             // quaternion block
+    double* jt = jb + (6 + nq) * nrows + 2 * R.row0 + R.k;      // t block: t0 column then tf column
+#pragma unroll 1
+    for (int s = 0; s < 12; s++) {
+      double rp[3], vp[3], qp[4];
+#pragma unroll
+      for (int c = 0; c < 3; c++) { rp[c] = (s == c) ? re[c] + dx : re[c]; vp[c] = (s == 3 + c) ? ve[c] + dx : ve[c]; }
+#pragma unroll
+      for (int c = 0; c < 4; c++) qp[c] = (s == 6 + c) ? q[c] + dx : q[c];
+      if (s >= 6 && s < 10 && kind == 1) continue;               // dynamic pressure has no quaternion block
+      const double tn = (s == 10) ? TNODE(to + dx, tf) : (s == 11) ? TNODE(to, tf + dx) : TNODE(to, tf);
+      const double fp = aero_value(kind, rp, vp, qp, tn, P, tb, R.limit);
+      const double gval = -((fp - fc) / dx);                      // jac = -dfdx  (con_aero.py:437-463)
+      chk += gval;
+      if (s < 3) jp[s * R.nk] = gval;
+      else if (s < 6) jv[(s - 3) * R.nk] = gval;
+      else if (s < 10) jq[(s - 6) * R.nk] = gval;
+      else jt[(s - 10) * R.nk] = gval;
+    }
+  }
+#undef TNODE
+  if (!(fabs(chk) <= 1.79769313486231570815e308)) atomicOr(P.flag, 1);
+}
+
+hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDev* rows, int B, const double* d_x,
+                       double* d_con, double* d_jac, hipStream_t s) {
+  if (B <= 0 || nrows <= 0) return hipSuccess;
+  const long long threads = (long long)B * nrows;
+  const size_t lds = sizeof(double) * (size_t)(kAtmDoubles + 3 * P.Kw + 2 * P.Kc);
+  hipLaunchKernelGGL(aero_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), lds, s, P, kind, nrows, rows, B, d_x,
+                     d_con, d_jac);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 static size_t table_lds_bytes(int Kw, int Kc) { return sizeof(double) * (size_t)(kAtmDoubles + 3 * Kw + 2 * Kc); }

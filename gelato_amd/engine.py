@@ -231,6 +231,47 @@ class Engine:
         rc = check(lib().gel_jac_fd(self._h, gi, _d(x), _d(J)))
         return J, rc
 
+    # ---- aero path constraints (lib/con_aero.py): kind in AERO_KINDS ----
+    AERO_KINDS = ["alpha", "q", "qalpha"]
+    AERO_VARS = ["position", "velocity", "quaternion", "t"]
+
+    def aero_configure(self, kind, spec):
+        """spec: rows of (phase, range_all, limit); limit = units[3] of con_aero.py."""
+        spec = np.asarray(spec, dtype=np.float64).reshape(-1, 3)
+        ph = np.ascontiguousarray(spec[:, 0], dtype=np.int32)
+        ra = np.ascontiguousarray(spec[:, 1], dtype=np.int32)
+        lim = _f64(spec[:, 2])
+        check(lib().gel_aero_configure(self._h, self.AERO_KINDS.index(kind), len(ph), ph.ctypes.data_as(_ip),
+                                       ra.ctypes.data_as(_ip), _d(lim)))
+
+    def aero_dims(self, kind):
+        n = C.c_int32()
+        nnz = (C.c_int64 * 4)()
+        check(lib().gel_aero_dims(self._h, self.AERO_KINDS.index(kind), C.byref(n), nnz))
+        return n.value, [int(v) for v in nnz]
+
+    def aero_pattern(self, kind):
+        nrow, nnz = self.aero_dims(kind)
+        out = []
+        for v in range(4):
+            r = np.zeros(nnz[v], dtype=np.int32)
+            c = np.zeros(nnz[v], dtype=np.int32)
+            check(lib().gel_aero_pattern(self._h, self.AERO_KINDS.index(kind), v, r.ctypes.data_as(_ip),
+                                         c.ctypes.data_as(_ip)))
+            out.append((r, c))
+        return out
+
+    def eval_aero(self, kind, X, want_jac=True):
+        """X [B, nvars] (or [nvars]) -> (con [B, nrows], jac_vals [B, sum nnz] | None, status)"""
+        X = _f64(X).reshape(-1, self.nvars)
+        B = X.shape[0]
+        nrow, nnz = self.aero_dims(kind)
+        con = np.empty((B, nrow))
+        jv = np.empty((B, sum(nnz))) if want_jac else None
+        rc = check(lib().gel_eval_aero(self._h, self.AERO_KINDS.index(kind), B, _d(X), _d(con),
+                                       _d(jv) if want_jac else None))
+        return con, jv, rc
+
     # ------------------------------------------------------------------
     def split_x(self, x):
         M, N, S = self.M, self.N, self.S

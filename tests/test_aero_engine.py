@@ -1,0 +1,100 @@
+"""Aero path constraints through the engine: the COO pattern on a host-only handle
+(CPU, bit-exact vs the reference golden) and values + FD gradients on the GPU vs the oracle and the golden.
+Tolerances as in tests/test_aero_oracle_golden.py (acos conditioning for the alpha / q-alpha gradients)."""
+import numpy as np
+import pytest
+
+from conftest import D_tau_from_golden, load_golden, problem_from_golden
+from test_aero_oracle_golden import ATOL, KINDS, VARS, spec_from_golden
+
+
+@pytest.mark.parametrize("cname", ["example", "synthetic"])
+def test_aero_pattern_host_only(cname):
+    from gelato_amd import Engine, _lib
+    g = load_golden("g9_aero_example.npz")
+    prob = problem_from_golden(g)
+    E = Engine(prob, device=-1)
+    for kind in KINDS:
+        spec = spec_from_golden(g, cname, kind)
+        E.aero_configure(kind, spec)
+        nrow, nnz = E.aero_dims(kind)
+        if len(spec) == 0:
+            assert nrow == 0
+            continue
+        assert nrow == len(g["%s_%s_con" % (cname, kind)])
+        for v, (r, c) in enumerate(E.aero_pattern(kind)):
+            key = "%s_%s_jac_%s" % (cname, kind, VARS[v])
+            assert np.array_equal(r, g[key + "_rows"]) and np.array_equal(c, g[key + "_cols"]), key
+    with pytest.raises(_lib.GelatoAmdError, match="host-only"):
+        E.eval_aero("alpha", g["x"])
+    with pytest.raises(_lib.GelatoAmdError):
+        E.aero_configure("alpha", [(11, 1, 0.1)])        # the last phase is never constrained
+    with pytest.raises(_lib.GelatoAmdError):
+        E.aero_configure("alpha", [(3, 1, 0.1), (2, 1, 0.1)])   # phases must increase
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cname", ["example", "synthetic"])
+def test_aero_values_and_gradients_gpu(cname):
+    import oracle
+    from gelato_amd import Engine
+    g = load_golden("g9_aero_example.npz")
+    prob = problem_from_golden(g)
+    D, tau = D_tau_from_golden(g, prob)
+    E = Engine(prob, D=D, tau=tau)
+    P = oracle.Problem(prob, D=D, tau=tau)
+    x = g["x"]
+    X = np.stack([x, x * (1 + 1e-7), x])
+    for kind in KINDS:
+        spec = spec_from_golden(g, cname, kind)
+        E.aero_configure(kind, spec)
+        P.aero_configure(kind, spec)
+        if len(spec) == 0:
+            continue
+        con, jv, rc = E.eval_aero(kind, X)
+        assert rc == 0 and np.array_equal(con[0], con[2]) and np.array_equal(jv[0], jv[2])
+        ref = g["%s_%s_con" % (cname, kind)]
+        oc = P.aero_residual(kind, x)
+        for a, b in ((con[0], ref), (con[0], oc), (con[1], P.aero_residual(kind, X[1]))):
+            assert np.all(np.abs(a - b) <= 1e-12 + 1e-10 * np.abs(b)), (kind, np.abs(a - b).max())
+        Jo = P.aero_jacobian(kind, x)
+        off = 0
+        nrow, nnz = E.aero_dims(kind)
+        for v, var in enumerate(VARS):
+            vals = jv[0, off:off + nnz[v]]
+            off += nnz[v]
+            for rv in (g["%s_%s_jac_%s_vals" % (cname, kind, var)], Jo[var]["coo"][2]):
+                assert vals.shape == rv.shape
+                assert np.all(np.abs(vals - rv) <= ATOL[kind] + 1e-6 * np.abs(rv)), (kind, var, np.abs(vals - rv).max())
+
+
+@pytest.mark.gpu
+def test_con_aero_shim_like_reference():
+    from gelato_amd import con_aero, problem
+    g = load_golden("g9_aero_example.npz")
+    pdict, unitdict, condition, xdict = problem.make_problem("example")
+    M, N = pdict["M"], pdict["N"]
+    x = g["x"]
+    o = np.cumsum([0, M, 3 * M, 3 * M, 4 * M, 2 * N, pdict["num_sections"] + 1])
+    xd = {k: x[o[i]:o[i + 1]].copy() for i, k in enumerate(["mass", "position", "velocity", "quaternion", "u", "t"])}
+    cond = {"AOA_max": {"MECO": {"value": 10.0, "range": "initial"}}, "dynamic_pressure_max": {},
+            "Q_alpha_max": {"ZEROLIFT_START": {"value": 30000.0, "range": "all"}}}
+    assert con_aero.inequality_max_q(xd, pdict, unitdict, cond) is None
+    assert con_aero.inequality_jac_max_q(xd, pdict, unitdict, cond) is None
+    assert con_aero.inequality_length_max_q(xd, pdict, unitdict, cond) == 0
+    assert con_aero.inequality_length_max_alpha(xd, pdict, unitdict, cond) == 1
+    assert con_aero.inequality_length_max_qalpha(xd, pdict, unitdict, cond) == 17
+    for kind, fn, jfn in [("alpha", con_aero.inequality_max_alpha, con_aero.inequality_jac_max_alpha),
+                          ("qalpha", con_aero.inequality_max_qalpha, con_aero.inequality_jac_max_qalpha)]:
+        con = fn(xd, pdict, unitdict, cond)
+        ref = g["example_%s_con" % kind]
+        # the shim's problem uses the engine's own tau (<= 1e-14 from the reference's): t nodes move by ~1e-14
+        assert con.shape == ref.shape and np.all(np.abs(con - ref) <= 1e-9 + 1e-9 * np.abs(ref))
+        jac = jfn(xd, pdict, unitdict, cond)
+        assert list(jac) == VARS
+        for var in VARS:
+            key = "example_%s_jac_%s" % (kind, var)
+            r, c, v = jac[var]["coo"]
+            assert np.array_equal(r, g[key + "_rows"]) and np.array_equal(c, g[key + "_cols"])
+            assert jac[var]["shape"] == tuple(g[key + "_shape"])
+            assert np.all(np.abs(v - g[key + "_vals"]) <= ATOL[kind] + 1e-6 * np.abs(g[key + "_vals"]))
