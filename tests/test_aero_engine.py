@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import D_tau_from_golden, load_golden, problem_from_golden
-from test_aero_oracle_golden import ATOL, KINDS, VARS, spec_from_golden
+from test_aero_oracle_golden import ATOL, CTOL, KINDS, VARS, spec_from_golden
 
 
 @pytest.mark.parametrize("cname", ["example", "synthetic"])
@@ -56,7 +56,7 @@ def test_aero_values_and_gradients_gpu(cname):
         ref = g["%s_%s_con" % (cname, kind)]
         oc = P.aero_residual(kind, x)
         for a, b in ((con[0], ref), (con[0], oc), (con[1], P.aero_residual(kind, X[1]))):
-            assert np.all(np.abs(a - b) <= 1e-12 + 1e-10 * np.abs(b)), (kind, np.abs(a - b).max())
+            assert np.all(np.abs(a - b) <= CTOL[kind] + 1e-10 * np.abs(b)), (kind, np.abs(a - b).max())
         Jo = P.aero_jacobian(kind, x)
         off = 0
         nrow, nnz = E.aero_dims(kind)

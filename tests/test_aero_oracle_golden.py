@@ -8,6 +8,9 @@ limit = 10 deg that is 4e-16/(3e-3 * 0.17 * 1e-8) = 8e-5 per evaluation, measure
 reference's Python twin and this C restatement -- so those gradients get |d| <= 5e-4 + 1e-6*|ref|
 (entries are O(10..3000))."""
 ATOL = {"alpha": 5e-4, "q": 1e-5, "qalpha": 5e-4}
+# constraint values: one ulp of cos(alpha) is eps/sin(alpha) in alpha, times q/limit for q-alpha (3e-13 at
+# q = 30 kPa, alpha = 1 deg) -- and the example trajectory rides the q-alpha limit (values ~1e-8)
+CTOL = {"alpha": 1e-11, "q": 1e-12, "qalpha": 1e-11}
 import numpy as np
 import pytest
 
@@ -41,7 +44,7 @@ def test_g9_aero_constraints(cname):
             continue
         ref = g["%s_%s_con" % (cname, kind)]
         assert con.shape == ref.shape
-        assert np.all(np.abs(con - ref) <= 1e-12 + 1e-10 * np.abs(ref)), (kind, np.abs(con - ref).max())
+        assert np.all(np.abs(con - ref) <= CTOL[kind] + 1e-10 * np.abs(ref)), (kind, np.abs(con - ref).max())
         J = P.aero_jacobian(kind, x)
         for var in VARS:
             key = "%s_%s_jac_%s" % (cname, kind, var)
