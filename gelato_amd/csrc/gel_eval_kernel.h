@@ -8,28 +8,35 @@
 // Memory discipline: vector-memory operations retire in order (one vmcnt per
 // wave), so a global load issued after a store waits for that store to drain to
 // HBM.  Therefore EVERY global load happens before the first store: the D.X
-// product runs first, and what is needed again late (quaternion, velocity,
-// mass, rates, the D.X rows of the velocity/quaternion defects) is parked in LDS
-// (its own lgkmcnt) instead of being re-read or kept in VGPRs.
+// product runs first, the groups that need no velocity RHS (position Jacobian
+// entries, the whole quaternion group) are finished right after it while their
+// inputs are in registers, and what the velocity group needs late is parked in
+// LDS (its own lgkmcnt) instead of being re-read or kept in VGPRs.
 //
-// Register discipline (fp64 = 2 VGPRs per value, 64-wide): the heavy chain
-// (geodetic -> atmosphere -> wind -> Earth-angle quaternion -> aero) has ONE
-// instance, in a loop whose LAST trip is the centre point and leaves through
-// `break`; nothing the later sweeps need is carried across a heavy trip.
+// Register discipline (fp64 = 2 VGPRs per value, 64-wide; 112 VGPRs -> 4 waves
+// per SIMD): the heavy chain (geodetic -> atmosphere -> wind -> Earth-angle
+// quaternion -> aero) has ONE instance, in a loop whose LAST trip is the centre
+// point and leaves through `break`; across a trip only the node position, the
+// Earth angle and 1/m stay in registers -- velocity and thrust direction are
+// re-formed from the park, position-sweep results wait in the park, and centre
+// values that only a later sweep block needs are parked as soon as they exist.
 #pragma once
 
 namespace gel {
 
 // per-lane LDS park, one region per wavefront ([slot][lane]: consecutive lanes hit consecutive banks).
 // The MFMA D.X path first uses the wave's region as the 64 x 17 staging tile of its result.
-enum ParkSlot { PK_Q0 = 0, PK_Q1, PK_Q2, PK_Q3, PK_V0, PK_V1, PK_V2, PK_ME, PK_U0, PK_U1, PK_DJJ,
-                PK_LV0, PK_LV1, PK_LV2, PK_LQ0, PK_LQ1, PK_LQ2, PK_LQ3, PK_COUNT };
+// Q, V, DJJ: inputs the velocity sweeps re-read; LV: D.X row of the velocity defect; FP: results of the
+// position sweeps waiting for the centre value.  19 slots = 9.5 KB per wavefront: 16 wavefronts per CU fit
+// the 160 KB LDS.
+enum ParkSlot { PK_Q0 = 0, PK_Q1, PK_Q2, PK_Q3, PK_V0, PK_V1, PK_V2, PK_DJJ, PK_LV0, PK_LV1, PK_LV2,
+                PK_FP0, PK_FP1, PK_FP2, PK_FP3, PK_FP4, PK_FP5, PK_FP6, PK_FP7, PK_COUNT };
 constexpr int kStageLd = 17;                     // padded row of the staging tile: conflict-free row reads
 constexpr int kWaveLds = PK_COUNT * 64;          // doubles per wavefront
 static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wave's park region");
 
 #ifndef GEL_MIN_WAVES_PER_SIMD
-#define GEL_MIN_WAVES_PER_SIMD 3  // ~150 VGPRs fit 3 waves/SIMD without spilling; forcing 4 spills and is slower
+#define GEL_MIN_WAVES_PER_SIMD 4  // 112 VGPRs, no scratch: 4 waves/SIMD (16 per CU, matching the LDS budget); 5 spills
 #endif
 
 typedef double gel_double4 __attribute__((ext_vector_type(4)));
@@ -96,11 +103,9 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   const double me = xm[xj];
   const double re[3] = {xr[3 * xj], xr[3 * xj + 1], xr[3 * xj + 2]};
   const double tau = P.tau[ph.toff + jc];
-  double dir[3];
   {
     const double q[4] = {xq[4 * xj], xq[4 * xj + 1], xq[4 * xj + 2], xq[4 * xj + 3]};
     const double ve[3] = {xv[3 * xj], xv[3 * xj + 1], xv[3 * xj + 2]};
-    thrust_dir(q, dir);
     double u0 = 0.0, u1 = 0.0;
     if (!ph.hold) { u0 = xu[2 * (ph.ua + jc)]; u1 = xu[2 * (ph.ua + jc) + 1]; }
     const double djj = JAC ? P.Dt[ph.doff + (size_t)(jc + 1) * n + jc] : 0.0;  // D[j][j+1]
@@ -173,23 +178,72 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
       }
     }
     if (MFMA && !active) return;  // ragged tail: nothing to write
-    // the staging tile has been consumed: the region now becomes the park
+    // the staging tile has been consumed: the region now becomes the park of what the velocity group
+    // needs late (its sweeps re-read quaternion, velocity and D[j][j+1]; its defect needs the D.X row)
     PARK(PK_Q0) = q[0]; PARK(PK_Q1) = q[1]; PARK(PK_Q2) = q[2]; PARK(PK_Q3) = q[3];
     PARK(PK_V0) = ve[0]; PARK(PK_V1) = ve[1]; PARK(PK_V2) = ve[2];
-    PARK(PK_ME) = me;
-    if (!ph.hold) { PARK(PK_U0) = u0; PARK(PK_U1) = u1; }
     if (JAC) PARK(PK_DJJ) = djj;
-    if (rb) {
-      PARK(PK_LV0) = lv[0]; PARK(PK_LV1) = lv[1]; PARK(PK_LV2) = lv[2];
-      PARK(PK_LQ0) = lq[0]; PARK(PK_LQ1) = lq[1]; PARK(PK_LQ2) = lq[2]; PARK(PK_LQ3) = lq[3];
-      const double m0 = ph.engine_on ? 0.0 : xm[ph.xa];
-      double q0[4] = {0, 0, 0, 0};
-      if (ph.hold) {
+    if (rb) { PARK(PK_LV0) = lv[0]; PARK(PK_LV1) = lv[1]; PARK(PK_LV2) = lv[2]; }
+    // last global loads: the reference rows of engine-off / hold phases
+    const double m0 = (rb && !ph.engine_on) ? xm[ph.xa] : 0.0;
+    double q0[4] = {0, 0, 0, 0};
+    if (rb && ph.hold) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) q0[c] = xq[4 * ph.xa + c];
-      }
+      for (int c = 0; c < 4; c++) q0[c] = xq[4 * ph.xa + c];
+    }
 
-      // ---- first stores: mass, position (and hold-type quaternion) defects (:34-63,116-152,521-522) ----
+    // ---- everything that needs no velocity RHS is finished here, while its inputs are in registers:
+    //      position Jacobian entries, the whole quaternion group (:155-213, :499-632) ----
+    if (JAC) {
+      const double rh_vel = -P.uv * (tf - to) * ut / 2.0 / P.up;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        EMIT(0 + c, rh_vel);
+        const double rh_to = ve[c] * P.uv * ut / 2.0 / P.up;
+        EMIT(3 + c, rh_to);
+        EMIT(6 + c, -rh_to);
+      }
+    }
+    if (!ph.hold) {
+      double fq[4];
+      quat_rate(q, u0, u1, P.uu, fq);
+      if (rb) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const double rh = fq[c] * (tf - to) * ut / 2.0;
+          const double cq = lq[c] - rh;
+          rb[7 * N + 4 * g + c] = cq;
+          chk += cq;
+        }
+      }
+      if (JAC) {
+        double f[4];
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+          double qp[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) qp[c] = (k == c) ? (q[c] + dx) : q[c];
+          quat_rate(qp, u0, u1, P.uu, f);
+          // submat_quat[4j+c, 4(j+1)+k] = D[j][j+1]*(c==k) + rh_quat   (con_dynamics.py:575-589)
+#pragma unroll
+          for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 4 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fq[c]));
+        }
+#pragma unroll 1
+        for (int k = 0; k < 2; k++) {
+          quat_rate(q, (k == 0) ? u0 + dx : u0, (k == 1) ? u1 + dx : u1, P.uu, f);
+#pragma unroll
+          for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 16 + 4 * k + c, FDQ(f[c], fq[c]));
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const double rh_to = fq[c] * ut / 2.0;
+          EMIT(ph.s_qq + 24 + c, rh_to);
+          EMIT(ph.s_qq + 28 + c, -rh_to);
+        }
+      }
+    }
+    if (rb) {
+      // ---- mass, position (and hold-type quaternion) defects (:34-63,116-152,521-522) ----
       double cm;
       if (ph.engine_on) {
         const double rh = -ph.massflow / P.um * (tf - to) * ut / 2.0;
@@ -227,12 +281,12 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     const double inv_m = 1.0 / (me * P.um);
 
     if (ph.air) {
-      const double v[3] = {PARK(PK_V0) * P.uv, PARK(PK_V1) * P.uv, PARK(PK_V2) * P.uv};
       const EarthAngle ea = earth_angle(tn);  // position sweeps do not change it
-      // Trips k = 0,1,2: position sweeps (pos_k + dx); trip k = 3: centre, leaves by break.
-      double fp[3][3];
+      // Trips k = 0,1,2: position sweeps (pos_k + dx); trip k = 3: centre, leaves by break.  Nothing but
+      // the node position, the Earth angle and 1/m stays in registers across a trip: velocity and thrust
+      // direction are re-formed from the park after the atmosphere chain, sweep results go to the park.
       PosPart pp;
-      double w[3], F[3], T;
+      double v[3], dir[3], w[3], F[3], T, fp8 = 0.0;
 #pragma unroll 1
       for (int k = JAC ? 0 : 3;; k++) {
         double r[3];
@@ -240,24 +294,38 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
         pp = pos_part(r, tb, P.barC20);
         wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = PARK(PK_V0 + c) * P.uv;
         aero_force(r, v, pp.rho, pp.a, ea, w, ph.area, tb, F);
         T = ph.thrust - ph.nozzle * pp.P;
+        {
+          const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
+          thrust_dir(q, dir);
+        }
         const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
         accel(Td, F, inv_m, pp.g, inv_uv, fc);
         if (k == 3) break;
+        // park the sweep result (9 values: 8 LDS slots + one register)
+        if (k < 2) {
 #pragma unroll
-        for (int kk = 0; kk < 3; kk++)
-          if (k == kk) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) fp[kk][c] = fc[c];
-          }
+          for (int c = 0; c < 3; c++) PARK(PK_FP0 + 3 * k + c) = fc[c];
+        } else {
+          PARK(PK_FP6) = fc[0];
+          PARK(PK_FP7) = fc[1];
+          fp8 = fc[2];
+        }
       }
-      // here pp, w, F, T, fc are the centre values
+      // here pp, w, F, T, v, dir, fc are the centre values
       if (JAC) {
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) EMIT(12 + 3 * k + c, FDQ(fp[k][c], fc[c]));
+        for (int i = 0; i < 8; i++) EMIT(12 + i, FDQ(PARK(PK_FP0 + i), fc[i % 3]));
+        EMIT(12 + 8, FDQ(fp8, fc[2]));
+
+        // The position-sweep slots are free now.  Values that only LATER blocks need leave the registers:
+        // the t0/tf sweeps' inputs (half-latitude pair, 1/p, wind) and the centre aero force.
+        PARK(PK_FP0) = pp.shp; PARK(PK_FP1) = pp.chp; PARK(PK_FP2) = pp.inv_p; PARK(PK_FP3) = pp.wn; PARK(PK_FP4) = pp.we;
+        PARK(PK_FP5) = F[0]; PARK(PK_FP6) = F[1]; PARK(PK_FP7) = F[2];
+        asm volatile("" ::: "memory");
 
         const double r[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
         const double Tdc[3] = {T * dir[0], T * dir[1], T * dir[2]};
@@ -277,6 +345,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
             for (int c = 0; c < 3; c++) EMIT(ph.s_vv + 3 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fc[c]));
           }
         }
+        const double Fc[3] = {PARK(PK_FP5), PARK(PK_FP6), PARK(PK_FP7)};
         // quaternion sweeps: only the thrust direction changes
         {
           const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
@@ -288,27 +357,37 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
             double dp[3];
             thrust_dir(qp, dp);
             const double Td[3] = {T * dp[0], T * dp[1], T * dp[2]};
-            accel(Td, F, inv_m, pp.g, inv_uv, f);
+            accel(Td, Fc, inv_m, pp.g, inv_uv, f);
 #pragma unroll
             for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
           }
         }
         // mass sweep: only the division by mass changes
-        accel(Tdc, F, 1.0 / ((me + dx) * P.um), pp.g, inv_uv, f);
+        accel(Tdc, Fc, 1.0 / ((me + dx) * P.um), pp.g, inv_uv, f);
 #pragma unroll
         for (int c = 0; c < 3; c++) EMIT(9 + c, FDQ(f[c], fc[c]));
         // t0 / tf sweeps (con_dynamics.py:452-480): only the Earth angle changes
         if (ph.air_fd) {
+          // quaternion, D[j][j+1] and force slots are free now: the rest of what these two sweeps need is
+          // parked there, so that only the node position lives in registers across the sincos chains of
+          // earth_angle()
+          PARK(PK_Q0) = pp.rho; PARK(PK_Q1) = pp.a; PARK(PK_Q2) = Tdc[0]; PARK(PK_Q3) = Tdc[1]; PARK(PK_DJJ) = Tdc[2];
+          PARK(PK_FP5) = pp.g[0]; PARK(PK_FP6) = pp.g[1]; PARK(PK_FP7) = pp.g[2];
 #pragma unroll 1
           for (int k = 0; k < 2; k++) {
+            asm volatile("" ::: "memory");  // re-read the park inside every trip
             const double to_p = (k == 0) ? to + dx : to;
             const double tf_p = (k == 1) ? tf + dx : tf;
             const double tnp = tau * (tf_p - to_p) / 2 + (tf_p + to_p) / 2;
             const EarthAngle eq = earth_angle(tnp);
             double wq[3], Fp[3];
-            wind_eci(r, eq, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, wq);
-            aero_force(r, v, pp.rho, pp.a, eq, wq, ph.area, tb, Fp);
-            accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
+            const double rq[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
+            wind_eci(rq, eq, PARK(PK_FP0), PARK(PK_FP1), PARK(PK_FP2), PARK(PK_FP3), PARK(PK_FP4), wq);
+            const double vq[3] = {PARK(PK_V0) * P.uv, PARK(PK_V1) * P.uv, PARK(PK_V2) * P.uv};
+            aero_force(rq, vq, PARK(PK_Q0), PARK(PK_Q1), eq, wq, ph.area, tb, Fp);
+            const double Tq[3] = {PARK(PK_Q2), PARK(PK_Q3), PARK(PK_DJJ)};
+            const double gq[3] = {PARK(PK_FP5), PARK(PK_FP6), PARK(PK_FP7)};
+            accel(Tq, Fp, inv_m, gq, inv_uv, f);
             // -(f_p*(tf_p - to_p) - f_c*(tf - to))/dx*unit_t/2   (con_dynamics.py:463-477)
 #pragma unroll
             for (int c = 0; c < 3; c++)
@@ -326,6 +405,11 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     } else {
       // NoAir (reference_area == 0): thrust + gravity only (src/pybind_dynamics.cpp:73-92)
       const double T = ph.thrust;
+      double dir[3];
+      {
+        const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
+        thrust_dir(q, dir);
+      }
       const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
       double gc[3];
       {
@@ -380,58 +464,6 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     }
   }
 
-  // ---------------- position / quaternion Jacobian entries, quaternion defect (:155-213, :499-632) ----------------
-  if (JAC) {
-    const double rh_vel = -P.uv * (tf - to) * ut / 2.0 / P.up;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      EMIT(0 + c, rh_vel);
-      const double rh_to = PARK(PK_V0 + c) * P.uv * ut / 2.0 / P.up;
-      EMIT(3 + c, rh_to);
-      EMIT(6 + c, -rh_to);
-    }
-  }
-  if (!ph.hold) {
-    const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
-    const double u0 = PARK(PK_U0), u1 = PARK(PK_U1);
-    double fq[4];
-    quat_rate(q, u0, u1, P.uu, fq);
-    if (rb) {
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const double rh = fq[c] * (tf - to) * ut / 2.0;
-        const double cq = PARK(PK_LQ0 + c) - rh;
-        rb[7 * N + 4 * g + c] = cq;
-        chk += cq;
-      }
-    }
-    if (JAC) {
-      const double djj = PARK(PK_DJJ);
-      double f[4];
-#pragma unroll 1
-      for (int k = 0; k < 4; k++) {
-        double qp[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) qp[c] = (k == c) ? (q[c] + dx) : q[c];
-        quat_rate(qp, u0, u1, P.uu, f);
-        // submat_quat[4j+c, 4(j+1)+k] = D[j][j+1]*(c==k) + rh_quat   (con_dynamics.py:575-589)
-#pragma unroll
-        for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 4 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fq[c]));
-      }
-#pragma unroll 1
-      for (int k = 0; k < 2; k++) {
-        quat_rate(q, (k == 0) ? u0 + dx : u0, (k == 1) ? u1 + dx : u1, P.uu, f);
-#pragma unroll
-        for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 16 + 4 * k + c, FDQ(f[c], fq[c]));
-      }
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const double rh_to = fq[c] * ut / 2.0;
-        EMIT(ph.s_qq + 24 + c, rh_to);
-        EMIT(ph.s_qq + 28 + c, -rh_to);
-      }
-    }
-  }
 #undef EMIT
 #undef FDQ
 #undef PARK
