@@ -188,35 +188,43 @@ GEL_DEV void quatrot(const double q[4], const double v[3], double out[3]) {
 // clamped linear interpolation: src/wrapper_utils.hpp:51-80, with np.interp's
 // value at x == xp[0].  Tables live in LDS.
 // ---------------------------------------------------------------------------
-GEL_DEV double interp_tab(double x, const double* tab, int n, int stride, int ycol) {
-  if (x <= tab[0]) return tab[ycol];
-  if (x > tab[(n - 1) * stride]) return tab[(n - 1) * stride + ycol];
-  int lo = 0, hi = n;  // std::lower_bound
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (tab[mid * stride] < x) lo = mid + 1; else hi = mid;
+// std::lower_bound on a sorted LDS column = number of entries < x.  Small tables (the usual case: 7-9
+// rows) are counted with independent broadcast reads -- no dependent LDS round trips, no divergent
+// loop; long tables fall back to the binary search.
+GEL_DEV int lower_count(double x, const double* tab, int n, int stride) {
+  int lo = 0;
+  if (n <= 32) {
+    for (int i = 0; i < n; i++) lo += (tab[i * stride] < x) ? 1 : 0;
+  } else {
+    int hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (tab[mid * stride] < x) lo = mid + 1; else hi = mid;
+    }
   }
-  const int idx = lo - 1;
+  return lo;
+}
+
+GEL_DEV double interp_tab(double x, const double* tab, int n, int stride, int ycol) {
+  const int idx = min(max(lower_count(x, tab, n, stride) - 1, 0), n - 2);
   const double xl = tab[idx * stride], xu = tab[(idx + 1) * stride];
   const double yl = tab[idx * stride + ycol], yu = tab[(idx + 1) * stride + ycol];
   const double alpha = (x - xl) / (xu - xl);
-  return yl + alpha * (yu - yl);
+  const double v = yl + alpha * (yu - yl);
+  // clamps of the reference (and yp[0] at x == xp[0]) as selects instead of early returns
+  return (x <= tab[0]) ? tab[ycol] : ((x > tab[(n - 1) * stride]) ? tab[(n - 1) * stride + ycol] : v);
 }
 
 // both wind components share one bracket search (src/wrapper_utils.hpp:82-87 runs it twice)
 GEL_DEV void wind_ned2(double h, const double* tab, int n, double& wn, double& we) {
-  if (h <= tab[0]) { wn = tab[1]; we = tab[2]; return; }
-  if (h > tab[(n - 1) * 3]) { wn = tab[(n - 1) * 3 + 1]; we = tab[(n - 1) * 3 + 2]; return; }
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (tab[mid * 3] < h) lo = mid + 1; else hi = mid;
-  }
-  const int idx = lo - 1;
+  const int idx = min(max(lower_count(h, tab, n, 3) - 1, 0), n - 2);
   const double xl = tab[idx * 3], xu = tab[(idx + 1) * 3];
   const double alpha = (h - xl) / (xu - xl);
-  wn = tab[idx * 3 + 1] + alpha * (tab[(idx + 1) * 3 + 1] - tab[idx * 3 + 1]);
-  we = tab[idx * 3 + 2] + alpha * (tab[(idx + 1) * 3 + 2] - tab[idx * 3 + 2]);
+  const double vn = tab[idx * 3 + 1] + alpha * (tab[(idx + 1) * 3 + 1] - tab[idx * 3 + 1]);
+  const double ve = tab[idx * 3 + 2] + alpha * (tab[(idx + 1) * 3 + 2] - tab[idx * 3 + 2]);
+  const bool below = h <= tab[0], above = h > tab[(n - 1) * 3];
+  wn = below ? tab[1] : (above ? tab[(n - 1) * 3 + 1] : vn);
+  we = below ? tab[2] : (above ? tab[(n - 1) * 3 + 2] : ve);
 }
 
 }  // namespace gel

@@ -69,10 +69,13 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
 // depends on time only: src/Coordinate.cpp:41-59 (cos/sin(omega t)), :75-79 (half angle)
 struct EarthAngle { double c, s, ch, sh; };
 
+// One sincos of the half angle; the full angle by the double-angle identities (<= 2 ulp from a second
+// sincos, and the same pair serves the centre and every sweep that does not move t).
 GEL_DEV EarthAngle earth_angle(double t) {
   EarthAngle e;
-  sincos(kOmega * t, &e.s, &e.c);
   sincos(kOmega * t / 2.0, &e.sh, &e.ch);
+  e.s = 2.0 * e.sh * e.ch;
+  e.c = (e.ch - e.sh) * (e.ch + e.sh);
   return e;
 }
 
