@@ -49,9 +49,14 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
   // exactly that round-off, so sin/cos(lat) are taken the reference's way (atan2, then sincos): measured,
   // the algebraic pair of geodetic_sincos() is equally accurate but decorrelates the FD noise from the
   // reference's (3e-4 on vel/position entries of a polar, high-dynamic-pressure test state).
-  double lat, p, sl, cl;
+  double p, sl, cl;
+#ifdef GEL_AB_LATALG  // A/B switch for tools/variant.sh only: the algebraic pair (see the comment above)
+  geodetic_sincos(r[0], r[1], r[2], sl, cl, p);
+#else
+  double lat;
   geodetic_lat_p(r[0], r[1], r[2], lat, p);
   sincos(lat, &sl, &cl);
+#endif
   o.inv_p = 1.0 / p;
   // half-angle pair of the NED quaternion (src/Coordinate.cpp:89-90): cos(lat/2) = sqrt((1+cos lat)/2)
   // (cos lat >= 0), sin(lat/2) = sin lat / (2 cos(lat/2))
