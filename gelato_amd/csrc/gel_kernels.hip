@@ -50,30 +50,33 @@ namespace gel {
 
 // ---------------------------------------------------------------------------
 // compact -> full COO values.  src[i] < 0: constant cval[i]; else jvar[b][src[i]].
-// Two doubles (16 B) per lane: wide coalesced stores; the template (cval, src)
-// is shared by all b and stays in L2 / Infinity Cache.
+// Two doubles (16 B) per lane: wide coalesced stores.  A thread keeps its two template entries
+// (cval, src: 12 B per entry, 7.3 MB at 6x64 -- larger than one XCD's L2) in registers and re-uses them
+// for kExpandGroup decision vectors, so the template is read once per group instead of once per vector
+// and the kernel is bounded by its 8 B/entry of HBM writes.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void expand_kernel(long long nnz, long long V, const double* __restrict__ cval,
+constexpr int kExpandGroup = 8;
+__global__ __launch_bounds__(kBlock) void expand_kernel(long long nnz, long long V, int B, const double* __restrict__ cval,
                                                         const int32_t* __restrict__ src,
                                                         const double* __restrict__ jvar, double* __restrict__ full) {
-  const int b = blockIdx.y;
-  const double* jv = jvar + (size_t)b * V;
-  double* out = full + (size_t)b * nnz;
-  const bool aligned = ((((size_t)b * nnz) & 1) == 0);
+  const int b0 = blockIdx.y * kExpandGroup;
+  const int nb = min(kExpandGroup, B - b0);
+  const bool even = (nnz & 1) == 0;  // then every vector's slice starts 16-byte aligned
   for (long long i = 2 * ((long long)blockIdx.x * kBlock + threadIdx.x); i < nnz; i += 2LL * gridDim.x * kBlock) {
-    const int s0 = src[i];
-    const double v0 = (s0 < 0) ? cval[i] : jv[s0];
-    if (i + 1 < nnz) {
-      const int s1 = src[i + 1];
-      const double v1 = (s1 < 0) ? cval[i + 1] : jv[s1];
-      if (aligned) {
-        *reinterpret_cast<double2*>(out + i) = make_double2(v0, v1);
+    const bool two = i + 1 < nnz;
+    const int s0 = src[i], s1 = two ? src[i + 1] : -1;
+    const double c0 = (s0 < 0) ? cval[i] : 0.0, c1 = (two && s1 < 0) ? cval[i + 1] : 0.0;
+    for (int g = 0; g < nb; g++) {
+      const double* jv = jvar + (size_t)(b0 + g) * V;
+      double* out = full + (size_t)(b0 + g) * nnz + i;
+      const double v0 = (s0 < 0) ? c0 : jv[s0];
+      const double v1 = (s1 < 0) ? c1 : jv[s1];
+      if (two && (even || ((b0 + g) & 1) == 0)) {
+        *reinterpret_cast<double2*>(out) = make_double2(v0, v1);
       } else {
-        out[i] = v0;
-        out[i + 1] = v1;
+        out[0] = v0;
+        if (two) out[1] = v1;
       }
-    } else {
-      out[i] = v0;
     }
   }
 }
@@ -357,10 +360,11 @@ hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, 
   long long pairs = (nnz + 1) / 2;
   unsigned gx = (unsigned)((pairs + kBlock - 1) / kBlock);
   if (gx > 4096) gx = 4096;
-  for (int b0 = 0; b0 < B; b0 += 65535) {
-    const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
-    hipLaunchKernelGGL(expand_kernel, dim3(gx, nb), dim3(kBlock), 0, s, nnz, V, cval, src,
-                       d_jvar + (size_t)b0 * V, d_full + (size_t)b0 * nnz);
+  const int per_launch = 65535 * kExpandGroup;  // grid.y limit
+  for (int b0 = 0; b0 < B; b0 += per_launch) {
+    const int nb = (B - b0 < per_launch) ? (B - b0) : per_launch;
+    hipLaunchKernelGGL(expand_kernel, dim3(gx, (nb + kExpandGroup - 1) / kExpandGroup), dim3(kBlock), 0, s, nnz, V, nb,
+                       cval, src, d_jvar + (size_t)b0 * V, d_full + (size_t)b0 * nnz);
   }
   return hipGetLastError();
 }
