@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="decision vectors per GPU per step")
     ap.add_argument("--workload", default="mixed-6x64", help="mixed-6x64 | dense-6x64 | 3x32 | stress-12x128 | example")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "phase-shard"],
+                    help="replicas: B vectors per GPU, no collective (weak scaling, the headline). phase-shard: ONE "
+                         "batch of B vectors evaluated by all GPUs together, work items dealt to ranks, one RCCL "
+                         "sum all-reduce per step (strong scaling; BASELINE.json config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational full-COO and B=1 legs")
     a = ap.parse_args()
@@ -94,14 +98,28 @@ def main():
     B, K, W = a.batch, a.steps, a.warmup
 
     x0 = pack_x(xdict)
-    X = problem.synthetic_batch(x0, E.M, B, seed=20260313 + rank * B)
+    shard = a.mode == "phase-shard" and world > 1
+    X = problem.synthetic_batch(x0, E.M, B, seed=20260313 + (0 if shard else rank * B))
     dX = torch.from_numpy(X).to(dev)
     dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
     djv = torch.empty((B, E.V), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream  # the engine launches on torch's current stream
 
-    def step():
-        E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), stream)
+    if shard:
+        from gelato_amd import parallel
+        ranges = parallel.shard_chunks(parallel.chunk_costs(E), world)
+        c0, cn = ranges[rank]
+
+        def step():
+            # every entry of res / jvar has exactly one owning rank: zero, fill own work items, sum all-reduce
+            dres.zero_()
+            djv.zero_()
+            E.eval_shard_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), c0, cn, stream)
+            dist.all_reduce(dres, op=dist.ReduceOp.SUM)
+            dist.all_reduce(djv, op=dist.ReduceOp.SUM)
+    else:
+        def step():
+            E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), stream)
 
     def barrier():
         if world > 1:
@@ -146,7 +164,7 @@ def main():
         check = {"residual_max_abs_diff": float(np.max(np.abs(r0 - ores[0]))),
                  "jacobian_max_abs_diff": float(np.max(np.abs(full0 - ovals[0])))}
 
-    evals = world * B * K
+    evals = (1 if shard else world) * B * K
     abytes = E.algorithmic_bytes * B  # per launch: SURVEY.md 8(d) A_min x evals per launch
     achieved = abytes / (kern_ms * 1e-3) / 1e9
     traffic = None
@@ -160,10 +178,10 @@ def main():
         "metric": "residual+Jacobian evals/sec (and ms/eval), 6-phase x 64-node LGR mesh",
         "value": evals / T, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * T / K, "ms_per_eval": 1e3 * T / (B * K), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": a.workload, "phases": int(S), "nodes_per_phase": [int(n) for n in prob["num_nodes"]],
                    "batch_per_gpu": B, "decision_vars": E.nvars, "residual_rows": E.nres,
-                   "jacobian_values_per_eval": E.V, "coo_nnz": E.total_nnz, "parallelism": "replicas x%d" % world,
+                   "jacobian_values_per_eval": E.V, "coo_nnz": E.total_nnz, "parallelism": ("phase-shard x%d + all-reduce" if shard else "replicas x%d") % world,
                    "output": "4 defect residuals + all x-dependent COO Jacobian values (compact), in HBM"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "gel::eval_kernel<true, true>",
