@@ -509,3 +509,34 @@ def test_dx_mfma_and_valu_paths_agree(name):
     r1, _ = Em.eval_residual(x)
     r2, _ = Ev.eval_residual(x)
     assert np.array_equal(r1, rm) and np.array_equal(r2, rv)
+
+
+def test_single_phase_long_tables_other_units():
+    """S = 1, wind / CA tables longer than 32 rows (binary-search branch of the lookups), another dx and
+    other units than the example's."""
+    prob, _, _ = named_problem("example")
+    rng = np.random.default_rng(11)
+    prob = dict(prob)
+    n = 37
+    prob["num_nodes"] = np.array([n], dtype=np.int32)
+    for k, v in [("thrust", 420000.0), ("massflow", 140.9), ("reference_area", 2.21), ("nozzle_area", 0.68)]:
+        prob[k] = np.array([v])
+    prob["engine_on"] = np.array([1], dtype=np.int32)
+    prob["attitude_hold"] = np.array([0], dtype=np.int32)
+    prob["units"] = np.array([20000.0, 6.4e6, 500.0, 2.0, 300.0])
+    prob["dx"] = 1e-7
+    alt = np.concatenate([[-1e8], np.linspace(0.0, 120e3, 40), [1e10]])
+    prob["wind_table"] = np.column_stack([alt, 20 * np.sin(alt / 7e3), 15 * np.cos(alt / 9e3)])
+    mach = np.concatenate([np.linspace(0.0, 6.0, 35), [100.0]])
+    prob["ca_table"] = np.column_stack([mach, 0.3 + 0.35 * np.exp(-(mach - 1.1) ** 2)])
+    E, P = make_pair(prob)
+    assert E.S == 1 and E.N == n and E.M == n + 1
+    th = 0.75 + np.linspace(0, 0.02, n + 1)
+    R = (6378137.0 + np.linspace(200.0, 90e3, n + 1)) / 6.4e6
+    pos = np.column_stack([R * np.cos(th) * 0.8, R * np.cos(th) * 0.6, R * np.sin(th)])
+    vel = np.column_stack([np.linspace(0.3, 4.0, n + 1), np.linspace(0.6, 2.0, n + 1), np.linspace(0.1, 1.5, n + 1)])
+    quat = rng.standard_normal((n + 1, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([np.linspace(1.2, 0.4, n + 1), pos.ravel(), vel.ravel(), quat.ravel(),
+                        0.5 * rng.standard_normal(2 * n), [0.1, 0.9]])
+    check_against_oracle(E, P, x, "single-phase/long-tables")
