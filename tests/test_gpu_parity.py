@@ -195,7 +195,7 @@ def check_against_oracle(E, P, x, what):
     return res, vals
 
 
-@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64"])
+@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64", "dense6x64"])
 def test_residuals_jacobians_vs_golden_and_oracle(name):
     oracle = _setup()
     g = load_golden("g6_%s.npz" % name)
