@@ -540,3 +540,35 @@ def test_single_phase_long_tables_other_units():
     x = np.concatenate([np.linspace(1.2, 0.4, n + 1), pos.ravel(), vel.ravel(), quat.ravel(),
                         0.5 * rng.standard_normal(2 * n), [0.1, 0.9]])
     check_against_oracle(E, P, x, "single-phase/long-tables")
+
+
+def test_benchmark_batch_against_oracle_in_full():
+    """Every decision vector of a bench-style batch (the exact generator bench.py uses, 512 vectors of the
+    mixed 6 x 64 workload) against the oracle: residuals and all x-dependent Jacobian entries."""
+    import os
+    import torch
+    from gelato_amd import problem
+    prob, x0, _ = named_problem("mixed-6x64")
+    E, P = make_pair(prob)
+    B = 512
+    X = problem.synthetic_batch(x0, E.M, B, seed=20260313)
+    dev = torch.device("cuda:0")
+    dX = torch.from_numpy(X).to(dev)
+    dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    djv = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), s)
+    assert E.sync(s) == 0
+    res, jv = dres.cpu().numpy(), djv.cpu().numpy()
+    vidx = E.var_index()
+    bound = np.concatenate(list(dx_roundoff_bound(E, x0).values()))
+    nthreads = max(1, min(64, len(os.sched_getaffinity(0))))
+    worst_r = worst_j = 0.0
+    for lo in range(0, B, 64):
+        ores, ovals = P.eval_batch(X[lo:lo + 64], nthreads=nthreads)
+        dr = np.abs(res[lo:lo + 64] - ores) - (1e-12 + 2 * bound + 1e-10 * np.abs(ores))
+        ov = ovals[:, vidx]
+        dj = np.abs(jv[lo:lo + 64] - ov) - 1e-6 * np.abs(ov)
+        worst_r, worst_j = max(worst_r, dr.max()), max(worst_j, dj.max())
+    assert worst_r <= 0.0, worst_r
+    assert worst_j <= 1e-5, worst_j
