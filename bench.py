@@ -219,6 +219,15 @@ def main():
         for _ in range(50):
             r, vals, _ = E.eval(x0, out=vals)
         out["b1_host_callback_ms"] = 1e3 * (time.perf_counter() - t0) / 50
+        # informational: the batched host-buffer entry point (pageable caller buffers -> pinned staging -> H2D,
+        # launch, D2H of residuals + compact Jacobian values): PCIe inclusive, never `value`
+        Bh = min(B, 512)
+        E.eval_batch(X[:Bh])
+        t0 = time.perf_counter()
+        E.eval_batch(X[:Bh])
+        dt = time.perf_counter() - t0
+        out["host_batch_pcie_inclusive"] = {"batch": Bh, "evals_per_s": Bh / dt, "ms": 1e3 * dt,
+                                            "bytes_moved": Bh * E.algorithmic_bytes}
 
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(prob, D, tau, X)
