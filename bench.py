@@ -77,14 +77,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # under torch.distributed.run (RANK set) the process group is always created, also for one rank, so
+    # that the barrier / max-over-ranks path is the same code at every N
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from gelato_amd import Engine, con_dynamics, pack_x, problem
 
@@ -122,8 +125,8 @@ def main():
             E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), stream)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(device_ids=[local])
 
     for _ in range(W):
         step()
@@ -144,12 +147,12 @@ def main():
     kern_ms = ev0.elapsed_time(ev1) / K
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     T = float(tmax.item())
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -233,7 +236,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(prob, D, tau, X)
         out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
