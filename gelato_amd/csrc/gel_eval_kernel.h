@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   double fc[3];
   {
     const double tn = tau * (tf - to) / 2 + (tf + to) / 2;  // PSparams.time_nodes, SectionParameters.py:77-81
-    const double inv_m = 1.0 / (me * P.um);
+    const double inv_m = frcp(me * P.um);
 
     if (ph.air) {
       const EarthAngle ea = earth_angle(tn);  // position sweeps do not change it
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
           }
         }
         // mass sweep: only the division by mass changes
-        accel(Tdc, Fc, 1.0 / ((me + dx) * P.um), pp.g, inv_uv, f);
+        accel(Tdc, Fc, frcp((me + dx) * P.um), pp.g, inv_uv, f);
 #pragma unroll
         for (int c = 0; c < 3; c++) EMIT(9 + c, FDQ(f[c], fc[c]));
         // t0 / tf sweeps (con_dynamics.py:452-480): only the Earth angle changes
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
       accel_noair(Td, inv_m, gc, inv_uv, fc);
       if (JAC) {
         double f[3];
-        accel_noair(Td, 1.0 / ((me + dx) * P.um), gc, inv_uv, f);
+        accel_noair(Td, frcp((me + dx) * P.um), gc, inv_uv, f);
 #pragma unroll
         for (int c = 0; c < 3; c++) EMIT(9 + c, FDQ(f[c], fc[c]));
 #pragma unroll 1

@@ -223,6 +223,10 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       out[3 * i] = wn; out[3 * i + 1] = we; out[3 * i + 2] = 0.0;
     } break;
     case 6: out[i] = interp_tab(in[i], lds, aux_rows, 2, 1); break;
+    case 7: {  // the path's guard-free sqrt / division beside the compiler's, for the bit-identity test
+      const double a = in[2 * i], b = in[2 * i + 1];
+      out[4 * i] = fsqrt(a); out[4 * i + 1] = sqrt(a); out[4 * i + 2] = fdiv(a, b); out[4 * i + 3] = a / b;
+    } break;
     default: break;
   }
 }

@@ -39,11 +39,52 @@ struct Tables {
 constexpr int kAtmDoubles = 66;
 
 // ---------------------------------------------------------------------------
+// fp64 square root and division without the range guards.
+//
+// hipcc expands sqrt(double) into v_rsq_f64 + a 9-operation Goldschmidt refinement wrapped in a
+// 2^+-256 rescale (inputs below 2^-767) and a class test (0, inf, nan): 8 of its 19 instructions; and
+// a/b into v_rcp_f64 + 7 fused operations wrapped in v_div_scale x2 / v_div_fmas / v_div_fixup, which
+// only act when an exponent is within ~2^100 of the format's ends.  Everything on this path is a
+// physical quantity in SI units or a scaled O(1) variable -- nowhere near either end -- so the
+// refinement alone is used: the SAME operations in the SAME order, hence the same bits as the
+// compiler's sequence for every finite positive normal operand (checked in tests/test_gpu_parity.py).
+// fsqrt(0) is NaN; the one call site that can legitimately see 0 (air-relative speed) clamps first.
+// -DGEL_STD_MATH restores the compiler's sequences (A/B and a fallback for doubts).
+// ---------------------------------------------------------------------------
+#ifndef GEL_STD_MATH
+GEL_DEV double fsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+GEL_DEV double fdiv(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = a * r;
+  const double t = __builtin_fma(-b, q, a);
+  return __builtin_fma(t, r, q);
+}
+#else
+GEL_DEV double fsqrt(double x) { return sqrt(x); }
+GEL_DEV double fdiv(double a, double b) { return a / b; }
+#endif
+GEL_DEV double frcp(double b) { return fdiv(1.0, b); }
+
+// ---------------------------------------------------------------------------
 // US Standard Atmosphere 1976.  One layer search serves T, P, rho and a; the
 // reference repeats it five times per node (src/Air.cpp:100-111).
 // ---------------------------------------------------------------------------
 GEL_DEV double geopotential_altitude(double z) {  // src/Air.cpp:47-54
-  return (z < 86000.0) ? 1.0 * (6356766.0 * z) / (6356766.0 + z) : z;
+  return (z < 86000.0) ? fdiv(1.0 * (6356766.0 * z), 6356766.0 + z) : z;
 }
 
 GEL_DEV int us76_layer(double h) {  // src/Air.cpp:56-61
@@ -98,13 +139,13 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
 #ifdef GEL_AB_POW  // A/B switch for tools/variant.sh only
     o.P = Pb * pow((Tmb + Lmb * (h - Hb)) / Tmb, atm[44 + k]);
 #else
-    o.P = Pb * exp(atm[44 + k] * log((Tmb + Lmb * (h - Hb)) / Tmb));
+    o.P = Pb * exp(atm[44 + k] * log(fdiv(Tmb + Lmb * (h - Hb), Tmb)));
 #endif
   } else {
-    o.P = Pb * exp(atm[55 + k] * (Hb - h) / Tmb);                 // g0/R from the table
+    o.P = Pb * exp(fdiv(atm[55 + k] * (Hb - h), Tmb));                // g0/R from the table
   }
-  o.rho = o.P / (R * o.T);      // src/Air.cpp:100-105 (P/R/T)
-  o.a = sqrt(1.4 * R * o.T);    // src/Air.cpp:107-111
+  o.rho = fdiv(o.P, R * o.T);     // src/Air.cpp:100-105 (P/R/T)
+  o.a = fsqrt(1.4 * R * o.T);   // src/Air.cpp:107-111
   return o;
 }
 
@@ -114,10 +155,10 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
 // theta = atan2(z Ra, p Rb) is only used through sin(theta), cos(theta): they are formed algebraically
 // (a/h, b/h with h = hypot(a, b)), identical up to rounding to sincos(atan2(a, b)).
 GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p) {
-  p = sqrt(x * x + y * y);
+  p = fsqrt(x * x + y * y);
   const double a = z * kRa, b = p * kRb;
-  const double h = sqrt(a * a + b * b);
-  const double ih = 1.0 / h;
+  const double h = fsqrt(a * a + b * b);
+  const double ih = frcp(h);
   const double st = (h > 0.0) ? a * ih : 0.0;
   const double ct = (h > 0.0) ? b * ih : 1.0;
   lat = atan2(z + kEp2 * kRb * (st * st * st), p - kE2 * kRa * (ct * ct * ct));
@@ -125,8 +166,8 @@ GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p
 
 // altitude from (p, sin lat, cos lat): src/Earth.cpp:58-59
 GEL_DEV double geodetic_alt_from(double p, double sl, double cl) {
-  const double N = kRa / sqrt(1.0 - kE2 * sl * sl);
-  return p / cl - N;
+  const double N = fdiv(kRa, fsqrt(1.0 - kE2 * sl * sl));
+  return fdiv(p, cl) - N;
 }
 
 GEL_DEV double geodetic_altitude(double x, double y, double z) {
@@ -143,8 +184,8 @@ GEL_DEV void geodetic_full(double x, double y, double z, double& lat, double& lo
   lon = atan2(y, x);
   double sl, cl;
   sincos(lat, &sl, &cl);
-  const double N = kRa / sqrt(1.0 - kE2 * sl * sl);
-  alt = p / cl - N;
+  const double N = fdiv(kRa, fsqrt(1.0 - kE2 * sl * sl));
+  alt = fdiv(p, cl) - N;
 }
 
 // ---------------------------------------------------------------------------
@@ -154,9 +195,9 @@ GEL_DEV void gravity_eci(const double r3[3], double barC20, double g[3]) {
   const double a = 6378137.0, mu = kMu;
   const double b = a * (1.0 - 1.0 / 298.257223563);
   const double x = r3[0], y = r3[1], z = r3[2];
-  double r = sqrt(x * x + y * y + z * z);
+  double r = fsqrt(x * x + y * y + z * z);
   double irx = 0.0, iry = 0.0, irz = 0.0;
-  double inv_r = 1.0 / r;  // one reciprocal serves x/r, y/r, z/r, a/r, mu/r^2 (each <= 1 ulp from the division)
+  double inv_r = frcp(r);  // one reciprocal serves x/r, y/r, z/r, a/r, mu/r^2 (each <= 1 ulp from the division)
   if (r != 0.0) { irx = x * inv_r; iry = y * inv_r; irz = z * inv_r; }
   const double s5 = 2.23606797749978969641;  // sqrt(5.0)
   const double barP20 = s5 * (3.0 * irz * irz - 1.0) * 0.5;

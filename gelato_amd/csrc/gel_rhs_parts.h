@@ -57,11 +57,11 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
   geodetic_lat_p(r[0], r[1], r[2], lat, p);
   sincos(lat, &sl, &cl);
 #endif
-  o.inv_p = 1.0 / p;
+  o.inv_p = frcp(p);
   // half-angle pair of the NED quaternion (src/Coordinate.cpp:89-90): cos(lat/2) = sqrt((1+cos lat)/2)
   // (cos lat >= 0), sin(lat/2) = sin lat / (2 cos(lat/2))
-  o.chp = sqrt(0.5 * (1.0 + cl));
-  o.shp = 0.5 * sl / o.chp;
+  o.chp = fsqrt(0.5 * (1.0 + cl));
+  o.shp = fdiv(0.5 * sl, o.chp);
   const double alt = geodetic_alt_from(p, sl, cl);
   const double h = geopotential_altitude(alt);
   const Air air = atmosphere(h, tb.atm);
@@ -98,8 +98,8 @@ GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double s_hp, doubl
   const double px = r[0] * e.c + r[1] * e.s;
   const double py = -r[0] * e.s + r[1] * e.c;
   const double clon = px * inv_p, slon = py * inv_p;
-  const double th = sqrt(0.5 * (1.0 + fabs(clon)));  // |cos| or |sin| of lon/2, whichever is >= 0.707
-  const double uh = 0.5 * slon / th;
+  const double th = fsqrt(0.5 * (1.0 + fabs(clon)));  // |cos| or |sin| of lon/2, whichever is >= 0.707
+  const double uh = fdiv(0.5 * slon, th);
   const double c_hl = (clon >= 0.0) ? th : fabs(uh);
   const double s_hl = (clon >= 0.0) ? uh : copysign(th, slon);
   // quat_ecef2ned: src/Coordinate.cpp:85-98
@@ -132,8 +132,10 @@ GEL_DEV void aero_force(const double r[3], const double v[3], double rho, double
   const double a0 = (e0 * e.c - e1 * e.s) - w[0];
   const double a1 = (e0 * e.s + e1 * e.c) - w[1];
   const double a2 = v[2] - w[2];
-  const double vn = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-  const double mach = vn / a_sound;
+  // a vehicle at rest in the air (vn = 0) is a legitimate input: clamp below anything physical so that
+  // fsqrt stays defined; the force is k * (-a) = 0 either way
+  const double vn = fsqrt(fmax(a0 * a0 + a1 * a1 + a2 * a2, 1.0e-200));
+  const double mach = fdiv(vn, a_sound);
   const double ca = interp_tab(mach, tb.ca, tb.Kc, 2, 1);
   const double k = 0.5 * rho * area * ca * vn;
   F[0] = k * -a0; F[1] = k * -a1; F[2] = k * -a2;

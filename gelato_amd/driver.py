@@ -9,7 +9,7 @@ timers the reference prints (:511-517).
 """
 import time
 
-from . import con_dynamics
+from . import con_aero, con_dynamics
 from .cost_gradient import cost_6DoF, cost_jac
 
 # wrt map of the four groups (Trajectory_Optimization.py:361-364)
@@ -22,13 +22,22 @@ WRT = {
 
 
 def make_callbacks(pdict, unitdict, condition):
+    # the aero path constraints take part when the condition dict carries any of their tables
+    aero = any(k in condition for k in ("AOA_max", "dynamic_pressure_max", "Q_alpha_max"))
+
     def objfunc(xdict):
         funcs = {"obj": cost_6DoF(xdict, condition)}
         funcs["eqcon_dyn_mass"] = con_dynamics.equality_dynamics_mass(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_pos"] = con_dynamics.equality_dynamics_position(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_vel"] = con_dynamics.equality_dynamics_velocity(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_quat"] = con_dynamics.equality_dynamics_quaternion(xdict, pdict, unitdict, condition)
-        return funcs, bool(con_dynamics.last_status(pdict))
+        fail = con_dynamics.last_status(pdict)
+        if aero:  # Trajectory_Optimization.py:214-221 (None when a kind has no entry, like the reference)
+            funcs["ineqcon_alpha"] = con_aero.inequality_max_alpha(xdict, pdict, unitdict, condition)
+            funcs["ineqcon_q"] = con_aero.inequality_max_q(xdict, pdict, unitdict, condition)
+            funcs["ineqcon_qalpha"] = con_aero.inequality_max_qalpha(xdict, pdict, unitdict, condition)
+            fail |= con_dynamics.last_status(pdict)
+        return funcs, bool(fail)
 
     def sens(xdict, funcs):
         fs = {"obj": cost_jac(xdict, condition)}
@@ -36,7 +45,13 @@ def make_callbacks(pdict, unitdict, condition):
         fs["eqcon_dyn_pos"] = con_dynamics.equality_jac_dynamics_position(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_vel"] = con_dynamics.equality_jac_dynamics_velocity(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_quat"] = con_dynamics.equality_jac_dynamics_quaternion(xdict, pdict, unitdict, condition)
-        return fs, bool(con_dynamics.last_status(pdict))
+        fail = con_dynamics.last_status(pdict)
+        if aero:  # Trajectory_Optimization.py:286-295
+            fs["ineqcon_alpha"] = con_aero.inequality_jac_max_alpha(xdict, pdict, unitdict, condition)
+            fs["ineqcon_q"] = con_aero.inequality_jac_max_q(xdict, pdict, unitdict, condition)
+            fs["ineqcon_qalpha"] = con_aero.inequality_jac_max_qalpha(xdict, pdict, unitdict, condition)
+            fail |= con_dynamics.last_status(pdict)
+        return fs, bool(fail)
 
     return objfunc, sens
 

@@ -98,3 +98,14 @@ def test_con_aero_shim_like_reference():
             assert np.array_equal(r, g[key + "_rows"]) and np.array_equal(c, g[key + "_cols"])
             assert jac[var]["shape"] == tuple(g[key + "_shape"])
             assert np.all(np.abs(v - g[key + "_vals"]) <= ATOL[kind] + 1e-6 * np.abs(g[key + "_vals"]))
+    # the mock driver hands the same groups to the optimiser, None where a kind has no entry
+    from gelato_amd import driver
+    full = dict(condition, **cond)
+    objfunc, sens = driver.make_callbacks(pdict, unitdict, full)
+    funcs, fail = objfunc(xd)
+    fs, fail2 = sens(xd, funcs)
+    assert fail is False and fail2 is False
+    assert funcs["ineqcon_q"] is None and fs["ineqcon_q"] is None
+    assert np.array_equal(funcs["ineqcon_alpha"], con_aero.inequality_max_alpha(xd, pdict, unitdict, full))
+    assert funcs["ineqcon_qalpha"].shape == (17,) and list(fs["ineqcon_qalpha"]) == VARS
+    assert "eqcon_dyn_vel" in funcs and "eqcon_dyn_vel" in fs

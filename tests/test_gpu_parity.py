@@ -572,3 +572,24 @@ def test_benchmark_batch_against_oracle_in_full():
         worst_r, worst_j = max(worst_r, dr.max()), max(worst_j, dj.max())
     assert worst_r <= 0.0, worst_r
     assert worst_j <= 1e-5, worst_j
+
+
+# --------------------------------------------------------------------------
+# the path's guard-free fp64 sqrt / division (csrc/gel_physics.h) give the compiler's bits
+# --------------------------------------------------------------------------
+def test_guard_free_sqrt_and_division_bit_identical():
+    _setup()
+    from gelato_amd import dynamics
+    rng = np.random.default_rng(77)
+    n = 1 << 18
+    a = 10.0 ** rng.uniform(-60, 60, n) * rng.uniform(1, 10, n)
+    b = 10.0 ** rng.uniform(-60, 60, n) * rng.uniform(1, 10, n) * rng.choice([-1.0, 1.0], n)
+    # the magnitudes the path actually feeds them: radii, speeds, O(1) ratios, table abscissae
+    a[:4096] = rng.uniform(0.5, 2.0, 4096)
+    a[4096:8192] = rng.uniform(6.3e6, 8.0e6, 4096) ** 2
+    b[:4096] = rng.uniform(0.5, 2.0, 4096)
+    out = dynamics.point_eval(7, np.stack([a, b], axis=1))
+    assert np.array_equal(out[:, 0], out[:, 1])            # fsqrt == sqrt, every bit
+    assert np.array_equal(out[:, 2], out[:, 3])            # fdiv  == a / b, every bit
+    # and both are the correctly rounded results numpy computes on the host
+    assert np.array_equal(out[:, 1], np.sqrt(a)) and np.array_equal(out[:, 3], a / b)
