@@ -34,7 +34,8 @@ struct ProblemDev {
   int32_t use_mfma;          // D.X on v_mfma_f64_16x16x4_f64 instead of VALU FMAs
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)
-  const int2* chunks;        // [nchunks] {phase, first node of the chunk}
+  const int2* chunks;        // [nchunks] {phase, first node of the chunk}: dearest phase type first for a whole
+                             // launch, the natural (phase) order for a phase-sharded one
   int64_t V;                 // compact entries per eval
   const PhaseDev* phases;    // [S]
   const int32_t* node_phase; // [N]

@@ -56,8 +56,13 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 
   const long long item = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
   if (item >= (long long)B * P.nchunks) return;
-  const int b = (int)(item / P.nchunks);
-  const int2 ck = P.chunks[P.chunk0 + (int)(item - (long long)b * P.nchunks)];
+  // work-item major: all B vectors of one (phase, chunk) are neighbours, so the four wavefronts of a
+  // workgroup cost the same (its LDS is only released when the slowest ends), and the list is ordered
+  // dearest phase type first, so the tail of the launch drains with cheap wavefronts (measured -4 % on
+  // the mixed vehicle at B = 4096, -6..9 % at B = 2048)
+  const int ci = (int)(item / B);
+  const int b = (int)(item - (long long)ci * B);
+  const int2 ck = P.chunks[P.chunk0 + ci];
   const int sec = __builtin_amdgcn_readfirstlane(ck.x);
   const int j0 = __builtin_amdgcn_readfirstlane(ck.y);
   const int j = j0 + lane;  // node inside the phase

@@ -139,7 +139,8 @@ struct gel_problem {
   // device buffers (static)
   gel::PhaseDev* d_phases = nullptr;
   int32_t* d_node_phase = nullptr;
-  int2* d_chunks = nullptr;
+  int2* d_chunks = nullptr;         // work items in phase order (what gel_chunk_phase / shard ranges index)
+  int2* d_chunks_sorted = nullptr;  // the same items, dearest phase type first (whole launches)
   double* d_Dt = nullptr;
   double* d_tau = nullptr;
   double* d_tables = nullptr;
@@ -461,8 +462,14 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   for (int i = 0; i < S; i++)
     for (int j0 = 0; j0 < p->ph[i].n; j0 += 64) chunks.push_back(make_int2(i, j0));
 
+  // launch order of a whole evaluation: aerodynamic phases (the long chain, 4x + sweeps) before NoAir
+  // ones, free attitude before held -- the same weights gelato_amd/parallel.py balances shards with
+  std::vector<int2> sorted_chunks = chunks;
+  auto weight = [&](const int2& c) { return (p->ph[c.x].air ? 10.0 : 1.5) + (p->ph[c.x].hold ? 0.0 : 0.5); };
+  std::stable_sort(sorted_chunks.begin(), sorted_chunks.end(), [&](const int2& a, const int2& b) { return weight(a) > weight(b); });
+
   int rc = GEL_OK;
-  if ((rc = upload(&p->d_chunks, chunks)) || (rc = upload(&p->d_phases, dph)) || (rc = upload(&p->d_node_phase, node_phase)) || (rc = upload(&p->d_Dt, Dt)) ||
+  if ((rc = upload(&p->d_chunks, chunks)) || (rc = upload(&p->d_chunks_sorted, sorted_chunks)) || (rc = upload(&p->d_phases, dph)) || (rc = upload(&p->d_node_phase, node_phase)) || (rc = upload(&p->d_Dt, Dt)) ||
       (rc = upload(&p->d_tau, tau)) || (rc = upload(&p->d_tables, tables)) || (rc = upload(&p->d_cval, p->cval)) ||
       (rc = upload(&p->d_src, p->src))) {
     gel_problem_destroy(p);
@@ -478,7 +485,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   dv.S = S; dv.N = N; dv.M = M; dv.nvars = dm.num_vars; dv.Kw = d->wind_rows; dv.Kc = d->ca_rows; dv.V = V;
   dv.phases = p->d_phases; dv.node_phase = p->d_node_phase; dv.Dt = p->d_Dt; dv.tau = p->d_tau; dv.tables = p->d_tables;
   dv.flag = p->d_flag;
-  dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks;
+  dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks_sorted;
   dv.park_off = (int32_t)((tables.size() + 1) / 2 * 2);
   {
     // D.X path: the matrix pipe runs beside the fp64 VALU pipe that bounds this kernel, so the MFMA form
@@ -498,7 +505,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->device == GEL_DEVICE_NONE) { delete p; return GEL_OK; }
   hipSetDevice(p->device);
   if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
-  hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
+  hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag);
   for (int k = 0; k < 3; k++) hipFree(p->d_aero_rows[k]);
   hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv);
@@ -593,6 +600,7 @@ int gel_eval_shard_device(gel_problem* p, int32_t B, const double* d_x, double* 
     return fail(GEL_ERR_ARG, "work-item range out of bounds");
   if (chunk_count == 0) return GEL_OK;
   gel::ProblemDev dv = p->dev;
+  dv.chunks = p->d_chunks;  // shard ranges index the phase-ordered list
   dv.chunk0 = chunk_begin;
   dv.nchunks = chunk_count;
   HIPCHK(gel::launch_eval(dv, B, d_x, d_res, d_jvar, stream ? (hipStream_t)stream : p->stream));
