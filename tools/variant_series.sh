@@ -1,0 +1,7 @@
+#!/bin/bash
+# like variant.sh but prints the per-launch duration series from idle (boost -> sustained clock)
+cd $GRAFT_REPO_ROOT/gelato_amd/csrc
+tag=$(echo "$1" | tr -cd 'A-Za-z0-9_=' )
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=on -mllvm -disable-machine-licm $1 -shared -o /tmp/libgel_$tag.so gel_kernels.hip gel_host.hip 2>/dev/null || { echo "build failed: $1"; exit 1; }
+echo "== variant [$1]"
+GELATO_AMD_LIB=/tmp/libgel_$tag.so python3 $GRAFT_REPO_ROOT/tools/launch_series.py ${2:-mixed-6x64} 2>/dev/null
