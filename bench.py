@@ -225,9 +225,9 @@ def main():
         # informational: the batched host-buffer entry point (pageable caller buffers -> pinned staging -> H2D,
         # launch, D2H of residuals + compact Jacobian values): PCIe inclusive, never `value`
         Bh = min(B, 512)
-        E.eval_batch(X[:Bh])
+        r_h, j_h, _ = E.eval_batch(X[:Bh])
         t0 = time.perf_counter()
-        E.eval_batch(X[:Bh])
+        E.eval_batch(X[:Bh], out=(r_h, j_h))
         dt = time.perf_counter() - t0
         out["host_batch_pcie_inclusive"] = {"batch": Bh, "evals_per_s": Bh / dt, "ms": 1e3 * dt,
                                             "bytes_moved": Bh * E.algorithmic_bytes}

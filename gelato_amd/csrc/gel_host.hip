@@ -8,6 +8,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gelato_amd.h"
@@ -154,6 +155,19 @@ struct gel_problem {
   double *d_x = nullptr, *d_res = nullptr, *d_jv = nullptr;
   double *h_x = nullptr, *h_res = nullptr, *h_jv = nullptr;  // pinned
   int32_t* h_flag = nullptr;                                  // pinned
+  // large host batches (gel_eval_batch): two staging slots of kPipeEvals decision vectors each, every
+  // slot with its own stream, so that PCIe in, kernel, PCIe out and the host copies of neighbouring
+  // sub-batches overlap
+  struct Slot {
+    double *d_x = nullptr, *d_res = nullptr, *d_jv = nullptr;
+    double *h_x = nullptr, *h_res = nullptr, *h_jv = nullptr;  // pinned
+    int32_t *d_flag = nullptr, *h_flag = nullptr;
+    hipStream_t stream = nullptr;
+    int64_t first = 0;  // sub-batch in flight: [first, first + count)
+    int count = 0;
+    bool res = false, jac = false;
+  } slot[2];
+  int pipe_evals = 0;  // capacity of a slot (0 = not allocated)
 };
 
 namespace {
@@ -314,6 +328,112 @@ int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_ja
     return GEL_NONFINITE;
   }
   return GEL_OK;
+}
+
+// ---- pipelined host batch ----
+constexpr size_t kPipeBytes = (size_t)16 << 20;  // staging per slot and direction
+
+// memcpy on a few threads: one core moves ~10 GB/s, PCIe delivers 2-5x that
+void par_copy(void* dst, const void* src, size_t bytes) {
+  const size_t kMin = (size_t)2 << 20;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t nt = std::min<size_t>(std::min<size_t>(4, hw), bytes / kMin);
+  if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+  std::vector<std::thread> th;
+  const size_t per = ((bytes / nt) + 63) & ~(size_t)63;
+  for (size_t t = 1; t < nt; t++) {
+    const size_t off = t * per, len = (t + 1 == nt) ? bytes - off : per;
+    th.emplace_back([=] { std::memcpy((char*)dst + off, (const char*)src + off, len); });
+  }
+  std::memcpy(dst, src, per);
+  for (auto& t : th) t.join();
+}
+
+int ensure_slots(gel_problem* p) {
+  NEED_DEVICE(p);
+  if (p->pipe_evals) return GEL_OK;
+  HIPCHK(hipSetDevice(p->device));
+  const size_t per_eval = 8 * (size_t)std::max<int64_t>(p->dims.num_var_entries, 1);
+  const int cap = (int)std::max<size_t>(1, kPipeBytes / per_eval);
+  const size_t nx = (size_t)cap * p->dims.num_vars, nr = (size_t)cap * 11 * p->dims.N, nj = (size_t)cap * std::max<int64_t>(1, p->dims.num_var_entries);
+  for (auto& sl : p->slot) {
+    HIPCHK(hipMalloc((void**)&sl.d_x, nx * 8));
+    HIPCHK(hipMalloc((void**)&sl.d_res, nr * 8));
+    HIPCHK(hipMalloc((void**)&sl.d_jv, nj * 8));
+    HIPCHK(hipMalloc((void**)&sl.d_flag, 4));
+    HIPCHK(hipMemset(sl.d_flag, 0, 4));
+    HIPCHK(hipHostMalloc((void**)&sl.h_x, nx * 8));
+    HIPCHK(hipHostMalloc((void**)&sl.h_res, nr * 8));
+    HIPCHK(hipHostMalloc((void**)&sl.h_jv, nj * 8));
+    HIPCHK(hipHostMalloc((void**)&sl.h_flag, 4));
+    HIPCHK(hipStreamCreate(&sl.stream));
+    *sl.h_flag = 0;
+    sl.count = 0;
+  }
+  p->pipe_evals = cap;
+  return GEL_OK;
+}
+
+void free_slots(gel_problem* p) {
+  for (auto& sl : p->slot) {
+    if (sl.stream) { hipStreamSynchronize(sl.stream); hipStreamDestroy(sl.stream); }
+    hipFree(sl.d_x); hipFree(sl.d_res); hipFree(sl.d_jv); hipFree(sl.d_flag);
+    if (sl.h_x) hipHostFree(sl.h_x);
+    if (sl.h_res) hipHostFree(sl.h_res);
+    if (sl.h_jv) hipHostFree(sl.h_jv);
+    if (sl.h_flag) hipHostFree(sl.h_flag);
+    sl = gel_problem::Slot{};
+  }
+  p->pipe_evals = 0;
+}
+
+// B evals from / to pageable host arrays in sub-batches: while sub-batch i runs (H2D, kernel, D2H on its
+// slot's stream), the host retires sub-batch i-1 of the other slot (pinned -> caller) and stages i+1.
+int run_host_pipelined(gel_problem* p, int B, const double* x, double* res, double* jvar) {
+  int rc = ensure_slots(p);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(p->device));
+  const int cap = p->pipe_evals;
+  const size_t nv = (size_t)p->dims.num_vars, nr = (size_t)11 * p->dims.N, nj = (size_t)p->dims.num_var_entries;
+  const int nsub = (B + cap - 1) / cap;
+  int status = GEL_OK;
+  auto retire = [&](gel_problem::Slot& sl) -> int {
+    if (!sl.count) return GEL_OK;
+    HIPCHK(hipStreamSynchronize(sl.stream));
+    if (*sl.h_flag) {
+      *sl.h_flag = 0;
+      HIPCHK(hipMemsetAsync(sl.d_flag, 0, 4, sl.stream));
+      status = GEL_NONFINITE;
+    }
+    if (sl.res) par_copy(res + (size_t)sl.first * nr, sl.h_res, (size_t)sl.count * nr * 8);
+    if (sl.jac && nj) par_copy(jvar + (size_t)sl.first * nj, sl.h_jv, (size_t)sl.count * nj * 8);
+    sl.count = 0;
+    return GEL_OK;
+  };
+  for (int i = 0; i < nsub; i++) {
+    gel_problem::Slot& sl = p->slot[i & 1];
+    if ((rc = retire(sl))) break;
+    const int64_t first = (int64_t)i * cap;
+    const int count = (int)std::min<int64_t>(cap, B - first);
+    par_copy(sl.h_x, x + (size_t)first * nv, (size_t)count * nv * 8);
+    sl.first = first; sl.count = count; sl.res = res != nullptr; sl.jac = jvar != nullptr;
+    gel::ProblemDev dv = p->dev;
+    dv.flag = sl.d_flag;
+    if (hipMemcpyAsync(sl.d_x, sl.h_x, (size_t)count * nv * 8, hipMemcpyHostToDevice, sl.stream) != hipSuccess ||
+        gel::launch_eval(dv, count, sl.d_x, res ? sl.d_res : nullptr, jvar ? sl.d_jv : nullptr, sl.stream) != hipSuccess ||
+        (res && hipMemcpyAsync(sl.h_res, sl.d_res, (size_t)count * nr * 8, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) ||
+        (jvar && nj && hipMemcpyAsync(sl.h_jv, sl.d_jv, (size_t)count * nj * 8, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) ||
+        hipMemcpyAsync(sl.h_flag, sl.d_flag, 4, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) {
+      rc = fail(GEL_ERR_HIP, "pipelined batch: enqueue failed");
+      break;
+    }
+  }
+  // drain both slots (also after an error, so that nothing is left in flight)
+  for (int k = 0; k < 2; k++) {
+    const int r2 = retire(p->slot[(nsub + k) & 1]);
+    if (!rc) rc = r2;
+  }
+  return rc ? rc : status;
 }
 
 void scatter_full(const gel_problem* p, const double* jv, double* vals_full, int fill) {
@@ -535,6 +655,7 @@ int gel_problem_destroy(gel_problem* p) {
   hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag);
   for (int k = 0; k < 3; k++) hipFree(p->d_aero_rows[k]);
+  free_slots(p);
   hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv);
   if (p->h_x) hipHostFree(p->h_x);
   if (p->h_res) hipHostFree(p->h_res);
@@ -605,6 +726,9 @@ int gel_eval(gel_problem* p, const double* x, double* res, double* vals_full, in
 
 int gel_eval_batch(gel_problem* p, int32_t B, const double* x, double* res, double* jvar) {
   if (!p || !x || B < 1 || (!res && !jvar)) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  // more than one staging slot's worth: sub-batches through the two-slot pipeline
+  if ((size_t)B * 8 * (size_t)std::max<int64_t>(p->dims.num_var_entries, 1) > kPipeBytes) return run_host_pipelined(p, B, x, res, jvar);
   const int rc = run_host(p, B, x, res != nullptr, jvar != nullptr);
   if (rc < 0) return rc;
   if (res) std::memcpy(res, p->h_res, (size_t)B * 11 * p->dims.N * 8);

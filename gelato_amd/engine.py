@@ -182,12 +182,19 @@ class Engine:
         rc = check(lib().gel_eval(self._h, _d(x), _d(res), _d(out), fill))
         return res, out, rc
 
-    def eval_batch(self, X, want_res=True, want_jac=True):
-        """X [B, nvars] -> (res [B, 11N] | None, jvar [B, V] | None, status)"""
+    def eval_batch(self, X, want_res=True, want_jac=True, out=None):
+        """X [B, nvars] -> (res [B, 11N] | None, jvar [B, V] | None, status).  `out` = (res, jvar) arrays of a
+        previous call to write into (saves the page faults of fresh 100-MB arrays on large batches)."""
         X = _f64(X).reshape(-1, self.nvars)
         B = X.shape[0]
-        res = np.empty((B, self.nres)) if want_res else None
-        jv = np.empty((B, self.V)) if want_jac else None
+        if out is not None:
+            res, jv = out
+            for a, shp, want in ((res, (B, self.nres), want_res), (jv, (B, self.V), want_jac)):
+                if want and (a is None or a.shape != shp or a.dtype != np.float64 or not a.flags.c_contiguous):
+                    raise ValueError("out arrays must be C-contiguous float64 of shape %r" % (shp,))
+        else:
+            res = np.empty((B, self.nres)) if want_res else None
+            jv = np.empty((B, self.V)) if want_jac else None
         rc = check(lib().gel_eval_batch(self._h, B, _d(X), _d(res) if want_res else None,
                                         _d(jv) if want_jac else None))
         return res, jv, rc

@@ -593,3 +593,49 @@ def test_guard_free_sqrt_and_division_bit_identical():
     assert np.array_equal(out[:, 2], out[:, 3])            # fdiv  == a / b, every bit
     # and both are the correctly rounded results numpy computes on the host
     assert np.array_equal(out[:, 1], np.sqrt(a)) and np.array_equal(out[:, 3], a / b)
+
+
+# --------------------------------------------------------------------------
+# host batches larger than one staging slot go through the two-slot pipeline: same bits as the
+# device-resident launch, ragged last sub-batch, out= reuse, non-finite status carried out
+# --------------------------------------------------------------------------
+def test_pipelined_host_batch_equals_resident_launch():
+    import torch
+    from gelato_amd import problem
+    prob, x0, _ = named_problem("mixed-6x64")
+    E, P = make_pair(prob)
+    B = 333                                         # 16 MiB / (8 V) = 80 per slot -> 5 sub-batches, last one ragged
+    assert B * 8 * E.V > (16 << 20)
+    X = np.tile(problem.synthetic_batch(x0, E.M, 37), (B // 37 + 1, 1))[:B]
+    X *= (1.0 + 1e-9 * np.arange(B))[:, None]
+    dev = torch.device("cuda:0")
+    dX = torch.from_numpy(X).to(dev)
+    dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    djv = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    res, jv, rc = E.eval_batch(X)
+    assert rc == 0
+    assert np.array_equal(res, dres.cpu().numpy()) and np.array_equal(jv, djv.cpu().numpy())
+    # a few rows against the oracle, across sub-batch borders
+    rows = [0, 79, 80, 81, 159, 160, 332]
+    ores, ovals = P.eval_batch(X[rows])
+    close(res[rows], ores, what="pipelined residual")
+    full = E.expand(jv[rows])
+    vm = np.zeros(E.total_nnz, bool); vm[E.var_index()] = True
+    assert np.all(np.abs(full - ovals)[:, vm] <= 1e-5 + 1e-6 * np.abs(ovals)[:, vm])
+    # out= reuse, residual only and Jacobian only
+    res2, jv2, _ = E.eval_batch(X, out=(res, jv))
+    assert res2 is res and jv2 is jv
+    r3, none, _ = E.eval_batch(X, want_jac=False)
+    assert none is None and np.array_equal(r3, res)
+    none, j4, _ = E.eval_batch(X, want_res=False)
+    assert none is None and np.array_equal(j4, jv)
+    with pytest.raises(ValueError):
+        E.eval_batch(X, out=(res[:10], jv))
+    # a NaN in the third sub-batch: status 1, the other vectors unaffected, next call clean
+    Xb = X.copy()
+    Xb[200, 5] = np.nan
+    rb, jb, rc = E.eval_batch(Xb)
+    assert rc == 1 and np.array_equal(rb[:200], res[:200]) and np.array_equal(jb[201:], jv[201:])
+    assert E.eval_batch(X)[2] == 0
