@@ -232,6 +232,32 @@ def main():
         out["host_batch_pcie_inclusive"] = {"batch": Bh, "evals_per_s": Bh / dt, "ms": 1e3 * dt,
                                             "bytes_moved": Bh * E.algorithmic_bytes}
 
+        # informational: the aero path constraints on every phase but the last, "all" nodes:
+        # value + forward-difference gradient of the three kinds, host buffers in and out
+        try:
+            S_ = len(prob["num_nodes"])
+            rows = 0
+            for kind, lim in (("alpha", 0.2), ("q", 4.0e4), ("qalpha", 5.0e3)):
+                E.aero_configure(kind, [(i, 1, lim) for i in range(S_ - 1)])
+                rows += E.aero_dims(kind)[0]
+            def aero_all(Xa):
+                for kind in ("alpha", "q", "qalpha"):
+                    E.eval_aero(kind, Xa)
+            aero_all(x0)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                aero_all(x0)
+            b1 = (time.perf_counter() - t0) / 20
+            Ba = min(B, 1024)
+            aero_all(X[:Ba])
+            t0 = time.perf_counter()
+            aero_all(X[:Ba])
+            dtb = time.perf_counter() - t0
+            out["aero_constraints"] = {"rows": rows, "b1_ms_3_kinds": 1e3 * b1, "batch": Ba,
+                                       "batch_evals_per_s": Ba / dtb}
+        except Exception as ex:  # noqa: BLE001
+            out["aero_constraints"] = {"error": str(ex)}
+
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(prob, D, tau, X)
         out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

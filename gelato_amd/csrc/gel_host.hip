@@ -155,6 +155,8 @@ struct gel_problem {
   double *d_x = nullptr, *d_res = nullptr, *d_jv = nullptr;
   double *h_x = nullptr, *h_res = nullptr, *h_jv = nullptr;  // pinned
   int32_t* h_flag = nullptr;                                  // pinned
+  double* h_aero = nullptr;                                   // pinned outputs of small gel_eval_aero calls
+  size_t h_aero_cap = 0;                                      // doubles
   // large host batches (gel_eval_batch): two staging slots of kPipeEvals decision vectors each, every
   // slot with its own stream, so that PCIe in, kernel, PCIe out and the host copies of neighbouring
   // sub-batches overlap
@@ -286,7 +288,13 @@ int ensure_capacity(gel_problem* p, int B) {
   NEED_DEVICE(p);
   if (B <= p->capB) return GEL_OK;
   HIPCHK(hipSetDevice(p->device));
-  if (p->d_x) { hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv); hipHostFree(p->h_x); hipHostFree(p->h_res); hipHostFree(p->h_jv); }
+  // release first and forget the old capacity: a failed allocation below must not leave freed pointers behind
+  hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv);
+  if (p->h_x) hipHostFree(p->h_x);
+  if (p->h_res) hipHostFree(p->h_res);
+  if (p->h_jv) hipHostFree(p->h_jv);
+  p->d_x = p->d_res = p->d_jv = p->h_x = p->h_res = p->h_jv = nullptr;
+  p->capB = 0;
   const size_t nx = (size_t)B * p->dims.num_vars, nr = (size_t)B * 11 * p->dims.N, nj = (size_t)B * std::max<int64_t>(1, p->dims.num_var_entries);
   HIPCHK(hipMalloc((void**)&p->d_x, nx * 8));
   HIPCHK(hipMalloc((void**)&p->d_res, nr * 8));
@@ -661,6 +669,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->h_res) hipHostFree(p->h_res);
   if (p->h_jv) hipHostFree(p->h_jv);
   if (p->h_flag) hipHostFree(p->h_flag);
+  if (p->h_aero) hipHostFree(p->h_aero);
   delete p;
   return GEL_OK;
 }
@@ -959,6 +968,26 @@ int gel_eval_aero(gel_problem* p, int32_t kind, int32_t B, const double* x, doub
   if (R == 0) return GEL_OK;
   HIPCHK(hipSetDevice(p->device));
   const size_t nx = (size_t)B * p->dims.num_vars, nc = (size_t)B * R, nj = (size_t)B * R * ((kind == 1) ? 8 : 12);
+  if ((nx + nc + (jac_vals ? nj : 0)) * 8 <= kZeroCopyBytes) {
+    // small call (the optimiser's callback): zero-copy through pinned host memory like run_host
+    int rc = ensure_capacity(p, B);
+    if (rc) return rc;
+    if (p->h_aero_cap < nc + nj) {
+      if (p->h_aero) hipHostFree(p->h_aero);
+      p->h_aero = nullptr; p->h_aero_cap = 0;
+      HIPCHK(hipHostMalloc((void**)&p->h_aero, (nc + nj) * 8));
+      p->h_aero_cap = nc + nj;
+    }
+    std::memcpy(p->h_x, x, nx * 8);
+    gel::ProblemDev dv = p->dev;
+    dv.flag = p->h_flag;
+    HIPCHK(gel::launch_aero(dv, kind, R, p->d_aero_rows[kind], B, p->h_x, p->h_aero, jac_vals ? p->h_aero + nc : nullptr, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    std::memcpy(con, p->h_aero, nc * 8);
+    if (jac_vals) std::memcpy(jac_vals, p->h_aero + nc, nj * 8);
+    if (*p->h_flag) { *p->h_flag = 0; return GEL_NONFINITE; }
+    return GEL_OK;
+  }
   double *d_x = nullptr, *d_c = nullptr, *d_j = nullptr;
   auto cleanup = [&]() { hipFree(d_x); hipFree(d_c); hipFree(d_j); };
 #define HIPCHK3(expr)                                                                                          \
