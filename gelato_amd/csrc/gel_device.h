@@ -21,6 +21,28 @@ struct PhaseDev {
   double thrust, massflow, area, nozzle;
 };
 
+#ifdef __HIPCC__
+// A phase record fetched through the constant address space: the loads are scalar (s_load) and -- unlike
+// loads through a plain global pointer -- known not to alias the kernel's own stores.  Without this the
+// compiler re-loaded single fields with VECTOR loads in the middle of the sweeps, and the s_waitcnt
+// vmcnt(0) behind each of them also waited for every Jacobian store in flight (vmcnt counts in order).
+template <class T>
+__device__ __forceinline__ T load_const(const T* p) {
+  return *(const T __attribute__((address_space(4)))*)p;
+}
+__device__ __forceinline__ PhaseDev load_phase(const PhaseDev* g) {
+  PhaseDev q;
+  q.n = load_const(&g->n); q.ua = load_const(&g->ua); q.xa = load_const(&g->xa);
+  q.air = load_const(&g->air); q.air_fd = load_const(&g->air_fd); q.engine_on = load_const(&g->engine_on);
+  q.hold = load_const(&g->hold); q.K = load_const(&g->K);
+  q.s_vv = load_const(&g->s_vv); q.s_vq = load_const(&g->s_vq); q.s_vt = load_const(&g->s_vt); q.s_qq = load_const(&g->s_qq);
+  q.doff = load_const(&g->doff); q.toff = load_const(&g->toff); q.voff = load_const(&g->voff);
+  q.thrust = load_const(&g->thrust); q.massflow = load_const(&g->massflow); q.area = load_const(&g->area);
+  q.nozzle = load_const(&g->nozzle);
+  return q;
+}
+#endif
+
 // one aero path-constraint row = one state node of a constrained phase (lib/con_aero.py)
 struct AeroRowDev {
   int32_t phase, k, nk, row0;  // phase, node 0..nk-1 inside it, rows of its spec, first row of its spec

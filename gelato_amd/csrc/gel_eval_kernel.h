@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   const int sec = __builtin_amdgcn_readfirstlane(ck.x);
   const int j0 = __builtin_amdgcn_readfirstlane(ck.y);
   const int j = j0 + lane;  // node inside the phase
-  const PhaseDev& ph = P.phases[sec];
+  const PhaseDev ph = load_phase(P.phases + sec);  // by value, in SGPRs, before any store
   const int n = ph.n;
   // the matrix pipe reads all 64 lanes: lanes past the end of a ragged phase stay alive (with zero
   // operands and clamped addresses) until the D.X product is done
