@@ -76,6 +76,10 @@ def mock_optimizer_loop(objfunc, sens, xdict, iterations=5, step=1e-7):
         t_obj += b - a
         t_sens += c - b
         fails += int(f) + int(g)
-    return {"optTime": time.perf_counter() - t0, "userObjTime": t_obj, "userSensTime": t_sens,
+    opt = time.perf_counter() - t0
+    # the reference prints seven counters (Trajectory_Optimization.py:511-517); without an optimiser in the
+    # loop optCodeTime is 0 and interfaceTime is what is left of optTime
+    return {"optTime": opt, "userObjTime": t_obj, "userSensTime": t_sens, "optCodeTime": 0.0,
+            "interfaceTime": max(0.0, opt - t_obj - t_sens),
             "userObjCalls": iterations, "userSensCalls": iterations, "fails": fails,
             "f_init": f_init, "jac_init": jac_init}
