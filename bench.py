@@ -232,6 +232,18 @@ def main():
         out["host_batch_pcie_inclusive"] = {"batch": Bh, "evals_per_s": Bh / dt, "ms": 1e3 * dt,
                                             "bytes_moved": Bh * E.algorithmic_bytes}
 
+        # informational: generic column-batched forward difference (lib/jac_fd.py): dense
+        # d(eqcon_dyn_vel)/dx over all columns = num_vars + 1 residual evaluations in one launch, host arrays out
+        try:
+            E.jac_fd("vel", x0)
+            t0 = time.perf_counter()
+            Jd, _ = E.jac_fd("vel", x0)
+            dtj = time.perf_counter() - t0
+            out["jac_fd_generic"] = {"group": "vel", "rows": int(Jd.shape[0]), "columns": int(Jd.shape[1]),
+                                     "ms": 1e3 * dtj, "residual_evals_per_s": (Jd.shape[1] + 1) / dtj}
+            del Jd
+        except Exception as ex:  # noqa: BLE001
+            out["jac_fd_generic"] = {"error": str(ex)}
         # informational: the aero path constraints on every phase but the last, "all" nodes:
         # value + forward-difference gradient of the three kinds, host buffers in and out
         try:

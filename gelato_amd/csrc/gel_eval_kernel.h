@@ -42,7 +42,11 @@ static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wav
 typedef double gel_double4 __attribute__((ext_vector_type(4)));
 
 // JAC: also the FD Jacobian.  MFMA: D.X on the matrix pipe (v_mfma_f64_16x16x4_f64) instead of VALU FMAs.
-template <bool JAC, bool MFMA>
+// SPLIT (latency form for a handful of decision vectors, e.g. the optimiser's B = 1 callback): every work item
+// becomes four wavefronts -- part 0 does everything except the three position sweeps, parts 1..3 do the
+// centre evaluation plus ONE position sweep each -- so the serial chain of a wavefront is about two trips of
+// the atmosphere/geodesy chain instead of four plus the light sweeps.  Same expressions, same bits.
+template <bool JAC, bool MFMA, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   extern __shared__ double lds[];
@@ -54,7 +58,9 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   lds_double* park = wave_lds + lane;
 #define PARK(slot) park[(slot) * 64]
 
-  const long long item = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
+  long long item = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
+  const int part = SPLIT ? (int)(item & 3) : 0;  // wave-uniform
+  if (SPLIT) item >>= 2;
   if (item >= (long long)B * P.nchunks) return;
   // work-item major: all B vectors of one (phase, chunk) are neighbours, so the four wavefronts of a
   // workgroup cost the same (its LDS is only released when the slowest ends), and the list is ordered
@@ -67,6 +73,8 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   const int j0 = __builtin_amdgcn_readfirstlane(ck.y);
   const int j = j0 + lane;  // node inside the phase
   const PhaseDev ph = load_phase(P.phases + sec);  // by value, in SGPRs, before any store
+  if (SPLIT && part && !ph.air) return;  // only aerodynamic phases have the long position sweeps
+  const bool lead = !(SPLIT && part);     // the wavefront that owns everything but the split-off sweeps
   const int n = ph.n;
   // the matrix pipe reads all 64 lanes: lanes past the end of a ragged phase stay alive (with zero
   // operands and clamped addresses) until the D.X product is done
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   const double dx = P.dx, ut = P.ut;
   double chk = 0.0;  // running sum of everything written: NaN/Inf detector
 
-  double* rb = res ? res + (size_t)b * 11 * N : nullptr;
+  double* rb = (res && lead) ? res + (size_t)b * 11 * N : nullptr;
   double* jb = JAC ? jvar + (size_t)b * P.V + ph.voff + j : nullptr;
 #ifdef GEL_ABL_NOSTORE  // ablation (tools/variant.sh): everything computed, (almost) nothing stored
 #define EMIT(slot, val)                                   \
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 
     // ---- everything that needs no velocity RHS is finished here, while its inputs are in registers:
     //      position Jacobian entries, the whole quaternion group (:155-213, :499-632) ----
-    if (JAC) {
+    if (JAC && lead) {
       const double rh_vel = -P.uv * (tf - to) * ut / 2.0 / P.up;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         EMIT(6 + c, -rh_to);
       }
     }
-    if (!ph.hold) {
+    if (!ph.hold && lead) {
       double fq[4];
       quat_rate(q, u0, u1, P.uu, fq);
       if (rb) {
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
       PosPart pp;
       double v[3], dir[3], w[3], F[3], T, fp8 = 0.0;
 #pragma unroll 1
-      for (int k = JAC ? 0 : 3;; k++) {
+      for (int k = SPLIT ? (part ? part - 1 : 3) : (JAC ? 0 : 3);; k = SPLIT ? 3 : k + 1) {
         double r[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
@@ -331,10 +339,21 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         }
       }
       // here pp, w, F, T, v, dir, fc are the centre values
-      if (JAC) {
+      if (JAC && SPLIT && part) {
+        // this wavefront's one position sweep (parked like in the unsplit form)
+        const int k = part - 1;
 #pragma unroll
-        for (int i = 0; i < 8; i++) EMIT(12 + i, FDQ(PARK(PK_FP0 + i), fc[i % 3]));
-        EMIT(12 + 8, FDQ(fp8, fc[2]));
+        for (int c = 0; c < 3; c++) {
+          const int i = 3 * k + c;
+          EMIT(12 + i, FDQ((i < 8) ? PARK(PK_FP0 + i) : fp8, fc[c]));
+        }
+      }
+      if (JAC && lead) {
+        if (!SPLIT) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) EMIT(12 + i, FDQ(PARK(PK_FP0 + i), fc[i % 3]));
+          EMIT(12 + 8, FDQ(fp8, fc[2]));
+        }
 
         // The position-sweep slots are free now.  Values that only LATER blocks need leave the registers:
         // the t0/tf sweeps' inputs (half-latitude pair, 1/p, wind) and the centre aero force.

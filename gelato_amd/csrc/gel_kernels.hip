@@ -338,6 +338,9 @@ hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDe
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+// launches with at most this many wavefronts (after the x4) use the split latency form: one per SIMD
+constexpr long long kSplitMaxWaves = 1024;
+
 static size_t table_lds_bytes(int Kw, int Kc) { return sizeof(double) * (size_t)(kAtmDoubles + 3 * Kw + 2 * Kc); }
 
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
@@ -347,6 +350,15 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
   const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)PK_COUNT * kBlock);  // tables | per-lane park
   // D.X on the matrix pipe only when residual rows are requested at all (d_res) and the problem asks for it
   const bool mfma = P.use_mfma && d_res;
+  // a handful of vectors cannot fill 1024 SIMDs: trade recomputation of the centre for a shorter serial chain
+  if (d_jvar && waves * 4 <= kSplitMaxWaves) {
+    const unsigned g4 = (unsigned)((waves * 4 * 64 + kBlock - 1) / kBlock);
+    if (mfma)
+      hipLaunchKernelGGL((eval_kernel<true, true, true>), dim3(g4), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+    else
+      hipLaunchKernelGGL((eval_kernel<true, false, true>), dim3(g4), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+    return hipGetLastError();
+  }
   if (d_jvar && mfma)
     hipLaunchKernelGGL((eval_kernel<true, true>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
   else if (d_jvar)
