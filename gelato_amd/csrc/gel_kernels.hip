@@ -273,12 +273,18 @@ GEL_DEV double aero_value(int kind, const double re[3], const double ve[3], cons
   return f / limit;
 }
 
+// SPLIT (latency form for small launches): 13 lanes per row -- lane group 0 writes the value, group s + 1 the
+// gradient entry of sweep s (re-evaluating the centre) -- so a lane runs the chain twice instead of 13 times.
+template <bool SPLIT>
 __global__ void aero_kernel(ProblemDev P, int kind, int nrows, const AeroRowDev* __restrict__ rows, int B,
                             const double* __restrict__ x, double* __restrict__ con, double* __restrict__ jac) {
   extern __shared__ double lds[];
   const Tables tb = stage_tables(P, lds);
-  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (long long)B * nrows) return;
+  long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = (long long)B * nrows;
+  int sp = 0;  // sweep group, lane-group major so that a wavefront mostly shares one sweep
+  if (SPLIT) { sp = (int)(tid / per); tid -= (long long)sp * per; if (sp > 12 || (sp && !jac)) return; }
+  if (tid >= per) return;
   const int b = (int)(tid / nrows), row = (int)(tid - (long long)b * nrows);
   const AeroRowDev R = rows[row];
   const PhaseDev& ph = P.phases[R.phase];
@@ -295,8 +301,8 @@ __global__ void aero_kernel(ProblemDev P, int kind, int nrows, const AeroRowDev*
   const double dx = P.dx;
   const double fc = aero_value(kind, re, ve, q, TNODE(to, tf), P, tb, R.limit);
   double chk = 1.0 - fc;
-  con[(size_t)b * nrows + row] = 1.0 - fc;  // con_aero.py:127-139
-  if (jac) {
+  if (!SPLIT || sp == 0) con[(size_t)b * nrows + row] = 1.0 - fc;  // con_aero.py:127-139
+  if (jac && !(SPLIT && sp == 0)) {
     const int nq = (kind == 1) ? 0 : 4;
     double* jb = jac + (size_t)b * nrows * (8 + nq);
     double* jp = jb + 3 * R.row0 + R.k;                         // position block, [j][k] per spec
@@ -304,7 +310,7 @@ __global__ void aero_kernel(ProblemDev P, int kind, int nrows, const AeroRowDev*
     double* jq = jb + 6 * nrows + 4 * R.row0 + R.k;             // quaternion block
     double* jt = jb + (6 + nq) * nrows + 2 * R.row0 + R.k;      // t block: t0 column then tf column
 #pragma unroll 1
-    for (int s = 0; s < 12; s++) {
+    for (int s = SPLIT ? sp - 1 : 0; s < (SPLIT ? sp : 12); s++) {
       double rp[3], vp[3], qp[4];
 #pragma unroll
       for (int c = 0; c < 3; c++) { rp[c] = (s == c) ? re[c] + dx : re[c]; vp[c] = (s == 3 + c) ? ve[c] + dx : ve[c]; }
@@ -330,8 +336,12 @@ hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDe
   if (B <= 0 || nrows <= 0) return hipSuccess;
   const long long threads = (long long)B * nrows;
   const size_t lds = sizeof(double) * (size_t)(kAtmDoubles + 3 * P.Kw + 2 * P.Kc);
-  hipLaunchKernelGGL(aero_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), lds, s, P, kind, nrows, rows, B, d_x,
-                     d_con, d_jac);
+  if (d_jac && threads * 13 <= 64 * 1024)  // fits one wavefront per SIMD even when split: take the short chain
+    hipLaunchKernelGGL(aero_kernel<true>, dim3((unsigned)((threads * 13 + 63) / 64)), dim3(64), lds, s, P, kind, nrows,
+                       rows, B, d_x, d_con, d_jac);
+  else
+    hipLaunchKernelGGL(aero_kernel<false>, dim3((unsigned)((threads + 63) / 64)), dim3(64), lds, s, P, kind, nrows, rows,
+                       B, d_x, d_con, d_jac);
   return hipGetLastError();
 }
 
