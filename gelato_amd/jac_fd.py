@@ -1,25 +1,46 @@
-"""Generic forward-difference Jacobian, column-batched on the GPU.
+"""Generic forward-difference Jacobian: interface of the reference's lib/jac_fd.py:29-62.
 
-Interface of the reference's lib/jac_fd.py:29-62: ``jac_fd(con, xdict, pdict, unitdict, condition)``
-returns ``{key: dense ndarray [nRows, xdict[key].size]}`` with column i = (con(x + dx e_i) - con(x))/dx,
-for *every* key of xdict (also those a constraint does not depend on, lib/jac_fd.py:54-60).
+``jac_fd(con, xdict, pdict, unitdict, condition)`` returns ``{key: dense ndarray [nRows, xdict[key].size]}``
+with column i = (con(x + dx e_i) - con(x)) / dx, for *every* key of xdict (also those a constraint does not
+depend on, lib/jac_fd.py:54-60).
 
-Here ``con`` must be one of the four defect residual functions of gelato_amd.con_dynamics: all
-num_vars + 1 perturbed decision vectors are built and evaluated in one batched launch on the device
-(one residual evaluation per decision-vector column), and the quotient is formed by a transpose
-kernel.  An arbitrary Python callable cannot run on the GPU and there is no CPU fallback in this
-package, so anything else raises TypeError (the reference uses jac_fd only for user-defined
-constraints, lib/con_user.py:33-42, which are outside the hot path).
+* ``con`` is one of the four defect residual functions of gelato_amd.con_dynamics: all num_vars + 1 perturbed
+  decision vectors are built and evaluated in ONE batched launch on the device (one residual evaluation per
+  column), and the quotient is formed by a transpose kernel (gel_jac_fd).
+* ``con`` is anything else -- in the reference that is the user's own ``equality_user`` / ``inequality_user``
+  from ``user_constraints.py`` (lib/con_user.py:33-42): a Python function this package knows nothing about.
+  It is called once per column exactly as the reference does; nothing of the engine runs in that loop (the
+  engine has no CPU path, and the user's Python cannot run on the GPU).  Unlike the reference the caller's
+  arrays are never modified: the perturbation is applied to a private copy, so no += / -= round-off drifts
+  into later columns.
 """
+import numpy as np
+
 from . import con_dynamics
 from .engine import XKEYS, pack_x
+
+
+def _jac_fd_user_callable(con, xdict, pdict, unitdict, condition):
+    dx = pdict["dx"]
+    g_base = con(xdict, pdict, unitdict, condition)
+    n_rows = len(g_base) if hasattr(g_base, "__len__") else 1          # lib/jac_fd.py:49-53
+    jac = {}
+    for key, val in xdict.items():
+        jac[key] = np.zeros((n_rows, val.size))
+        work = np.array(val, dtype=np.float64, copy=True)
+        xp = dict(xdict)
+        xp[key] = work
+        for i in range(val.size):
+            work[i] = val[i] + dx
+            jac[key][:, i] = (con(xp, pdict, unitdict, condition) - g_base) / dx
+            work[i] = val[i]
+    return jac
 
 
 def jac_fd(con, xdict, pdict, unitdict, condition):
     group = con_dynamics.RESIDUAL_FUNCTIONS.get(con)
     if group is None:
-        raise TypeError("gelato_amd.jac_fd runs on the device and only accepts the four "
-                        "gelato_amd.con_dynamics.equality_dynamics_* functions")
+        return _jac_fd_user_callable(con, xdict, pdict, unitdict, condition)
     eng = con_dynamics.engine_of(pdict, unitdict)
     J, rc = eng.jac_fd(group, pack_x(xdict))
     pdict[con_dynamics._KEY].status = rc

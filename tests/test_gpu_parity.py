@@ -404,8 +404,11 @@ def test_callback_surface_like_reference():
     # jac_fd front end
     J = jac_fd.jac_fd(con_dynamics.equality_dynamics_mass, xd, pdict, unitdict, condition)
     assert set(J) == set(xd) and J["mass"].shape == (pdict["N"], pdict["M"])
-    with pytest.raises(TypeError):
-        jac_fd.jac_fd(lambda *a: np.zeros(3), xd, pdict, unitdict, condition)
+    # a user's own Python function goes column by column like lib/jac_fd.py, without touching xd
+    Ju = jac_fd.jac_fd(lambda xd_, *a: 2.0 * xd_["mass"][:3] + xd_["t"][-1], xd, pdict, unitdict, condition)
+    assert set(Ju) == set(xd) and Ju["mass"].shape == (3, pdict["M"]) and np.allclose(Ju["mass"][:, :3], 2 * np.eye(3), atol=1e-6)
+    assert np.allclose(Ju["t"][:, -1], 1.0, atol=1e-6) and not Ju["position"].any()
+    assert all(np.array_equal(xd[k], keep[k]) for k in xd)
     stats = driver.mock_optimizer_loop(objfunc, sens, xd, iterations=3)
     assert stats["userObjCalls"] == 3 and stats["fails"] == 0
 

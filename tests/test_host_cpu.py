@@ -144,3 +144,50 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "gelato_oracle" not in txt, f
+
+
+def test_jac_fd_of_a_user_function_matches_reference_loop(tmp_path, monkeypatch):
+    """SURVEY f-2: lib/jac_fd.py + lib/con_user.py on a user's own Python function (golden G10 = the reference's
+    loop on tests/golden/user_function.py).  No engine is involved: host logic only."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from user_function import scalar_con, user_con
+    from gelato_amd import jac_fd
+    g = load_golden("g10_jacfd_user.npz")
+    g6 = load_golden("g6_example.npz")
+    nn = problem_from_golden(g6)["num_nodes"]
+    N, S = int(nn.sum()), len(nn)
+    M = N + S
+    x = g["x"]
+    o = np.cumsum([0, M, 3 * M, 3 * M, 4 * M, 2 * N, S + 1])
+    keys = ["mass", "position", "velocity", "quaternion", "u", "t"]
+    xd = {k: x[o[i]:o[i + 1]].copy() for i, k in enumerate(keys)}
+    keep = {k: v.copy() for k, v in xd.items()}
+    pdict = {"dx": float(g["dx"])}
+    unitdict = {"mass": 27442.0, "position": 6378137.0, "velocity": 1000.0, "u": 1.0, "t": 597.0}
+    for name, fn in (("user", user_con), ("scalar", scalar_con)):
+        J = jac_fd.jac_fd(fn, xd, pdict, unitdict, None)
+        assert list(J) == keys                                       # every key, reference order
+        for k in keys:
+            ref = g["%s_%s" % (name, k)]
+            assert J[k].shape == ref.shape
+            # the reference's in-place += / -= leaves <= 1.1e-16 of drift in x (golden 'drift'), i.e. <= ~1e-8 here
+            assert np.all(np.abs(J[k] - ref) <= 1e-6 + 1e-7 * np.abs(ref)), (name, k, np.abs(J[k] - ref).max())
+    assert all(np.array_equal(xd[k], keep[k]) for k in keys)          # the caller's arrays are never touched
+    # con_user: no user_constraints module -> behaves like _user_constraints_empty.py
+    from gelato_amd import con_user
+    monkeypatch.setattr(con_user, "_mod", None)
+    assert con_user.equality_user(xd, pdict, unitdict, None) is None
+    assert con_user.equality_jac_user(xd, pdict, unitdict, None) is None
+    # ... and with one on the path it is differentiated by jac_fd (lib/con_user.py:33-42)
+    (tmp_path / "user_constraints.py").write_text(
+        "from user_function import user_con as equality_user\n"
+        "def inequality_user(xdict, pdict, unitdict, condition):\n    return None\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    monkeypatch.setattr(con_user, "_mod", None)
+    sys.modules.pop("user_constraints", None)
+    Ju = con_user.equality_jac_user(xd, pdict, unitdict, None)
+    assert np.allclose(Ju["velocity"], g["user_velocity"], rtol=1e-7, atol=1e-6)
+    assert con_user.inequality_jac_user(xd, pdict, unitdict, None) is None
+    sys.modules.pop("user_constraints", None)
+    monkeypatch.setattr(con_user, "_mod", None)
