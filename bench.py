@@ -187,7 +187,7 @@ def main():
                    "jacobian_values_per_eval": E.V, "coo_nnz": E.total_nnz, "parallelism": ("phase-shard x%d + all-reduce" if shard else "replicas x%d") % world,
                    "output": "4 defect residuals + all x-dependent COO Jacobian values (compact), in HBM"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "gel::eval_kernel<true, true>",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "gel::eval_kernel<true, true, false>",
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_eval": E.algorithmic_bytes,
                      "algorithmic_bytes_per_launch": abytes,
                      "note": "fp64-VALU-bound, not HBM-bound: ~6.6 VALU lane-instructions per algorithmic byte (libm chains); VALU floor ~52% of the HBM roofline, see DESIGN.md 3.1"},
