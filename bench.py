@@ -27,9 +27,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(prob, D, tau, X, budget_s=12.0):
+def cpu_baseline(prob, D, tau, X, gpu_first=None, budget_s=12.0):
     """The oracle (scalar C port of the reference algorithm) timed on this box's host cores, 1 thread,
-    on a bounded sample of the same workload."""
+    on a bounded sample of the same workload.  This leg is the only place bench.py touches oracle/: besides
+    the timing it checks element 0 of what the GPU just produced (`gpu_first` = (res, full values)) against
+    it, after the timed region."""
     import oracle
     P = oracle.Problem(prob, D=D, tau=tau)
     t0 = time.perf_counter()
@@ -53,6 +55,10 @@ def cpu_baseline(prob, D, tau, X, budget_s=12.0):
             out["all_cores"] = {"value": m / dt2, "cores": nc, "sample": "%d evals, %.1f s" % (m, dt2)}
     except Exception:
         pass
+    if gpu_first is not None:
+        ores, ovals = P.eval_batch(X[:1])
+        out["parity_spot_check"] = {"residual_max_abs_diff": float(np.max(np.abs(gpu_first[0] - ores[0]))),
+                                    "jacobian_max_abs_diff": float(np.max(np.abs(gpu_first[1] - ovals[0])))}
     return out
 
 
@@ -156,16 +162,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    # parity spot check of what was just timed (element 0 against the oracle), never inside the timed region
-    check = None
-    if not a.no_cpu_baseline:
-        import oracle
-        P = oracle.Problem(prob, D=D, tau=tau)
-        ores, ovals = P.eval_batch(X[:1])
-        r0 = dres[0].cpu().numpy()
-        full0 = E.expand(djv[0].cpu().numpy())
-        check = {"residual_max_abs_diff": float(np.max(np.abs(r0 - ores[0]))),
-                 "jacobian_max_abs_diff": float(np.max(np.abs(full0 - ovals[0])))}
+    # element 0 of what was just timed, kept for the oracle check inside the cpu_baseline leg
+    gpu_first = None
+    if not a.no_cpu_baseline and world == 1:
+        gpu_first = (dres[0].cpu().numpy(), E.expand(djv[0].cpu().numpy()))
 
     evals = (1 if shard else world) * B * K
     abytes = E.algorithmic_bytes * B  # per launch: SURVEY.md 8(d) A_min x evals per launch
@@ -193,8 +193,6 @@ def main():
                      "note": "fp64-VALU-bound, not HBM-bound: ~6.6 VALU lane-instructions per algorithmic byte (libm chains); VALU floor ~52% of the HBM roofline, see DESIGN.md 3.1"},
         "status": int(status),
     }
-    if check:
-        out["parity_spot_check"] = check
 
     if not a.no_extras:
         # informational: materialise every COO value like the reference does (compact -> full expansion)
@@ -271,7 +269,7 @@ def main():
             out["aero_constraints"] = {"error": str(ex)}
 
     if not a.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(prob, D, tau, X)
+        out["cpu_baseline"] = cpu_baseline(prob, D, tau, X, gpu_first)
         out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if use_dist:
