@@ -16,6 +16,20 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+
+/* Per-thread scratch for the dense sub-matrices of the velocity / quaternion Jacobians (300-530 KB at n = 64):
+ * allocated once per thread and kept.  Fresh malloc()s of that size are mmap()ed and page-faulted on every
+ * call, which serialises the OpenMP threads of orc_eval_batch on the kernel's mm lock. */
+static double* tls_buf(int slot, size_t n) {
+  static __thread double* buf[2];
+  static __thread size_t cap[2];
+  if (cap[slot] < n) {
+    free(buf[slot]);
+    buf[slot] = (double*)malloc(n * sizeof(double));
+    cap[slot] = buf[slot] ? n : 0;
+  }
+  return buf[slot];
+}
 #endif
 
 /* ------------------------------------------------------------------ */
@@ -749,7 +763,7 @@ static void jac_vel(const orc_problem* p, const double* x_in, int32_t* rows, int
   double* fc = (double*)malloc(3 * nmax * sizeof(double));
   double* fp = (double*)malloc(3 * nmax * sizeof(double));
   double* rh = (double*)malloc(3 * nmax * sizeof(double));
-  double* sub = (double*)malloc((size_t)9 * nmax * (nmax + 1) * sizeof(double));
+  double* sub = tls_buf(0, (size_t)9 * nmax * (nmax + 1));
   const double dx = p->dx;
   for (int i = 0; i < p->S; i++) {
     int n = p->n[i], ua = p->ua[i], ub = ua + n, xa = ua + i, xb = xa + n + 1;
@@ -831,7 +845,7 @@ static void jac_vel(const orc_problem* p, const double* x_in, int32_t* rows, int
     }
     (void)xb;
   }
-  free(x); free(tn); free(tn2); free(fc); free(fp); free(rh); free(sub);
+  free(x); free(tn); free(tn2); free(fc); free(fp); free(rh);
 }
 
 static void jac_quat(const orc_problem* p, const double* x_in, int32_t* rows, int32_t* cols, double* vals) {
@@ -847,7 +861,7 @@ static void jac_quat(const orc_problem* p, const double* x_in, int32_t* rows, in
   double* fc = (double*)malloc(4 * nmax * sizeof(double));
   double* fp = (double*)malloc(4 * nmax * sizeof(double));
   double* rh = (double*)malloc(4 * nmax * sizeof(double));
-  double* sub = (double*)malloc((size_t)16 * nmax * (nmax + 1) * sizeof(double));
+  double* sub = tls_buf(1, (size_t)16 * nmax * (nmax + 1));
   const double dx = p->dx;
   for (int i = 0; i < p->S; i++) {
     int n = p->n[i], ua = p->ua[i], ub = ua + n, xa = ua + i, xb = xa + n + 1;
@@ -886,7 +900,7 @@ static void jac_quat(const orc_problem* p, const double* x_in, int32_t* rows, in
     for (int j = 0; j < 4 * n; j++) put(Jt, 4 * ua + j, i, fc[j] * p->ut / 2.0);
     for (int j = 0; j < 4 * n; j++) put(Jt, 4 * ua + j, i + 1, -(fc[j] * p->ut / 2.0));
   }
-  free(x); free(fc); free(fp); free(rh); free(sub);
+  free(x); free(fc); free(fp); free(rh);
 }
 
 void orc_jacobian(const orc_problem* p, int g, const double* x, int32_t* rows, int32_t* cols, double* vals) {
@@ -938,15 +952,25 @@ void orc_eval_batch(const orc_problem* p, int B, const double* x, double* res, d
     for (int b = 0; b < orc_num_blocks(g); b++) s += orc_block_nnz(p, g, b);
   }
   (void)nthreads;
+  /* vals == NULL: timing mode -- every thread writes its Jacobian values into one scratch array it
+   * allocates once, instead of B fresh 5-MB rows (whose page faults serialise the threads) */
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(dynamic)
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
 #endif
-  for (int b = 0; b < B; b++) {
-    const double* xb = x + (size_t)b * nv;
-    for (int g = 0; g < 4; g++) {
-      orc_residual(p, g, xb, res + (size_t)b * nr + roff[g]);
-      orc_jacobian(p, g, xb, NULL, NULL, vals + (size_t)b * nnz + goff[g]);
+  {
+    double* scratch = vals ? NULL : (double*)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic)
+#endif
+    for (int b = 0; b < B; b++) {
+      const double* xb = x + (size_t)b * nv;
+      double* vb = vals ? vals + (size_t)b * nnz : scratch;
+      for (int g = 0; g < 4; g++) {
+        orc_residual(p, g, xb, res + (size_t)b * nr + roff[g]);
+        orc_jacobian(p, g, xb, NULL, NULL, vb + goff[g]);
+      }
     }
+    free(scratch);
   }
 }
 
