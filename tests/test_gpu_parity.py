@@ -642,3 +642,43 @@ def test_pipelined_host_batch_equals_resident_launch():
     rb, jb, rc = E.eval_batch(Xb)
     assert rc == 1 and np.array_equal(rb[:200], res[:200]) and np.array_equal(jb[201:], jv[201:])
     assert E.eval_batch(X)[2] == 0
+
+
+def test_all_atmosphere_layers_and_both_hemispheres():
+    """One aerodynamic phase whose 64 nodes climb from 300 m below the ellipsoid to 700 km: every US-1976 layer
+    (lapse, isothermal, the 91-110 km ellipse, the exponential above 120 km), the geopotential switch at 86 km,
+    wind / CA clamps on both sides, southern and northern latitudes, Mach 0.03 ... 30, long flight times."""
+    prob, _, _ = named_problem("example")
+    rng = np.random.default_rng(23)
+    prob = dict(prob)
+    n = 64
+    prob["num_nodes"] = np.array([n], dtype=np.int32)
+    for k, v in [("thrust", 420000.0), ("massflow", 140.9), ("reference_area", 2.21), ("nozzle_area", 0.68)]:
+        prob[k] = np.array([v])
+    prob["engine_on"] = np.array([1], dtype=np.int32)
+    prob["attitude_hold"] = np.array([0], dtype=np.int32)
+    E, P = make_pair(prob)
+    up, uv, ut = prob["units"][1], prob["units"][2], prob["units"][4]
+    alt = np.concatenate([[-300.0, -50.0, 0.0, 10.0], np.linspace(2e3, 130e3, 53), [150e3, 200e3, 300e3, 400e3, 500e3, 600e3, 700e3, 700e3]])
+    assert len(alt) == n + 1
+    # -54 ... +83 degrees (geocentric): the dense-air nodes sit at moderate latitude on purpose.  The altitude
+    # p/cos(lat) - N amplifies the last-bit difference between ocml's and glibc's atan2/sincos by tan(lat)/cos(lat),
+    # and the sea-level pressure-thrust term turns that into FD noise ~ nozzle*P/H * d(alt)/dx: at 80 degrees and
+    # 0 m the reference's own entries are only good to 3e-6 relative (measured here: 8.7e-4 on an entry of 257).
+    lat = np.linspace(-0.95, 1.45, n + 1)
+    lon = np.linspace(-3.0, 3.0, n + 1)
+    a_e, b_e = 6378137.0, 6356752.314245
+    R = (a_e * b_e / np.sqrt((b_e * np.cos(lat)) ** 2 + (a_e * np.sin(lat)) ** 2) + alt) / up   # ellipsoid radius + altitude
+    pos = np.column_stack([R * np.cos(lat) * np.cos(lon), R * np.cos(lat) * np.sin(lon), R * np.sin(lat)])
+    speed = np.geomspace(10.0, 9000.0, n + 1) / uv
+    d = rng.standard_normal((n + 1, 3))
+    vel = d / np.linalg.norm(d, axis=1, keepdims=True) * speed[:, None]
+    quat = rng.standard_normal((n + 1, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([np.linspace(1.0, 0.3, n + 1), pos.ravel(), vel.ravel(), quat.ravel(),
+                        2.0 * rng.standard_normal(2 * n), [100.0 / ut, 9000.0 / ut]])
+    check_against_oracle(E, P, x, "all-layers")
+    # the oracle's own altitudes really span the table (guards the construction above)
+    oracle = _setup()
+    h = np.array([oracle.ecef2geodetic(*(pos[i] * up))[2] for i in (1, n)])
+    assert h[0] < 0.0 and h[1] > 6.0e5
