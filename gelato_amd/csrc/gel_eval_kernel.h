@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         for (int c = 0; c < 4; c++) {
           const double rh = fq[c] * (tf - to) * ut / 2.0;
           const double cq = lq[c] - rh;
-          rb[7 * N + 4 * g + c] = cq;
+          __builtin_nontemporal_store(cq, &rb[7 * N + 4 * g + c]);
           chk += cq;
         }
       }
@@ -274,20 +274,20 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
       } else {
         cm = me - m0;
       }
-      rb[g] = cm;
+      __builtin_nontemporal_store(cm, &rb[g]);
       chk += cm;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const double rh = ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
         const double cp = lr[c] - rh;
-        rb[N + 3 * g + c] = cp;
+        __builtin_nontemporal_store(cp, &rb[N + 3 * g + c]);
         chk += cp;
       }
       if (ph.hold) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const double cq = q[c] - q0[c];
-          rb[7 * N + 4 * g + c] = cq;
+          __builtin_nontemporal_store(cq, &rb[7 * N + 4 * g + c]);
           chk += cq;
         }
       }
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     for (int c = 0; c < 3; c++) {
       const double rh = fc[c] * (tf - to) * ut / 2.0;
       const double cv = PARK(PK_LV0 + c) - rh;
-      rb[4 * N + 3 * g + c] = cv;
+      __builtin_nontemporal_store(cv, &rb[4 * N + 3 * g + c]);
       chk += cv;
     }
   }
