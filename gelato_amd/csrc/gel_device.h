@@ -56,8 +56,10 @@ struct ProblemDev {
   int32_t use_mfma;          // D.X on v_mfma_f64_16x16x4_f64 instead of VALU FMAs
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)
-  const int2* chunks;        // [nchunks] {phase, first node of the chunk}: dearest phase type first for a whole
-                             // launch, the natural (phase) order for a phase-sharded one
+  const int4* chunks;        // [nchunks] {phase, first node of the chunk, offset of its MFMA-ordered D in Dsw / 4, 0}:
+                             // dearest phase type first for a whole launch, the natural (phase) order for a
+                             // phase-sharded one
+  const double* Dsw;         // D in matrix-pipe feed order: [chunk][k-step][lane][row tile 0..3] (see gel_host.hip)
   int64_t V;                 // compact entries per eval
   const PhaseDev* phases;    // [S]
   const int32_t* node_phase; // [N]

@@ -68,9 +68,10 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   // the mixed vehicle at B = 4096, -6..9 % at B = 2048)
   const int ci = (int)(item / B);
   const int b = (int)(item - (long long)ci * B);
-  const int2 ck = P.chunks[P.chunk0 + ci];
+  const int4 ck = P.chunks[P.chunk0 + ci];
   const int sec = __builtin_amdgcn_readfirstlane(ck.x);
   const int j0 = __builtin_amdgcn_readfirstlane(ck.y);
+  const int dsw = __builtin_amdgcn_readfirstlane(ck.z);  // first gel_double4 of this work item in Dsw
   const int j = j0 + lane;  // node inside the phase
   const PhaseDev ph = load_phase(P.phases + sec);  // by value, in SGPRs, before any store
   if (SPLIT && part && !ph.air) return;  // only aerodynamic phases have the long position sweeps
@@ -150,24 +151,17 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         gel_double4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = gel_double4{0.0, 0.0, 0.0, 0.0};
-        const double* Dt = P.Dt + ph.doff;
-        // Only the B operand is zeroed for k > n: rows of nodes >= n and columns >= 11 are computed on
-        // clamped (finite) data and never read back, so A needs no masking at all.
-        unsigned offA[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) offA[t] = (unsigned)min(j0 + 16 * t + c16, n - 1);
+        // A operands come pre-arranged (ProblemDev::Dsw): one 32-byte access per lane and k-step fetches the
+        // values of all four row tiles; columns past n hold zeros there, so B is only clamped, never masked.
+        const gel_double4* ap = reinterpret_cast<const gel_double4*>(P.Dsw) + (size_t)dsw * 1 + lane;
         const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4)
         const unsigned un = (unsigned)n, ubs = (unsigned)bs;
         for (int ks = 0; ks < ksteps; ks++) {
-          const unsigned k = 4u * ks + kq;
-          const bool kv = k <= un;
-          const unsigned kc = kv ? k : un;
-          const double bl = bp[kc * ubs];
-          const double bv = kv ? bl : 0.0;
-          const unsigned ko = kc * un;
+          const unsigned k = min(4u * ks + kq, un);
+          const double bl = bp[k * ubs];
+          const gel_double4 a4 = ap[ks * 64];
 #pragma unroll
-          for (int t = 0; t < 4; t++)
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Dt[ko + offA[t]], bv, acc[t], 0, 0, 0);
+          for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], bl, acc[t], 0, 0, 0);
         }
         // transpose through the wave's LDS region: tile -> one row (node) per lane
 #pragma unroll

@@ -142,8 +142,9 @@ struct gel_problem {
   // device buffers (static)
   gel::PhaseDev* d_phases = nullptr;
   int32_t* d_node_phase = nullptr;
-  int2* d_chunks = nullptr;         // work items in phase order (what gel_chunk_phase / shard ranges index)
-  int2* d_chunks_sorted = nullptr;  // the same items, dearest phase type first (whole launches)
+  int4* d_chunks = nullptr;         // work items in phase order (what gel_chunk_phase / shard ranges index)
+  int4* d_chunks_sorted = nullptr;  // the same items, dearest phase type first (whole launches)
+  double* d_Dsw = nullptr;          // D per work item in the feed order of v_mfma_f64_16x16x4_f64
   double* d_Dt = nullptr;
   double* d_tau = nullptr;
   double* d_tables = nullptr;
@@ -613,18 +614,35 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   gel::fill_atmosphere_table(tables.data());
   std::memcpy(tables.data() + gel::kAtmTableDoubles, d->wind_table, sizeof(double) * 3 * d->wind_rows);
   std::memcpy(tables.data() + gel::kAtmTableDoubles + 3 * d->wind_rows, d->ca_table, sizeof(double) * 2 * d->ca_rows);
-  std::vector<int2> chunks;
-  for (int i = 0; i < S; i++)
-    for (int j0 = 0; j0 < p->ph[i].n; j0 += 64) chunks.push_back(make_int2(i, j0));
+  // Work items, and D laid out the way the matrix pipe consumes it.  A operand of v_mfma_f64_16x16x4_f64:
+  // lane l holds A[row l & 15][k l >> 4]; a wavefront covers 64 nodes = 4 row tiles, and k-step ks covers
+  // columns 4 ks .. 4 ks + 3 of D.  Dsw[((item_off + ks) * 64 + l) * 4 + t] = D[j0 + 16 t + (l & 15)][4 ks + (l >> 4)]
+  // (0 beyond column n; rows beyond the phase repeat its last row: computed, never read back), so that one lane
+  // fetches its four tile operands of a k-step with a single 32-byte access at a fixed stride.
+  std::vector<int4> chunks;
+  std::vector<double> Dsw;
+  for (int i = 0; i < S; i++) {
+    const HostPhase& h = p->ph[i];
+    const int n = h.n, ksteps = (n + 4) >> 2;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      chunks.push_back(make_int4(i, j0, (int)(Dsw.size() / 4), 0));
+      for (int ks = 0; ks < ksteps; ks++)
+        for (int l = 0; l < 64; l++)
+          for (int t = 0; t < 4; t++) {
+            const int k = 4 * ks + (l >> 4), row = std::min(j0 + 16 * t + (l & 15), n - 1);
+            Dsw.push_back(k <= n ? h.D[(size_t)row * (n + 1) + k] : 0.0);
+          }
+    }
+  }
 
   // launch order of a whole evaluation: aerodynamic phases (the long chain, 4x + sweeps) before NoAir
   // ones, free attitude before held -- the same weights gelato_amd/parallel.py balances shards with
-  std::vector<int2> sorted_chunks = chunks;
-  auto weight = [&](const int2& c) { return (p->ph[c.x].air ? 10.0 : 1.5) + (p->ph[c.x].hold ? 0.0 : 0.5); };
-  std::stable_sort(sorted_chunks.begin(), sorted_chunks.end(), [&](const int2& a, const int2& b) { return weight(a) > weight(b); });
+  std::vector<int4> sorted_chunks = chunks;
+  auto weight = [&](const int4& c) { return (p->ph[c.x].air ? 10.0 : 1.5) + (p->ph[c.x].hold ? 0.0 : 0.5); };
+  std::stable_sort(sorted_chunks.begin(), sorted_chunks.end(), [&](const int4& a, const int4& b) { return weight(a) > weight(b); });
 
   int rc = GEL_OK;
-  if ((rc = upload(&p->d_chunks, chunks)) || (rc = upload(&p->d_chunks_sorted, sorted_chunks)) || (rc = upload(&p->d_phases, dph)) || (rc = upload(&p->d_node_phase, node_phase)) || (rc = upload(&p->d_Dt, Dt)) ||
+  if ((rc = upload(&p->d_chunks, chunks)) || (rc = upload(&p->d_chunks_sorted, sorted_chunks)) || (rc = upload(&p->d_Dsw, Dsw)) || (rc = upload(&p->d_phases, dph)) || (rc = upload(&p->d_node_phase, node_phase)) || (rc = upload(&p->d_Dt, Dt)) ||
       (rc = upload(&p->d_tau, tau)) || (rc = upload(&p->d_tables, tables)) || (rc = upload(&p->d_cval, p->cval)) ||
       (rc = upload(&p->d_src, p->src))) {
     gel_problem_destroy(p);
@@ -640,7 +658,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   dv.S = S; dv.N = N; dv.M = M; dv.nvars = dm.num_vars; dv.Kw = d->wind_rows; dv.Kc = d->ca_rows; dv.V = V;
   dv.phases = p->d_phases; dv.node_phase = p->d_node_phase; dv.Dt = p->d_Dt; dv.tau = p->d_tau; dv.tables = p->d_tables;
   dv.flag = p->d_flag;
-  dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks_sorted;
+  dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks_sorted; dv.Dsw = p->d_Dsw;
   dv.park_off = (int32_t)((tables.size() + 1) / 2 * 2);
   {
     // D.X path: the matrix pipe runs beside the fp64 VALU pipe that bounds this kernel, so the MFMA form
@@ -660,7 +678,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->device == GEL_DEVICE_NONE) { delete p; return GEL_OK; }
   hipSetDevice(p->device);
   if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
-  hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
+  hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dsw); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag);
   for (int k = 0; k < 3; k++) hipFree(p->d_aero_rows[k]);
   free_slots(p);
