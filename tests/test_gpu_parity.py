@@ -682,3 +682,43 @@ def test_all_atmosphere_layers_and_both_hemispheres():
     oracle = _setup()
     h = np.array([oracle.ecef2geodetic(*(pos[i] * up))[2] for i in (1, n)])
     assert h[0] < 0.0 and h[1] > 6.0e5
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_problem_structures_values(seed):
+    """Random phase structures (see tests/test_pattern_and_parallel_cpu.py) at random physical states: residuals
+    and every Jacobian value against the oracle.  Small launches take the split latency form of the kernel, so
+    this also pins that form on ragged, multi-chunk and mixed-type problems."""
+    prob, _, _ = named_problem("example")
+    rng = np.random.default_rng(2000 + seed)
+    S = int(rng.integers(1, 9))
+    prob = dict(prob)
+    nn = rng.integers(2, 24, S)
+    if seed % 2 == 0:
+        nn[rng.integers(0, S)] = int(rng.integers(64, 100))
+    prob["num_nodes"] = nn.astype(np.int32)
+    on = rng.integers(0, 2, S)
+    prob["engine_on"] = on.astype(np.int32)
+    prob["thrust"] = np.where(on, rng.uniform(1e4, 5e5, S), 0.0)
+    prob["massflow"] = np.where(on, rng.uniform(1.0, 150.0, S), 0.0)
+    prob["reference_area"] = np.where(rng.integers(0, 2, S), rng.uniform(0.5, 3.0, S), 0.0)
+    prob["nozzle_area"] = np.where(on, rng.uniform(0.0, 1.0, S), 0.0)
+    prob["attitude_hold"] = rng.integers(0, 2, S).astype(np.int32)
+    E, P = make_pair(prob)
+    N, M = E.N, E.M
+    up = prob["units"][1]
+    lat = rng.uniform(-1.0, 1.0, M)                            # |lat| <= 57 deg: see DESIGN.md on FD conditioning
+    lon = rng.uniform(-np.pi, np.pi, M)
+    R = (6378137.0 - 21385.0 * np.sin(lat) ** 2 + rng.uniform(0.0, 150e3, M)) / up
+    pos = np.column_stack([R * np.cos(lat) * np.cos(lon), R * np.cos(lat) * np.sin(lon), R * np.sin(lat)])
+    vel = rng.standard_normal((M, 3)) * rng.uniform(0.05, 4.0, (M, 1))
+    quat = rng.standard_normal((M, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([0.2 + rng.random(M), pos.ravel(), vel.ravel(), quat.ravel(), rng.standard_normal(2 * N),
+                        np.sort(rng.random(S + 1))])
+    res1, vals1 = check_against_oracle(E, P, x, "random-%d" % seed)
+    # the same vector inside a large batch goes through the throughput form of the kernel: same bits
+    B = 200
+    X = np.tile(x, (B, 1))
+    res, jv, rc = E.eval_batch(X)
+    assert rc == 0 and np.array_equal(res[B - 1], res1) and np.array_equal(E.expand(jv[B - 1]), vals1)

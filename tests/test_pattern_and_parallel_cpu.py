@@ -206,3 +206,54 @@ def test_world_size_2_gloo(tmp_path):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "WORKER_OK %d" % r in out, out[-3000:]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_problem_structures_pattern_and_constants(seed):
+    """Random phase structures (1..8 phases, 2..70 nodes, every combination of aerodynamic / NoAir, engine on / off,
+    free / held attitude): sparsity pattern, block shapes and every constant entry of the host-only engine equal the
+    oracle's, and the compact map covers exactly the entries that move with x."""
+    rng = np.random.default_rng(1000 + seed)
+    S = int(rng.integers(1, 9))
+    g = load_golden("g6_example.npz")
+    prob = dict(problem_from_golden(g))
+    nn = rng.integers(2, 24, S)
+    if seed % 4 == 0:
+        nn[rng.integers(0, S)] = int(rng.integers(64, 71))       # a multi-chunk phase with a ragged tail
+    prob["num_nodes"] = nn.astype(np.int32)
+    on = rng.integers(0, 2, S)
+    prob["engine_on"] = on.astype(np.int32)
+    prob["thrust"] = np.where(on, rng.uniform(1e4, 5e5, S), 0.0)
+    prob["massflow"] = np.where(on, rng.uniform(1.0, 150.0, S), 0.0)
+    prob["reference_area"] = np.where(rng.integers(0, 2, S), rng.uniform(0.5, 3.0, S), 0.0)
+    prob["nozzle_area"] = np.where(on, rng.uniform(0.0, 1.0, S), 0.0)
+    prob["attitude_hold"] = rng.integers(0, 2, S).astype(np.int32)
+    P = oracle.Problem(prob)
+    E = host_engine(prob, [P.D(i) for i in range(S)], [P.tau(i) for i in range(S)])
+    N = int(nn.sum())
+    M = N + S
+    assert (E.N, E.M, E.nvars) == (N, M, 11 * M + 2 * N + S + 1)
+    x1 = rng.random(E.nvars) + 0.5
+    x2 = rng.random(E.nvars) + 0.5
+    for x in (x1, x2):                                          # keep positions above ground, times increasing
+        x[M:4 * M] = 0.6 + 0.05 * x[M:4 * M]
+        x[-(S + 1):] = np.sort(x[-(S + 1):])
+    pat, cv, vidx = E.pattern(), E.const_values(), E.var_index()
+    is_var = np.zeros(E.total_nnz, dtype=bool)
+    is_var[vidx] = True
+    b = 0
+    for grp in oracle.GROUPS:
+        J1, J2 = P.jacobian(grp, x1), P.jacobian(grp, x2)
+        for var in oracle.BLOCK_VARS[grp]:
+            r, c = pat[b]
+            ro, co, v1 = J1[var]["coo"]
+            v2 = J2[var]["coo"][2]
+            assert np.array_equal(r, ro) and np.array_equal(c, co), (grp, var)
+            assert E.block_shape[b] == J1[var]["shape"]
+            lo, hi = E.block_off[b], E.block_off[b + 1]
+            m = is_var[lo:hi]
+            assert np.array_equal(cv[lo:hi][~m], v1[~m]) and np.array_equal(v1[~m], v2[~m]), (grp, var)  # constants
+            # an entry outside the compact map never moves with x (the converse need not hold: an x-dependent
+            # entry may be 0 at both points, e.g. d/dquaternion of a zero-thrust phase)
+            b += 1
+    assert b == 13 and len(np.unique(vidx)) == E.V
