@@ -229,8 +229,8 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         for (int c = 0; c < 4; c++) {
           const double rh = fq[c] * (tf - to) * ut / 2.0;
           const double cq = lq[c] - rh;
-          __builtin_nontemporal_store(cq, &rb[7 * N + 4 * g + c]);
-          chk += cq;
+          rb[7 * N + 4 * g + c] = cq;  // ordinary store: the interleaved residual rows are partial lines that
+          chk += cq;                   // L2 merges; written non-temporally they cost 4 % more HBM writes (PMC)
         }
       }
       if (JAC) {
@@ -268,20 +268,20 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
       } else {
         cm = me - m0;
       }
-      __builtin_nontemporal_store(cm, &rb[g]);
+      rb[g] = cm;
       chk += cm;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const double rh = ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
         const double cp = lr[c] - rh;
-        __builtin_nontemporal_store(cp, &rb[N + 3 * g + c]);
+        rb[N + 3 * g + c] = cp;
         chk += cp;
       }
       if (ph.hold) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const double cq = q[c] - q0[c];
-          __builtin_nontemporal_store(cq, &rb[7 * N + 4 * g + c]);
+          rb[7 * N + 4 * g + c] = cq;
           chk += cq;
         }
       }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     for (int c = 0; c < 3; c++) {
       const double rh = fc[c] * (tf - to) * ut / 2.0;
       const double cv = PARK(PK_LV0 + c) - rh;
-      __builtin_nontemporal_store(cv, &rb[4 * N + 3 * g + c]);
+      rb[4 * N + 3 * g + c] = cv;
       chk += cv;
     }
   }
