@@ -97,7 +97,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="decision vectors per GPU per step")
+    ap.add_argument("--batch", type=int, default=16384, help="decision vectors per GPU per step (16384 x 6 = 24 rounds of "
+                    "the 4096 wavefronts the chip holds: at 4096 vectors the ramp and tail of a launch cost a quarter)")
     ap.add_argument("--workload", default="mixed-6x64", help="mixed-6x64 | dense-6x64 | 3x32 | stress-12x128 | example")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "phase-shard"],
                     help="replicas: B vectors per GPU, no collective (weak scaling, the headline). phase-shard: ONE "
