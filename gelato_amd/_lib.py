@@ -56,6 +56,7 @@ SIGNATURES = {
     "gel_problem_D": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "gel_problem_tau": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "gel_pattern": (C.c_int, [C.c_void_p, C.c_int32, _ip, _ip]),
+    "gel_pattern_all": (C.c_int, [C.c_void_p, _ip, _ip]),
     "gel_const_values": (C.c_int, [C.c_void_p, _dp]),
     "gel_var_index": (C.c_int, [C.c_void_p, _lp]),
     "gel_eval_residual": (C.c_int, [C.c_void_p, _dp, _dp]),

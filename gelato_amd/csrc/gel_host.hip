@@ -718,6 +718,15 @@ int gel_pattern(const gel_problem* p, int32_t block, int32_t* rows, int32_t* col
   return GEL_OK;
 }
 
+int gel_pattern_all(const gel_problem* p, int32_t* rows_full, int32_t* cols_full) {
+  if (!p || !rows_full || !cols_full) return fail(GEL_ERR_ARG, "null argument");
+  walk_pattern(*p, [&](int blk, int64_t k, int32_t r, int32_t c, int, double, int64_t) {
+    rows_full[p->block_off[blk] + k] = r;
+    cols_full[p->block_off[blk] + k] = c;
+  });
+  return GEL_OK;
+}
+
 int gel_const_values(const gel_problem* p, double* vals_full) {
   if (!p || !vals_full) return fail(GEL_ERR_ARG, "null argument");
   std::memcpy(vals_full, p->cval.data(), p->cval.size() * 8);

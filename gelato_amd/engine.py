@@ -130,13 +130,11 @@ class Engine:
     def pattern(self):
         """[(rows int32, cols int32)] for the 13 blocks (fixed; depends only on the static problem)."""
         if self._pattern is None:
-            pat = []
-            for b in range(13):
-                r = np.zeros(self.block_nnz[b], dtype=np.int32)
-                c = np.zeros(self.block_nnz[b], dtype=np.int32)
-                check(lib().gel_pattern(self._h, b, r.ctypes.data_as(_ip), c.ctypes.data_as(_ip)))
-                pat.append((r, c))
-            self._pattern = pat
+            rows = np.zeros(self.total_nnz, dtype=np.int32)
+            cols = np.zeros(self.total_nnz, dtype=np.int32)
+            check(lib().gel_pattern_all(self._h, rows.ctypes.data_as(_ip), cols.ctypes.data_as(_ip)))   # one pass
+            self._pattern = [(rows[self.block_off[b]:self.block_off[b + 1]].copy(),
+                              cols[self.block_off[b]:self.block_off[b + 1]].copy()) for b in range(13)]
         return self._pattern
 
     def const_values(self):
