@@ -156,6 +156,12 @@ struct gel_problem {
   double *d_x = nullptr, *d_res = nullptr, *d_jv = nullptr;
   double *h_x = nullptr, *h_res = nullptr, *h_jv = nullptr;  // pinned
   int32_t* h_flag = nullptr;                                  // pinned
+  // gel_jac_fd working set: kept between calls; the residuals of all num_vars + 1 perturbed vectors are
+  // re-used while x stays the same (the four groups are asked for one after the other)
+  double *jfd_x = nullptr, *jfd_Xp = nullptr, *jfd_res = nullptr, *jfd_J = nullptr;
+  size_t jfd_J_cap = 0;                                       // doubles
+  std::vector<double> jfd_last_x;                             // empty = nothing cached
+  int jfd_status = GEL_OK;
   double* h_aero = nullptr;                                   // pinned outputs of small gel_eval_aero calls
   size_t h_aero_cap = 0;                                      // doubles
   // large host batches (gel_eval_batch): two staging slots of kPipeEvals decision vectors each, every
@@ -688,6 +694,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->h_jv) hipHostFree(p->h_jv);
   if (p->h_flag) hipHostFree(p->h_flag);
   if (p->h_aero) hipHostFree(p->h_aero);
+  hipFree(p->jfd_x); hipFree(p->jfd_Xp); hipFree(p->jfd_res); hipFree(p->jfd_J);
   delete p;
   return GEL_OK;
 }
@@ -833,31 +840,53 @@ int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) {
   if (!p || !x || !J || group < 0 || group >= GEL_NUM_GROUPS) return fail(GEL_ERR_ARG, "bad argument");
   NEED_DEVICE(p);
   HIPCHK(hipSetDevice(p->device));
-  const int nv = p->dims.num_vars, nres = 11 * p->dims.N, nrows = p->dims.num_rows[group];
+  int rc = ensure_slots(p);  // the two pinned staging slots also carry J back to the caller
+  if (rc) return rc;
+  const size_t nv = (size_t)p->dims.num_vars, nres = (size_t)11 * p->dims.N, nrows = (size_t)p->dims.num_rows[group];
   const int roff = (group == 0) ? 0 : (group == 1) ? p->dims.N : (group == 2) ? 4 * p->dims.N : 7 * p->dims.N;
-  double *d_x = nullptr, *d_Xp = nullptr, *d_res = nullptr, *d_J = nullptr;
-  int rc = GEL_OK;
-  auto cleanup = [&]() { hipFree(d_x); hipFree(d_Xp); hipFree(d_res); hipFree(d_J); };
-#define HIPCHK2(expr)                                                                                 \
-  do {                                                                                                \
-    hipError_t _e = (expr);                                                                           \
-    if (_e != hipSuccess) { cleanup(); return fail(GEL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } \
-  } while (0)
-  HIPCHK2(hipMalloc((void**)&d_x, (size_t)nv * 8));
-  HIPCHK2(hipMalloc((void**)&d_Xp, (size_t)(nv + 1) * nv * 8));
-  HIPCHK2(hipMalloc((void**)&d_res, (size_t)(nv + 1) * nres * 8));
-  HIPCHK2(hipMalloc((void**)&d_J, (size_t)nrows * nv * 8));
-  HIPCHK2(hipMemcpyAsync(d_x, x, (size_t)nv * 8, hipMemcpyHostToDevice, p->stream));
-  HIPCHK2(gel::launch_perturb(nv, p->dx, d_x, d_Xp, p->stream));
-  HIPCHK2(gel::launch_eval(p->dev, nv + 1, d_Xp, d_res, nullptr, p->stream));
-  HIPCHK2(gel::launch_quotient(nv, nres, roff, nrows, p->dx, d_res, d_J, p->stream));
-  HIPCHK2(hipMemcpyAsync(J, d_J, (size_t)nrows * nv * 8, hipMemcpyDeviceToHost, p->stream));
-  HIPCHK2(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
-  HIPCHK2(hipStreamSynchronize(p->stream));
-  if (*p->h_flag) { hipMemsetAsync(p->d_flag, 0, 4, p->stream); rc = GEL_NONFINITE; }
-  cleanup();
-#undef HIPCHK2
-  return rc;
+  if (!p->jfd_x) {
+    HIPCHK(hipMalloc((void**)&p->jfd_x, nv * 8));
+    HIPCHK(hipMalloc((void**)&p->jfd_Xp, (nv + 1) * nv * 8));
+    HIPCHK(hipMalloc((void**)&p->jfd_res, (nv + 1) * nres * 8));
+  }
+  if (p->jfd_J_cap < nrows * nv) {
+    hipFree(p->jfd_J);
+    p->jfd_J = nullptr; p->jfd_J_cap = 0;
+    HIPCHK(hipMalloc((void**)&p->jfd_J, nrows * nv * 8));
+    p->jfd_J_cap = nrows * nv;
+  }
+  // one residual evaluation per column, all columns in one launch -- unless the same x was just differenced
+  if (p->jfd_last_x.size() != nv || std::memcmp(p->jfd_last_x.data(), x, nv * 8) != 0) {
+    p->jfd_last_x.clear();
+    HIPCHK(hipMemcpyAsync(p->jfd_x, x, nv * 8, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(gel::launch_perturb((int)nv, p->dx, p->jfd_x, p->jfd_Xp, p->stream));
+    HIPCHK(gel::launch_eval(p->dev, (int)nv + 1, p->jfd_Xp, p->jfd_res, nullptr, p->stream));
+    HIPCHK(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->jfd_status = GEL_OK;
+    if (*p->h_flag) { *p->h_flag = 0; HIPCHK(hipMemsetAsync(p->d_flag, 0, 4, p->stream)); p->jfd_status = GEL_NONFINITE; }
+    p->jfd_last_x.assign(x, x + nv);
+  }
+  HIPCHK(gel::launch_quotient((int)nv, (int)nres, roff, (int)nrows, p->dx, p->jfd_res, p->jfd_J, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  // J -> caller through the two pinned slots: D2H of piece i+1 overlaps the host copy of piece i
+  const size_t total = nrows * nv, piece = (size_t)p->pipe_evals * (size_t)std::max<int64_t>(p->dims.num_var_entries, 1);
+  size_t pend_off[2] = {0, 0}, pend_n[2] = {0, 0};
+  for (size_t off = 0, i = 0; off < total || pend_n[0] || pend_n[1]; i++) {
+    gel_problem::Slot& sl = p->slot[i & 1];
+    if (pend_n[i & 1]) {
+      HIPCHK(hipStreamSynchronize(sl.stream));
+      par_copy(J + pend_off[i & 1], sl.h_jv, pend_n[i & 1] * 8);
+      pend_n[i & 1] = 0;
+    }
+    if (off < total) {
+      const size_t n = std::min(piece, total - off);
+      HIPCHK(hipMemcpyAsync(sl.h_jv, p->jfd_J + off, n * 8, hipMemcpyDeviceToHost, sl.stream));
+      pend_off[i & 1] = off; pend_n[i & 1] = n;
+      off += n;
+    }
+  }
+  return p->jfd_status;
 }
 
 // --------------------------- RHS / point hooks ---------------------------
