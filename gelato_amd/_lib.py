@@ -67,6 +67,8 @@ SIGNATURES = {
     "gel_expand_full_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gel_eval_shard_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_void_p]),
+    "gel_eval_shard_units_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_void_p]),
     "gel_num_chunks": (C.c_int, [C.c_void_p, _ip]),
     "gel_chunk_phase": (C.c_int, [C.c_void_p, _ip]),
     "gel_sync": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -55,6 +55,7 @@ struct ProblemDev {
   int32_t nchunks;           // sum over phases of ceil(n/64): wavefront work items per eval
   int32_t use_mfma;          // D.X on v_mfma_f64_16x16x4_f64 instead of VALU FMAs
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
+  int32_t unit0, nunits;     // split form only: first unit and number of units (unit = 4 * work item + part)
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)
   const int4* chunks;        // [nchunks] {phase, first node of the chunk, offset of its MFMA-ordered D in Dsw / 4, 0}:
                              // dearest phase type first for a whole launch, the natural (phase) order for a

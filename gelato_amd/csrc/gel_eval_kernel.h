@@ -58,17 +58,19 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   lds_double* park = wave_lds + lane;
 #define PARK(slot) park[(slot) * 64]
 
-  long long item = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
-  const int part = SPLIT ? (int)(item & 3) : 0;  // wave-uniform
-  if (SPLIT) item >>= 2;
-  if (item >= (long long)B * P.nchunks) return;
+  const long long item = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
+  if (item >= (long long)B * (SPLIT ? P.nunits : P.nchunks)) return;
   // work-item major: all B vectors of one (phase, chunk) are neighbours, so the four wavefronts of a
   // workgroup cost the same (its LDS is only released when the slowest ends), and the list is ordered
   // dearest phase type first, so the tail of the launch drains with cheap wavefronts (measured -4 % on
   // the mixed vehicle at B = 4096, -6..9 % at B = 2048)
-  const int ci = (int)(item / B);
-  const int b = (int)(item - (long long)ci * B);
-  const int4 ck = P.chunks[P.chunk0 + ci];
+  // SPLIT: the list is walked in units = (work item, part), unit id = 4 * item + part, again with all B vectors
+  // of a unit next to each other; P.unit0 / P.nunits select a range of units (unit-sharded launches)
+  const int q = (int)(item / B);
+  const int b = (int)(item - (long long)q * B);
+  const int ci = SPLIT ? ((P.unit0 + q) >> 2) : q;
+  const int part = SPLIT ? ((P.unit0 + q) & 3) : 0;  // wave-uniform
+  const int4 ck = P.chunks[(SPLIT ? 0 : P.chunk0) + ci];
   const int sec = __builtin_amdgcn_readfirstlane(ck.x);
   const int j0 = __builtin_amdgcn_readfirstlane(ck.y);
   const int dsw = __builtin_amdgcn_readfirstlane(ck.z);  // first gel_double4 of this work item in Dsw

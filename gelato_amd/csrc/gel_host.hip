@@ -801,6 +801,23 @@ int gel_eval_shard_device(gel_problem* p, int32_t B, const double* d_x, double* 
   return GEL_OK;
 }
 
+int gel_eval_shard_units_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar,
+                                int32_t unit_begin, int32_t unit_count, void* stream) {
+  if (!p || !d_x || B < 1 || !d_jvar) return fail(GEL_ERR_ARG, "bad argument (the unit form always writes Jacobian values)");
+  NEED_DEVICE(p);
+  const int32_t total = 4 * (int32_t)p->chunk_phase.size();
+  if (unit_begin < 0 || unit_count < 0 || unit_begin + unit_count > total)
+    return fail(GEL_ERR_ARG, "unit range out of bounds");
+  if (unit_count == 0) return GEL_OK;
+  gel::ProblemDev dv = p->dev;
+  dv.chunks = p->d_chunks;  // unit ids refer to the phase-ordered list
+  dv.chunk0 = 0;
+  dv.unit0 = unit_begin;
+  dv.nunits = unit_count;
+  HIPCHK(gel::launch_eval(dv, B, d_x, d_res, d_jvar, stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
 int gel_num_chunks(const gel_problem* p, int32_t* nchunks) {
   if (!p || !nchunks) return fail(GEL_ERR_ARG, "null argument");
   *nchunks = (int32_t)p->chunk_phase.size();

@@ -363,12 +363,16 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
   // D.X on the matrix pipe only when residual rows are requested at all (d_res) and the problem asks for it
   const bool mfma = P.use_mfma && d_res;
   // a handful of vectors cannot fill 1024 SIMDs: trade recomputation of the centre for a shorter serial chain
-  if (d_jvar && waves * 4 <= kSplitMaxWaves) {
-    const unsigned g4 = (unsigned)((waves * 4 * 64 + kBlock - 1) / kBlock);
+  if (d_jvar && (P.nunits > 0 || waves * 4 <= kSplitMaxWaves)) {
+    // P.nunits > 0: the caller asked for a range of units (unit-sharded launch); else the whole list, split
+    ProblemDev Q = P;
+    if (Q.nunits <= 0) { Q.unit0 = 4 * P.chunk0; Q.nunits = 4 * P.nchunks; }
+    const long long w4 = (long long)B * Q.nunits;
+    const unsigned g4 = (unsigned)((w4 * 64 + kBlock - 1) / kBlock);
     if (mfma)
-      hipLaunchKernelGGL((eval_kernel<true, true, true>), dim3(g4), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+      hipLaunchKernelGGL((eval_kernel<true, true, true>), dim3(g4), dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
     else
-      hipLaunchKernelGGL((eval_kernel<true, false, true>), dim3(g4), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+      hipLaunchKernelGGL((eval_kernel<true, false, true>), dim3(g4), dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
     return hipGetLastError();
   }
   if (d_jvar && mfma)

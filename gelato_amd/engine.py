@@ -229,6 +229,11 @@ class Engine:
         check(lib().gel_eval_shard_device(self._h, B, d_x, d_res or None, d_jvar or None, int(chunk_begin),
                                           int(chunk_count), stream or None))
 
+    def eval_shard_units_device(self, B, d_x, d_res, d_jvar, unit_begin, unit_count, stream=0):
+        """unit = 4 * work_item + part (part 0: all but the three position sweeps; 1..3: one position sweep)."""
+        check(lib().gel_eval_shard_units_device(self._h, B, d_x, d_res or None, d_jvar, int(unit_begin),
+                                                int(unit_count), stream or None))
+
     def jac_fd(self, group, x):
         gi = GROUPS.index(group)
         x = _f64(x)

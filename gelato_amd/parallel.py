@@ -36,6 +36,23 @@ def chunk_costs(engine_or_desc):
     return cost
 
 
+def unit_costs(engine_or_desc):
+    """Relative cost of every unit = (work item, part) in unit-id order 4 * item + part: part 0 is the centre
+    evaluation with the light sweeps, parts 1..3 one position sweep (plus a centre evaluation) each; phases
+    without aerodynamics have empty parts 1..3 (gel_eval_shard_units_device)."""
+    if isinstance(engine_or_desc, dict):
+        ph, area, hold = engine_or_desc["chunk_phase"], engine_or_desc["reference_area"], engine_or_desc["attitude_hold"]
+    else:
+        e = engine_or_desc
+        ph, area, hold = e.chunk_phase(), e.prob["reference_area"], e.prob["attitude_hold"]
+    air = np.asarray(area)[ph] != 0.0
+    free = np.asarray(hold)[ph] == 0
+    cost = np.zeros((len(ph), 4))
+    cost[:, 0] = np.where(air, 4.5, 1.5) + np.where(free, 0.5, 0.0)
+    cost[:, 1:] = np.where(air, 4.0, 0.0)[:, None]
+    return cost.ravel()
+
+
 def shard_chunks(costs, world):
     """Contiguous partition of the work items into `world` ranges with balanced total cost.
     -> list of (begin, count); ranges are disjoint, ordered, and cover every item."""

@@ -486,6 +486,47 @@ def test_phase_shards_compose_to_the_full_evaluation():
         assert torch.equal(tot_r, ref_r) and torch.equal(tot_j, ref_j)
 
 
+@pytest.mark.parametrize("name,B", [("mixed-6x64", 3), ("example", 1), ("mixed-6x64", 300)])
+def test_unit_shards_compose_to_the_full_evaluation(name, B):
+    """BASELINE.json configs[3]: phases AND Jacobian columns dealt to GPUs.  unit = 4 * work item + part; every
+    unit range writes only its own entries, and any disjoint cover sums to the unsharded result, bit for bit
+    (B = 300 compares the unit form with the throughput form of the kernel)."""
+    import torch
+    from gelato_amd import parallel, problem
+    prob, x0, _ = named_problem(name)
+    E, _ = make_pair(prob)
+    X = problem.synthetic_batch(x0, E.M, min(B, 16))
+    X = np.tile(X, (B // len(X) + 1, 1))[:B]
+    dev = torch.device("cuda:0")
+    dX = torch.from_numpy(X).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    ref_r = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    ref_j = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    E.eval_batch_device(B, dX.data_ptr(), ref_r.data_ptr(), ref_j.data_ptr(), s)
+    assert E.sync(s) == 0
+    costs = parallel.unit_costs(E)
+    assert len(costs) == 4 * E.num_chunks()
+    for world in (1, 3, 8, len(costs)):
+        ranges = parallel.shard_chunks(costs, world)
+        assert sum(c for _, c in ranges) == len(costs)
+        if name == "mixed-6x64" and world == 8:
+            assert all(c > 0 for _, c in ranges)              # 8 GPUs all get work on the 6-phase mesh
+        tot_r = torch.zeros_like(ref_r)
+        tot_j = torch.zeros_like(ref_j)
+        for rank in range(world):
+            r = torch.zeros_like(ref_r)
+            jv = torch.zeros_like(ref_j)
+            b, c = ranges[rank]
+            E.eval_shard_units_device(B, dX.data_ptr(), r.data_ptr(), jv.data_ptr(), b, c, s)
+            assert E.sync(s) == 0
+            assert torch.all((tot_r == 0) | (r == 0)) and torch.all((tot_j == 0) | (jv == 0))   # disjoint owners
+            tot_r += r
+            tot_j += jv
+        assert torch.equal(tot_r, ref_r) and torch.equal(tot_j, ref_j), (name, B, world)
+    with pytest.raises(Exception):
+        E.eval_shard_units_device(B, dX.data_ptr(), 0, ref_j.data_ptr(), 0, len(costs) + 1, s)
+
+
 # --------------------------------------------------------------------------
 # D.X on the matrix pipe (v_mfma_f64_16x16x4_f64) vs wavefront dot-products (VALU)
 # --------------------------------------------------------------------------

@@ -117,6 +117,16 @@ def test_replica_and_chunk_partitions():
         assert len(sh) == world and sh[0][0] == 0 and sum(c for _, c in sh) == len(costs)
         assert all(sh[i][0] + sh[i][1] == sh[i + 1][0] for i in range(world - 1))
     assert parallel.shard_chunks(costs, 2) == [(0, 3), (3, 3)]
+    # units = (work item, part): a 6-phase mesh gives 8 ranks something to do each
+    from gelato_amd import con_dynamics, problem
+    pdict, unitdict, _, _ = problem.make_problem("mixed-6x64")
+    E = host_engine(con_dynamics.problem_arrays(pdict, unitdict))
+    uc = parallel.unit_costs(E)
+    assert len(uc) == 24 and uc.reshape(6, 4)[5, 1:].sum() == 0.0     # the NoAir phase has no position-sweep units
+    sh = parallel.shard_chunks(uc, 8)
+    assert all(c > 0 for _, c in sh) and sum(c for _, c in sh) == 24
+    loads = [uc[b:b + c].sum() for b, c in sh]
+    assert max(loads) <= 1.6 * (uc.sum() / 8)
 
 
 WORKER = r"""
