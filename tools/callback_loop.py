@@ -2,7 +2,6 @@
 """The drop-in figure: wall time of objfunc / sens through the reference-named Python functions
 (gelato_amd.con_dynamics + driver.make_callbacks), per call, on the GPU box."""
 import json, os, sys
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gelato_amd import driver, problem
 for name in sys.argv[1:] or ["example", "mixed-6x64", "dense-6x64"]:
