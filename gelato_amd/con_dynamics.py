@@ -93,8 +93,13 @@ def last_status(pdict):
     return 0 if st is None else st.status
 
 
-def _copy_jac(j):
-    # values are copied so that the caller may keep them across calls, like the reference's fresh arrays
+def _copy_jac(j, pdict=None):
+    # values are copied so that the caller may keep them across calls, like the reference's fresh arrays.
+    # pdict["gelato_amd_share_values"] = True hands out the engine's own value arrays instead (updated in place
+    # by the next evaluation): pyoptsparse copies what it is given into its own matrices straight away, and the
+    # fresh copies of 607 k values are half of a sens() call at 6 x 64.
+    if pdict is not None and pdict.get("gelato_amd_share_values"):
+        return {var: {"coo": [blk["coo"][0], blk["coo"][1], blk["coo"][2]], "shape": blk["shape"]} for var, blk in j.items()}
     return {var: {"coo": [blk["coo"][0], blk["coo"][1], blk["coo"][2].copy()], "shape": blk["shape"]}
             for var, blk in j.items()}
 
@@ -106,7 +111,7 @@ def equality_dynamics_mass(xdict, pdict, unitdict, condition):
 
 def equality_jac_dynamics_mass(xdict, pdict, unitdict, condition):
     """Jacobian of equality_dynamics_mass."""
-    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["mass"])
+    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["mass"], pdict)
 
 
 def equality_dynamics_position(xdict, pdict, unitdict, condition):
@@ -116,7 +121,7 @@ def equality_dynamics_position(xdict, pdict, unitdict, condition):
 
 def equality_jac_dynamics_position(xdict, pdict, unitdict, condition):
     """Jacobian of equality_dynamics_position."""
-    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["pos"])
+    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["pos"], pdict)
 
 
 def equality_dynamics_velocity(xdict, pdict, unitdict, condition):
@@ -126,7 +131,7 @@ def equality_dynamics_velocity(xdict, pdict, unitdict, condition):
 
 def equality_jac_dynamics_velocity(xdict, pdict, unitdict, condition):
     """Jacobian of equality_dynamics_velocity."""
-    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["vel"])
+    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["vel"], pdict)
 
 
 def equality_dynamics_quaternion(xdict, pdict, unitdict, condition):
@@ -136,7 +141,7 @@ def equality_dynamics_quaternion(xdict, pdict, unitdict, condition):
 
 def equality_jac_dynamics_quaternion(xdict, pdict, unitdict, condition):
     """Jacobian of equality_dynamics_quaternion."""
-    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["quat"])
+    return _copy_jac(_state(pdict, unitdict).jacobians(xdict)["quat"], pdict)
 
 
 RESIDUAL_FUNCTIONS = {

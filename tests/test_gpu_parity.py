@@ -411,6 +411,14 @@ def test_callback_surface_like_reference():
     assert all(np.array_equal(xd[k], keep[k]) for k in xd)
     stats = driver.mock_optimizer_loop(objfunc, sens, xd, iterations=3)
     assert stats["userObjCalls"] == 3 and stats["fails"] == 0
+    # fresh value arrays by default (like the reference); shared ones on request
+    a1 = con_dynamics.equality_jac_dynamics_velocity(xd, pdict, unitdict, condition)["velocity"]["coo"][2]
+    a2 = con_dynamics.equality_jac_dynamics_velocity(xd, pdict, unitdict, condition)["velocity"]["coo"][2]
+    assert a1 is not a2 and not np.shares_memory(a1, a2) and np.array_equal(a1, a2)
+    pdict["gelato_amd_share_values"] = True
+    b1 = con_dynamics.equality_jac_dynamics_velocity(xd, pdict, unitdict, condition)["velocity"]["coo"][2]
+    b2 = con_dynamics.equality_jac_dynamics_velocity(xd, pdict, unitdict, condition)["velocity"]["coo"][2]
+    assert np.shares_memory(b1, b2) and np.array_equal(b1, a1)
 
 
 # --------------------------------------------------------------------------
