@@ -1084,8 +1084,8 @@ int gel_eval_aero(gel_problem* p, int32_t kind, int32_t B, const double* x, doub
 }
 
 int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux, int32_t aux_rows, double* out) {
-  static const int nin[8] = {1, 3, 3, 6, 7, 1, 1, 2}, nout[8] = {5, 3, 3, 3, 3, 3, 1, 4};
-  if (kind < 0 || kind > 7 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
+  static const int nin[9] = {1, 3, 3, 6, 7, 1, 1, 2, 2}, nout[9] = {5, 3, 3, 3, 3, 3, 1, 4, 6};
+  if (kind < 0 || kind > 8 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
   if (n == 0) return GEL_OK;
   int rc = need_device();
   if (rc) return rc;

@@ -187,7 +187,7 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       // latitude and altitude exactly as pos_part forms them; angles reported in degrees
       double lat, sl, cl, p;
       geodetic_lat_p(in[3 * i], in[3 * i + 1], in[3 * i + 2], lat, p);
-      sincos(lat, &sl, &cl);
+      fsincos(lat, &sl, &cl);
       const double lon = atan2(in[3 * i + 1], in[3 * i]);
       out[3 * i] = lat * 180.0 / kPi; out[3 * i + 1] = lon * 180.0 / kPi;
       out[3 * i + 2] = geodetic_alt_from(p, sl, cl);
@@ -204,7 +204,7 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       const double r[3] = {a[0], a[1], a[2]};
       double lat, sl, cl, p, w[3];
       geodetic_lat_p(r[0], r[1], r[2], lat, p);
-      sincos(lat, &sl, &cl);
+      fsincos(lat, &sl, &cl);
       const EarthAngle ea = earth_angle(a[3]);
       const double chp = sqrt(0.5 * (1.0 + cl)), shp = 0.5 * sl / chp;
       wind_eci(r, ea, shp, chp, 1.0 / p, a[4], a[5], w);
@@ -229,6 +229,13 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       const double a = in[2 * i], b = in[2 * i + 1];
       out[4 * i] = fsqrt(a); out[4 * i + 1] = sqrt(a); out[4 * i + 2] = fdiv(a, b); out[4 * i + 3] = a / b;
     } break;
+    case 8: {  // the path's sincos / log beside the library's, for the accuracy test
+      double s1, c1, s2, c2;
+      fsincos(in[2 * i], &s1, &c1);
+      sincos(in[2 * i], &s2, &c2);
+      out[6 * i] = s1; out[6 * i + 1] = c1; out[6 * i + 2] = s2; out[6 * i + 3] = c2;
+      out[6 * i + 4] = flog_ratio(in[2 * i + 1]); out[6 * i + 5] = log(in[2 * i + 1]);
+    } break;
     default: break;
   }
 }
@@ -248,7 +255,7 @@ GEL_DEV double aero_value(int kind, const double re[3], const double ve[3], cons
   // air-relative velocity in ECI: wrapper_utils.hpp:93-100 (same chain as the RHS)
   double lat, p, sl, cl;
   geodetic_lat_p(r[0], r[1], r[2], lat, p);
-  sincos(lat, &sl, &cl);
+  fsincos(lat, &sl, &cl);
   const double h = geopotential_altitude(geodetic_alt_from(p, sl, cl));
   double wn, we, w[3];
   wind_ned2(h, tb.wind, tb.Kw, wn, we);

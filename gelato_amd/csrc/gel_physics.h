@@ -80,6 +80,64 @@ GEL_DEV double fdiv(double a, double b) { return a / b; }
 GEL_DEV double frcp(double b) { return fdiv(1.0, b); }
 
 // ---------------------------------------------------------------------------
+// log of the temperature ratio of a lapse layer, and sin/cos of a latitude or of half the Earth angle.
+// tools/microbench/piece_time.hip times every piece of the chain at the kernel's occupancy: ocml's fp64 log
+// costs 164 ns per call and SIMD (4x its exp), sincos 132 ns -- together a quarter of pos_part().
+//
+// flog_ratio: inside a layer's own altitude range the ratio lies in (0.65, 1.3); there
+//   log x = 2 atanh(z), z = (x - 1)/(x + 1)   (x - 1 exact by Sterbenz, |z| <= 1/3 for x in [0.5, 2])
+// as the odd series to z^33 (truncation < 3e-18 relative), ~1.5 ulp, 59 ns.  Anything else (the top layer is
+// extrapolated upwards without bound, src/Air.cpp:56-61) takes the library's log.
+// fsincos: |x| <= 3 pi/4 needs at most one subtraction of pi/2, exact against a two-part pi/2 with the rounding
+// tail carried into the classic k_sin / k_cos minimax kernels on [-pi/4, pi/4]; 1 ulp like the library's
+// (3.0 % vs 3.1 % of results differ from glibc's on 2.6 M arguments), 84 ns.  Larger arguments: the library's.
+// -DGEL_STD_MATH restores log() / sincos() everywhere.
+// ---------------------------------------------------------------------------
+GEL_DEV double flog_ratio(double x) {
+#ifndef GEL_STD_MATH
+  if (x > 0.5 && x < 2.0) {
+    const double z = fdiv(x - 1.0, x + 1.0), w = z * z;
+    double p = 1.0 / 33.0;
+    p = __builtin_fma(p, w, 1.0 / 31.0); p = __builtin_fma(p, w, 1.0 / 29.0); p = __builtin_fma(p, w, 1.0 / 27.0);
+    p = __builtin_fma(p, w, 1.0 / 25.0); p = __builtin_fma(p, w, 1.0 / 23.0); p = __builtin_fma(p, w, 1.0 / 21.0);
+    p = __builtin_fma(p, w, 1.0 / 19.0); p = __builtin_fma(p, w, 1.0 / 17.0); p = __builtin_fma(p, w, 1.0 / 15.0);
+    p = __builtin_fma(p, w, 1.0 / 13.0); p = __builtin_fma(p, w, 1.0 / 11.0); p = __builtin_fma(p, w, 1.0 / 9.0);
+    p = __builtin_fma(p, w, 1.0 / 7.0); p = __builtin_fma(p, w, 1.0 / 5.0); p = __builtin_fma(p, w, 1.0 / 3.0);
+    return __builtin_fma(2.0 * z * w, p, 2.0 * z);
+  }
+#endif
+  return log(x);
+}
+
+GEL_DEV void fsincos(double x, double* sn, double* cs) {
+#ifdef GEL_STD_MATH
+  sincos(x, sn, cs);
+#else
+  const double ax = fabs(x);
+  if (ax > 2.35619449019234492885) { sincos(x, sn, cs); return; }  // 3 pi / 4
+  const double n = (ax > 0.78539816339744830962) ? 1.0 : 0.0;       // pi / 4
+  const double kPio2Hi = 1.57079632679489655800e+00, kPio2Lo = 6.12323399573676603587e-17;
+  const double hi = __builtin_fma(-n, kPio2Hi, ax);                  // exact
+  const double r = __builtin_fma(-n, kPio2Lo, hi);
+  const double y = __builtin_fma(-n, kPio2Lo, hi - r);               // r + y = |x| - n pi/2 to ~1e-33
+  const double z = r * r;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double v = z * r;
+  const double ps = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double ks = r - ((z * (0.5 * y - v * ps) - y) - v * S1);
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double kc = w + (((1.0 - w) - hz) + (z * pc - r * y));
+  const bool q = n != 0.0;        // |x| = n pi/2 + (r + y):  n = 0 -> (ks, kc);  n = 1 -> (kc, -ks); sin is odd in x
+  *sn = copysign(q ? kc : ks, x);
+  *cs = q ? -ks : kc;
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // US Standard Atmosphere 1976.  One layer search serves T, P, rho and a; the
 // reference repeats it five times per node (src/Air.cpp:100-111).
 // ---------------------------------------------------------------------------
@@ -133,13 +191,13 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
   }
   // pressure: src/Air.cpp:90-98
   if (fabs(Lmb) > 1.0e-6) {
-    // (T/Tmb)^(-g0/Lmb/R), exponent from the table.  The base lies in (0.65, 1.3) and the exponent is a
-    // per-layer constant of magnitude <= 35, so exp(y*log(x)) is within ~2 ulp of pow(x, y) here at less
-    // than half its cost (measured 223 VALU instructions for ocml's pow, the largest single item of the chain).
+    // (T/Tmb)^(-g0/Lmb/R), exponent from the table.  Inside a layer the base lies in (0.65, 1.3) and the exponent
+    // is a per-layer constant of magnitude <= 35, so exp(y*log(x)) is within ~|y log x| ulp (<= 10) of pow(x, y)
+    // at a quarter of its cost (piece_time.hip: pow 336 ns, exp(y*log x) 201 ns, with flog_ratio 95 ns).
 #ifdef GEL_AB_POW  // A/B switch for tools/variant.sh only
     o.P = Pb * pow((Tmb + Lmb * (h - Hb)) / Tmb, atm[44 + k]);
 #else
-    o.P = Pb * exp(atm[44 + k] * log(fdiv(Tmb + Lmb * (h - Hb), Tmb)));
+    o.P = Pb * exp(atm[44 + k] * flog_ratio(fdiv(Tmb + Lmb * (h - Hb), Tmb)));
 #endif
   } else {
     o.P = Pb * exp(fdiv(atm[55 + k] * (Hb - h), Tmb));                // g0/R from the table
@@ -174,7 +232,7 @@ GEL_DEV double geodetic_altitude(double x, double y, double z) {
   double lat, p;
   geodetic_lat_p(x, y, z, lat, p);
   double sl, cl;
-  sincos(lat, &sl, &cl);
+  fsincos(lat, &sl, &cl);
   return geodetic_alt_from(p, sl, cl);
 }
 
@@ -183,7 +241,7 @@ GEL_DEV void geodetic_full(double x, double y, double z, double& lat, double& lo
   geodetic_lat_p(x, y, z, lat, p);
   lon = atan2(y, x);
   double sl, cl;
-  sincos(lat, &sl, &cl);
+  fsincos(lat, &sl, &cl);
   const double N = fdiv(kRa, fsqrt(1.0 - kE2 * sl * sl));
   alt = fdiv(p, cl) - N;
 }

@@ -55,7 +55,7 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
 #else
   double lat;
   geodetic_lat_p(r[0], r[1], r[2], lat, p);
-  sincos(lat, &sl, &cl);
+  fsincos(lat, &sl, &cl);
 #endif
   o.inv_p = frcp(p);
   // half-angle pair of the NED quaternion (src/Coordinate.cpp:89-90): cos(lat/2) = sqrt((1+cos lat)/2)
@@ -78,7 +78,7 @@ struct EarthAngle { double c, s, ch, sh; };
 // sincos, and the same pair serves the centre and every sweep that does not move t).
 GEL_DEV EarthAngle earth_angle(double t) {
   EarthAngle e;
-  sincos(kOmega * t / 2.0, &e.sh, &e.ch);
+  fsincos(kOmega * t / 2.0, &e.sh, &e.ch);
   e.s = 2.0 * e.sh * e.ch;
   e.c = (e.ch - e.sh) * (e.ch + e.sh);
   return e;

@@ -771,3 +771,34 @@ def test_random_problem_structures_values(seed):
     X = np.tile(x, (B, 1))
     res, jv, rc = E.eval_batch(X)
     assert rc == 0 and np.array_equal(res[B - 1], res1) and np.array_equal(E.expand(jv[B - 1]), vals1)
+
+
+def test_path_sincos_and_log_accuracy():
+    """gel::fsincos (|x| <= 3 pi/4: latitudes, half Earth angles) and gel::flog_ratio (0.5 < x < 2: temperature ratios
+    inside a layer) against numpy: at most 1 ulp resp. 2 ulp off the correctly rounded value, and not more often
+    wrong than the library's own functions; outside those ranges they ARE the library's functions."""
+    _setup()
+    from gelato_amd import dynamics
+    rng = np.random.default_rng(5)
+    n = 1 << 19
+    ang = np.concatenate([rng.uniform(-2.35, 2.35, n), np.pi / 2 + rng.uniform(-1e-3, 1e-3, n // 4) * rng.random(n // 4),
+                          rng.uniform(-1e-3, 1e-3, n // 4), np.pi / 4 + rng.uniform(-1e-6, 1e-6, n // 4),
+                          rng.uniform(-40.0, 40.0, n // 4)])
+    rat = np.concatenate([rng.uniform(0.5, 2.0, n), 1.0 + rng.uniform(-1e-6, 1e-6, n // 2), rng.uniform(2.0, 40.0, n // 4),
+                          rng.uniform(1e-3, 0.5, n // 4)])
+    assert len(ang) == len(rat)
+    out = dynamics.point_eval(8, np.stack([ang, rat], axis=1))
+
+    def ulps(a, ref):
+        return np.abs(a - ref) / np.spacing(np.abs(ref))
+    us, uc = ulps(out[:, 0], np.sin(ang)), ulps(out[:, 1], np.cos(ang))
+    ls, lc = ulps(out[:, 2], np.sin(ang)), ulps(out[:, 3], np.cos(ang))
+    assert us.max() <= 1.0 and uc.max() <= 1.0
+    assert np.mean(us > 0) <= np.mean(ls > 0) + 0.005 and np.mean(uc > 0) <= np.mean(lc > 0) + 0.005
+    big = np.abs(ang) > 2.35619449019234492885
+    assert np.array_equal(out[big, 0], out[big, 2]) and np.array_equal(out[big, 1], out[big, 3])
+    ref = np.log(rat)
+    inside = (rat > 0.5) & (rat < 2.0)
+    ul = np.abs(out[:, 4] - ref) / np.spacing(np.maximum(np.abs(ref), 1e-300))
+    assert ul[inside].max() <= 2.0
+    assert np.array_equal(out[~inside, 4], out[~inside, 5])

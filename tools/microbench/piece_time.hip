@@ -1,0 +1,137 @@
+// Time per call of every piece of the RHS chain at the occupancy of the real kernel (4 waves/SIMD), with a
+// dependent loop so nothing is hoisted: tells which pieces cost more than their instruction count suggests.
+// Build & run on the GPU box: tools/microbench/run_time.sh
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../gelato_amd/csrc/gel_rhs_parts.h"
+using namespace gel;
+constexpr int R = 256;
+
+// candidates measured here before they go anywhere near the product
+// log(x) for x in (0.5, 2): 2 atanh((x-1)/(x+1)), odd series in z = (x-1)/(x+1), |z| <= 1/3
+__device__ __forceinline__ double flog_near1(double x) {
+  const double z = fdiv(x - 1.0, x + 1.0), w = z * z;
+  double p = 1.0 / 33.0;
+  p = __builtin_fma(p, w, 1.0 / 31.0); p = __builtin_fma(p, w, 1.0 / 29.0); p = __builtin_fma(p, w, 1.0 / 27.0);
+  p = __builtin_fma(p, w, 1.0 / 25.0); p = __builtin_fma(p, w, 1.0 / 23.0); p = __builtin_fma(p, w, 1.0 / 21.0);
+  p = __builtin_fma(p, w, 1.0 / 19.0); p = __builtin_fma(p, w, 1.0 / 17.0); p = __builtin_fma(p, w, 1.0 / 15.0);
+  p = __builtin_fma(p, w, 1.0 / 13.0); p = __builtin_fma(p, w, 1.0 / 11.0); p = __builtin_fma(p, w, 1.0 / 9.0);
+  p = __builtin_fma(p, w, 1.0 / 7.0); p = __builtin_fma(p, w, 1.0 / 5.0); p = __builtin_fma(p, w, 1.0 / 3.0);
+  // log x = 2 z + 2 z^3 p
+  return __builtin_fma(2.0 * z * w, p, 2.0 * z);
+}
+__device__ __forceinline__ void fsincos_small(double x, double* sn, double* cs) {
+  const double ax = fabs(x);
+  if (ax > 2.35619449019234492885) { sincos(x, sn, cs); return; }
+  const double n = (ax > 0.78539816339744830962) ? 1.0 : 0.0;
+  const double kPio2Hi = 1.57079632679489655800e+00, kPio2Lo = 6.12323399573676603587e-17;
+  const double hi = __builtin_fma(-n, kPio2Hi, ax);
+  const double r = __builtin_fma(-n, kPio2Lo, hi);
+  const double y = __builtin_fma(-n, kPio2Lo, hi - r);
+  const double z = r * r;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double v = z * r;
+  const double ps = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double ks = r - ((z * (0.5 * y - v * ps) - y) - v * S1);
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double kc = w + (((1.0 - w) - hz) + (z * pc - r * y));
+  const bool q = n != 0.0;
+  *sn = copysign(q ? kc : ks, x);
+  *cs = q ? -ks : kc;
+}
+// LDS sized so that exactly 4 workgroups of 4 waves fit a CU (like the fused kernel): 39 KB each
+#define K(name, ...)                                                                                    \
+  __global__ __launch_bounds__(256, 4) void name(const double* in, double* out, const double* tabs) {   \
+    extern __shared__ double lds[];                                                                     \
+    for (int i = threadIdx.x; i < 107; i += blockDim.x) lds[i] = tabs[i];                               \
+    __syncthreads();                                                                                    \
+    Tables tb{lds, lds + 66, lds + 93, 9, 7};                                                            \
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;                                                \
+    double a[16];                                                                                       \
+    for (int i = 0; i < 16; i++) a[i] = in[16 * (t & 65535) + i];                                       \
+    double acc = 0.0;                                                                                   \
+    for (int it = 0; it < R; it++) {                                                                    \
+      double o0 = 0.0;                                                                                  \
+      __VA_ARGS__                                                                                       \
+      acc += o0;                                                                                        \
+      const double eps = 1.0 + 1e-16 * (o0 != 12345.0);                                                 \
+      a[0] *= eps; a[9] *= eps; a[10] *= eps; a[12] *= eps; a[13] *= eps; a[14] *= eps; a[3] *= eps;    \
+    }                                                                                                   \
+    out[t] = acc;                                                                                       \
+  }
+K(t_base, o0 = a[0];)
+K(t_div, o0 = a[0] / a[1];)
+K(t_fdiv, o0 = fdiv(a[0], a[1]);)
+K(t_sqrt, o0 = sqrt(a[0]);)
+K(t_fsqrt, o0 = fsqrt(a[0]);)
+K(t_fma8, double x = a[0]; for (int i = 0; i < 8; i++) x = __builtin_fma(x, 1.0000001, 1e-9); o0 = x;)
+K(t_sincos, double s, c; sincos(a[9], &s, &c); o0 = s + c;)
+K(t_atan2, o0 = atan2(a[0], a[1]);)
+K(t_exp, o0 = exp(-a[10]);)
+K(t_log, o0 = log(a[10]);)
+K(t_flog, o0 = flog_near1(a[10]);)
+K(t_fsincos, double s, c; fsincos_small(a[9], &s, &c); o0 = s + c;)
+K(t_pow, o0 = pow(a[10], a[11]);)
+K(t_explog, o0 = exp(a[11] * log(a[10]));)
+K(t_expflog, o0 = exp(a[11] * flog_near1(a[10]));)
+K(t_geolatp, double lat, p; geodetic_lat_p(a[0], a[1], a[2], lat, p); o0 = lat + p;)
+K(t_atmos, Air p = atmosphere(a[12], tb.atm); o0 = p.rho + p.P + p.a;)
+K(t_wind, double wn, we; wind_ned2(a[12], tb.wind, tb.Kw, wn, we); o0 = wn + we;)
+K(t_interp, o0 = interp_tab(a[13], tb.ca, tb.Kc, 2, 1);)
+K(t_gravity, double r[3] = {a[0], a[1], a[2]}; double g[3]; gravity_eci(r, -0.484165371736e-3, g); o0 = g[0] + g[1] + g[2];)
+K(t_pos_part, double r[3] = {a[0], a[1], a[2]}; PosPart p = pos_part(r, tb, -0.484165371736e-3);
+  o0 = p.rho + p.P + p.a + p.wn + p.we + p.g[0] + p.g[1] + p.g[2] + p.shp + p.chp + p.inv_p;)
+K(t_earth, EarthAngle e = earth_angle(a[14]); o0 = e.c + e.s + e.ch + e.sh;)
+K(t_wind_eci, double r[3] = {a[0], a[1], a[2]}; EarthAngle e{0.999, 0.01, 0.9999, 0.005}; double w[3];
+  wind_eci(r, e, 0.36, 0.93, 1.0 / 4.7e6, 10.0, -5.0, w); o0 = w[0] + w[1] + w[2];)
+K(t_aero, double r[3] = {a[0], a[1], a[2]}; double v[3] = {a[3], a[4], a[5]}; EarthAngle e{0.999, 0.01, 0.9999, 0.005};
+  double w[3] = {1, 2, 3}; double F[3]; aero_force(r, v, 0.5, 300.0, e, w, 2.21, tb, F); o0 = F[0] + F[1] + F[2];)
+
+int main() {
+  const int n = 64 * 1024;
+  std::vector<double> in(16 * n), tabs(160, 0.0);
+  for (int i = 0; i < n; i++) {
+    double th = 0.74 + 1e-6 * i, Rr = 6378137.0 + 10.0 + 1.2 * i;
+    double* a = &in[16 * i];
+    a[0] = Rr * cos(th) * 0.8; a[1] = Rr * cos(th) * 0.6; a[2] = Rr * sin(th);
+    a[3] = 100.0 + 0.05 * i; a[4] = 300.0; a[5] = 50.0; a[6] = 0.5; a[7] = -0.5; a[8] = 0.5; a[9] = 0.7 + 1e-5 * i;
+    a[10] = 0.8 + 1e-6 * i; a[11] = 5.2558; a[12] = 1.2 * i; a[13] = 0.1 + 4e-5 * i; a[14] = 0.3;
+  }
+  const double lmb[11] = {-0.0065, 0.0, 0.001, 0.0028, 0.0, -0.0028, -0.002, 0.0, 0.0025, 0.012, 0.012};
+  const double tmb[11] = {288.15, 216.65, 216.65, 228.65, 270.65, 270.65, 214.65, 186.8673, 186.8673, 240.0, 360.0};
+  const double pb[11] = {101325.0, 22632.0, 5474.9, 868.02, 110.91, 66.939, 3.9564, 0.37338, 0.15381, 7.1042e-3, 2.5382e-3};
+  for (int k = 0; k < 11; k++) { tabs[k] = lmb[k]; tabs[11 + k] = tmb[k]; tabs[22 + k] = pb[k]; tabs[33 + k] = 8314.32 / 28.9644;
+    tabs[44 + k] = fabs(lmb[k]) > 1e-6 ? -9.80665 / lmb[k] / tabs[33 + k] : 0.0; tabs[55 + k] = 9.80665 / tabs[33 + k]; }
+  const double wind[27] = {-1e8,0,0, 0,0,0, 1000,0,0, 3000,0,10, 11000,0,30, 15000,0,30, 16000,0,25, 23000,0,0, 1e10,0,0};
+  const double ca[14] = {0,0.3, 0.7,0.3, 1,0.65, 1.5,0.65, 2,0.6, 5,0.3, 100,0.3};
+  for (int i = 0; i < 27; i++) tabs[66 + i] = wind[i];
+  for (int i = 0; i < 14; i++) tabs[93 + i] = ca[i];
+  const int waves = 256 * 16 * 4, threads = waves * 64;   // 4 rounds of the 4096 resident waves
+  double *d_in, *d_out, *d_t;
+  hipMalloc(&d_in, in.size() * 8); hipMalloc(&d_out, (size_t)threads * 8); hipMalloc(&d_t, tabs.size() * 8);
+  hipMemcpy(d_in, in.data(), in.size() * 8, hipMemcpyHostToDevice); hipMemcpy(d_t, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float base_ms = 0.f;
+#define RUN(k)                                                                                              \
+  {                                                                                                         \
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k, dim3(threads / 256), dim3(256), 39000, 0, d_in, d_out, d_t); \
+    hipEventRecord(e0);                                                                                     \
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL(k, dim3(threads / 256), dim3(256), 39000, 0, d_in, d_out, d_t); \
+    hipEventRecord(e1); hipEventSynchronize(e1);                                                            \
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;                                                    \
+    if (!strcmp(#k, "t_base")) base_ms = ms;                                                                \
+    /* per SIMD: 16 waves (4 rounds x 4 resident) x R calls each */                                         \
+    printf("%-12s %8.3f ms  net %8.3f ms  -> %7.1f ns per call per SIMD-slot (x clock = cycles)\n", #k, ms, ms - base_ms, \
+           (ms - base_ms) * 1e6 / (16.0 * R));                                                              \
+  }
+  RUN(t_base) RUN(t_fma8) RUN(t_div) RUN(t_fdiv) RUN(t_sqrt) RUN(t_fsqrt) RUN(t_sincos) RUN(t_atan2) RUN(t_exp) RUN(t_log) RUN(t_flog) RUN(t_fsincos) RUN(t_pow) RUN(t_explog) RUN(t_expflog)
+  RUN(t_geolatp) RUN(t_atmos) RUN(t_wind) RUN(t_interp) RUN(t_gravity) RUN(t_pos_part) RUN(t_earth) RUN(t_wind_eci) RUN(t_aero)
+  return 0;
+}
