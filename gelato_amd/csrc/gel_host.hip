@@ -479,6 +479,8 @@ void fill_atmosphere_table(double* atm) {
     const double R = atm[33 + k], g0 = 9.80665;
     atm[44 + k] = (std::fabs(lmb[k]) > 1.0e-6) ? (-g0 / lmb[k] / R) : 0.0;
     atm[55 + k] = g0 / R;
+    static const double hb[11] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0, 86000.0, 91000.0, 110000.0, 120000.0};
+    atm[66 + k] = hb[k];  // src/Air.cpp:29-30
   }
 }
 }  // namespace gel
@@ -508,6 +510,12 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
       !d->engine_on || !d->attitude_hold || !d->wind_table || !d->ca_table || d->wind_rows < 2 || d->ca_rows < 2)
     return fail(GEL_ERR_ARG, "incomplete problem description");
   if (!(d->dx > 0.0)) return fail(GEL_ERR_ARG, "dx must be positive");
+  // interpolation tables: strictly increasing abscissae (np.interp's precondition; the bracket search and the
+  // guard-free division of the device lookup rely on distinct knots)
+  for (int k = 1; k < d->wind_rows; k++)
+    if (!(d->wind_table[3 * k] > d->wind_table[3 * (k - 1)])) return fail(GEL_ERR_ARG, "wind table altitudes must increase strictly");
+  for (int k = 1; k < d->ca_rows; k++)
+    if (!(d->ca_table[2 * k] > d->ca_table[2 * (k - 1)])) return fail(GEL_ERR_ARG, "CA table Mach numbers must increase strictly");
   for (int i = 0; i < d->num_sections; i++)
     if (d->num_nodes[i] < 2) return fail(GEL_ERR_ARG, "every phase needs >= 2 LGR nodes (nodes_LGR requires n >= 2)");
   // device == GEL_DEVICE_NONE: a host-only handle (dims, LGR data, sparsity pattern, constant values,

@@ -25,7 +25,7 @@ hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDe
                        double* d_con, double* d_jac, hipStream_t s);
 
 // US-1976 layer table as the kernels expect it: Lmb[11] | Tmb[11] | Pb[11] | R[11] | pexp[11] | gR[11]
-constexpr int kAtmTableDoubles = 66;  // must equal kAtmDoubles of gel_physics.h (static_assert in gel_kernels.hip)
+constexpr int kAtmTableDoubles = 77;  // must equal kAtmDoubles of gel_physics.h (static_assert in gel_kernels.hip)
 void fill_atmosphere_table(double* atm);
 
 }  // namespace gel

@@ -27,7 +27,7 @@ constexpr double kEp2 = (kRa * kRa - kRb * kRb) / kRb / kRb;
 constexpr double kPi = 3.14159265358979323846;
 
 // LDS-resident tables: US-1976 layers (src/Air.cpp:31-45) + wind + CA.
-// atm is [6][11]: Lmb, Tmb, Pb, R (= Rstar / mb, src/Air.cpp:67), and the two per-layer constants of the
+// atm is [7][11]: Lmb, Tmb, Pb, R (= Rstar / mb, src/Air.cpp:67), and the two per-layer constants of the
 // pressure formula (src/Air.cpp:93-97) precomputed on the host with the reference's own operation
 // order: pexp = -g0 / Lmb / R (lapse layers), gR = g0 / R (isothermal layers).
 struct Tables {
@@ -36,7 +36,7 @@ struct Tables {
   const double* ca;    // [Kc][2]
   int Kw, Kc;
 };
-constexpr int kAtmDoubles = 66;
+constexpr int kAtmDoubles = 77;  // Lmb, Tmb, Pb, R, pressure exponent, g0/R, layer base altitude: 11 layers each
 
 // ---------------------------------------------------------------------------
 // fp64 square root and division without the range guards.
@@ -160,19 +160,11 @@ GEL_DEV int us76_layer(double h) {  // src/Air.cpp:56-61
   return k;
 }
 
-GEL_DEV double us76_hb(int k) {
-  const double hb[11] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0, 86000.0, 91000.0, 110000.0, 120000.0};
-  double v = 0.0;
-#pragma unroll
-  for (int i = 1; i < 11; i++) v = (k == i) ? hb[i] : v;
-  return v;
-}
-
 struct Air { double T, P, rho, a; };
 
 GEL_DEV Air atmosphere(double h, const double* atm) {
   const int k = us76_layer(h);
-  const double Hb = us76_hb(k);
+  const double Hb = atm[66 + k];  // layer base altitude from the table (a 30-instruction select chain otherwise)
   const double Lmb = atm[k], Tmb = atm[11 + k], Pb = atm[22 + k], R = atm[33 + k];
   const double r0 = 6356766.0;
   Air o;
@@ -315,7 +307,7 @@ GEL_DEV double interp_tab(double x, const double* tab, int n, int stride, int yc
   const int idx = min(max(lower_count(x, tab, n, stride) - 1, 0), n - 2);
   const double xl = tab[idx * stride], xu = tab[(idx + 1) * stride];
   const double yl = tab[idx * stride + ycol], yu = tab[(idx + 1) * stride + ycol];
-  const double alpha = (x - xl) / (xu - xl);
+  const double alpha = fdiv(x - xl, xu - xl);  // knots are distinct (checked at problem creation)
   const double v = yl + alpha * (yu - yl);
   // clamps of the reference (and yp[0] at x == xp[0]) as selects instead of early returns
   return (x <= tab[0]) ? tab[ycol] : ((x > tab[(n - 1) * stride]) ? tab[(n - 1) * stride + ycol] : v);
@@ -325,7 +317,7 @@ GEL_DEV double interp_tab(double x, const double* tab, int n, int stride, int yc
 GEL_DEV void wind_ned2(double h, const double* tab, int n, double& wn, double& we) {
   const int idx = min(max(lower_count(h, tab, n, 3) - 1, 0), n - 2);
   const double xl = tab[idx * 3], xu = tab[(idx + 1) * 3];
-  const double alpha = (h - xl) / (xu - xl);
+  const double alpha = fdiv(h - xl, xu - xl);
   const double vn = tab[idx * 3 + 1] + alpha * (tab[(idx + 1) * 3 + 1] - tab[idx * 3 + 1]);
   const double ve = tab[idx * 3 + 2] + alpha * (tab[(idx + 1) * 3 + 2] - tab[idx * 3 + 2]);
   const bool below = h <= tab[0], above = h > tab[(n - 1) * 3];

@@ -124,6 +124,9 @@ int main(void) {
   REQUIRE(gel_problem_create(&bad, &q) != GEL_OK);
   bad = d; bad.wind_rows = 1;
   REQUIRE(gel_problem_create(&bad, &q) != GEL_OK);
+  const double dup[3][3] = {{0.0, 1.0, 2.0}, {5000.0, 3.0, -1.0}, {5000.0, 10.0, 4.0}};   /* repeated knot */
+  bad = d; bad.wind_table = &dup[0][0];
+  REQUIRE(gel_problem_create(&bad, &q) != GEL_OK && strstr(gel_last_error(), "strictly"));
   REQUIRE(gel_problem_create(NULL, &q) != GEL_OK);
   printf("HOST_SANITIZE_OK\n");
   return 0;

@@ -7,8 +7,8 @@
 #include "../../gelato_amd/csrc/gel_rhs_parts.h"
 using namespace gel;
 #define K(name, ...) __global__ void name(const double* in, double* out, const double* tabs) { \
-  __shared__ double lds[160]; for (int i = threadIdx.x; i < 107; i += blockDim.x) lds[i] = tabs[i]; __syncthreads(); \
-  Tables tb{lds, lds+66, lds+93, 9, 7}; const int t = blockIdx.x * blockDim.x + threadIdx.x; const double* a = in + 16*t; double* o = out + 16*t; __VA_ARGS__ }
+  __shared__ double lds[176]; for (int i = threadIdx.x; i < 118; i += blockDim.x) lds[i] = tabs[i]; __syncthreads(); \
+  Tables tb{lds, lds+77, lds+104, 9, 7}; const int t = blockIdx.x * blockDim.x + threadIdx.x; const double* a = in + 16*t; double* o = out + 16*t; __VA_ARGS__ }
 K(k_base, o[0]=a[0];)
 K(k_div, o[0]=a[0]/a[1];)
 K(k_sqrt, o[0]=sqrt(a[0]);)
@@ -29,7 +29,7 @@ K(k_aero, double r[3]={a[0],a[1],a[2]}; double v[3]={a[3],a[4],a[5]}; EarthAngle
 K(k_thrustdir, double q[4]={a[5],a[6],a[7],a[8]}; double d[3]; thrust_dir(q,d); o[0]=d[0];o[1]=d[1];o[2]=d[2];)
 int main() {
   const int n = 64 * 1024;
-  std::vector<double> in(16 * n), tabs(160, 0.0);
+  std::vector<double> in(16 * n), tabs(176, 0.0);
   for (int i = 0; i < n; i++) {
     double th = 0.74 + 1e-6 * i, R = 6378137.0 + 10.0 + 1.2 * i;  // altitudes 0..79 km
     double* a = &in[16 * i];
@@ -43,10 +43,11 @@ int main() {
   const double pb[11] = {101325.0, 22632.0, 5474.9, 868.02, 110.91, 66.939, 3.9564, 0.37338, 0.15381, 7.1042e-3, 2.5382e-3};
   for (int k = 0; k < 11; k++) { tabs[k] = lmb[k]; tabs[11+k] = tmb[k]; tabs[22+k] = pb[k]; tabs[33+k] = 8314.32/28.9644;
     tabs[44+k] = fabs(lmb[k]) > 1e-6 ? -9.80665/lmb[k]/tabs[33+k] : 0.0; tabs[55+k] = 9.80665/tabs[33+k]; }
+  { const double hb[11] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0, 86000.0, 91000.0, 110000.0, 120000.0}; for (int k = 0; k < 11; k++) tabs[66+k] = hb[k]; }
   const double wind[27] = {-1e8,0,0, 0,0,0, 1000,0,0, 3000,0,10, 11000,0,30, 15000,0,30, 16000,0,25, 23000,0,0, 1e10,0,0};
   const double ca[14] = {0,0.3, 0.7,0.3, 1,0.65, 1.5,0.65, 2,0.6, 5,0.3, 100,0.3};
-  for (int i = 0; i < 27; i++) tabs[66+i] = wind[i];
-  for (int i = 0; i < 14; i++) tabs[93+i] = ca[i];
+  for (int i = 0; i < 27; i++) tabs[77+i] = wind[i];
+  for (int i = 0; i < 14; i++) tabs[104+i] = ca[i];
   double *d_in, *d_out, *d_t;
   hipMalloc(&d_in, in.size()*8); hipMalloc(&d_out, in.size()*8); hipMalloc(&d_t, tabs.size()*8);
   hipMemcpy(d_in, in.data(), in.size()*8, hipMemcpyHostToDevice); hipMemcpy(d_t, tabs.data(), tabs.size()*8, hipMemcpyHostToDevice);

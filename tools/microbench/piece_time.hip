@@ -50,9 +50,9 @@ __device__ __forceinline__ void fsincos_small(double x, double* sn, double* cs) 
 #define K(name, ...)                                                                                    \
   __global__ __launch_bounds__(256, 4) void name(const double* in, double* out, const double* tabs) {   \
     extern __shared__ double lds[];                                                                     \
-    for (int i = threadIdx.x; i < 107; i += blockDim.x) lds[i] = tabs[i];                               \
+    for (int i = threadIdx.x; i < 118; i += blockDim.x) lds[i] = tabs[i];                               \
     __syncthreads();                                                                                    \
-    Tables tb{lds, lds + 66, lds + 93, 9, 7};                                                            \
+    Tables tb{lds, lds + 77, lds + 104, 9, 7};                                                            \
     const int t = blockIdx.x * blockDim.x + threadIdx.x;                                                \
     double a[16];                                                                                       \
     for (int i = 0; i < 16; i++) a[i] = in[16 * (t & 65535) + i];                                       \
@@ -89,6 +89,10 @@ K(t_gravity, double r[3] = {a[0], a[1], a[2]}; double g[3]; gravity_eci(r, -0.48
 K(t_pos_part, double r[3] = {a[0], a[1], a[2]}; PosPart p = pos_part(r, tb, -0.484165371736e-3);
   o0 = p.rho + p.P + p.a + p.wn + p.we + p.g[0] + p.g[1] + p.g[2] + p.shp + p.chp + p.inv_p;)
 K(t_earth, EarthAngle e = earth_angle(a[14]); o0 = e.c + e.s + e.ch + e.sh;)
+K(t_thrustdir, double q[4] = {a[5] * 1e-2, a[6], a[7], a[8]}; double d[3]; thrust_dir(q, d); o0 = d[0] + d[1] + d[2]; a[5] += o0 * 1e-300;)
+K(t_accel, double Td[3] = {a[0], a[1], a[2]}; double F[3] = {a[3], a[4], a[5]}; double g[3] = {1, 2, 3}; double f[3];
+  accel(Td, F, a[10], g, 1e-3, f); o0 = f[0] + f[1] + f[2];)
+K(t_quatrate, double q[4] = {a[5] * 1e-2, a[6], a[7], a[8]}; double dq[4]; quat_rate(q, a[10], a[13], 1.0, dq); o0 = dq[0] + dq[1] + dq[2] + dq[3];)
 K(t_wind_eci, double r[3] = {a[0], a[1], a[2]}; EarthAngle e{0.999, 0.01, 0.9999, 0.005}; double w[3];
   wind_eci(r, e, 0.36, 0.93, 1.0 / 4.7e6, 10.0, -5.0, w); o0 = w[0] + w[1] + w[2];)
 K(t_aero, double r[3] = {a[0], a[1], a[2]}; double v[3] = {a[3], a[4], a[5]}; EarthAngle e{0.999, 0.01, 0.9999, 0.005};
@@ -96,7 +100,7 @@ K(t_aero, double r[3] = {a[0], a[1], a[2]}; double v[3] = {a[3], a[4], a[5]}; Ea
 
 int main() {
   const int n = 64 * 1024;
-  std::vector<double> in(16 * n), tabs(160, 0.0);
+  std::vector<double> in(16 * n), tabs(176, 0.0);
   for (int i = 0; i < n; i++) {
     double th = 0.74 + 1e-6 * i, Rr = 6378137.0 + 10.0 + 1.2 * i;
     double* a = &in[16 * i];
@@ -109,10 +113,11 @@ int main() {
   const double pb[11] = {101325.0, 22632.0, 5474.9, 868.02, 110.91, 66.939, 3.9564, 0.37338, 0.15381, 7.1042e-3, 2.5382e-3};
   for (int k = 0; k < 11; k++) { tabs[k] = lmb[k]; tabs[11 + k] = tmb[k]; tabs[22 + k] = pb[k]; tabs[33 + k] = 8314.32 / 28.9644;
     tabs[44 + k] = fabs(lmb[k]) > 1e-6 ? -9.80665 / lmb[k] / tabs[33 + k] : 0.0; tabs[55 + k] = 9.80665 / tabs[33 + k]; }
+  { const double hb[11] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0, 86000.0, 91000.0, 110000.0, 120000.0}; for (int k = 0; k < 11; k++) tabs[66 + k] = hb[k]; }
   const double wind[27] = {-1e8,0,0, 0,0,0, 1000,0,0, 3000,0,10, 11000,0,30, 15000,0,30, 16000,0,25, 23000,0,0, 1e10,0,0};
   const double ca[14] = {0,0.3, 0.7,0.3, 1,0.65, 1.5,0.65, 2,0.6, 5,0.3, 100,0.3};
-  for (int i = 0; i < 27; i++) tabs[66 + i] = wind[i];
-  for (int i = 0; i < 14; i++) tabs[93 + i] = ca[i];
+  for (int i = 0; i < 27; i++) tabs[77 + i] = wind[i];
+  for (int i = 0; i < 14; i++) tabs[104 + i] = ca[i];
   const int waves = 256 * 16 * 4, threads = waves * 64;   // 4 rounds of the 4096 resident waves
   double *d_in, *d_out, *d_t;
   hipMalloc(&d_in, in.size() * 8); hipMalloc(&d_out, (size_t)threads * 8); hipMalloc(&d_t, tabs.size() * 8);
@@ -132,6 +137,6 @@ int main() {
            (ms - base_ms) * 1e6 / (16.0 * R));                                                              \
   }
   RUN(t_base) RUN(t_fma8) RUN(t_div) RUN(t_fdiv) RUN(t_sqrt) RUN(t_fsqrt) RUN(t_sincos) RUN(t_atan2) RUN(t_exp) RUN(t_log) RUN(t_flog) RUN(t_fsincos) RUN(t_pow) RUN(t_explog) RUN(t_expflog)
-  RUN(t_geolatp) RUN(t_atmos) RUN(t_wind) RUN(t_interp) RUN(t_gravity) RUN(t_pos_part) RUN(t_earth) RUN(t_wind_eci) RUN(t_aero)
+  RUN(t_geolatp) RUN(t_atmos) RUN(t_wind) RUN(t_interp) RUN(t_gravity) RUN(t_pos_part) RUN(t_earth) RUN(t_thrustdir) RUN(t_accel) RUN(t_quatrate) RUN(t_wind_eci) RUN(t_aero)
   return 0;
 }
