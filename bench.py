@@ -223,7 +223,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "gel::eval_kernel<true, true, false>",
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_eval": E.algorithmic_bytes,
                      "algorithmic_bytes_per_launch": abytes,
-                     "note": "fp64-VALU-bound, not HBM-bound: ~6.3 VALU lane-instructions per algorithmic byte (libm chains); VALU floor ~52% of the HBM roofline, see DESIGN.md 3.1"},
+                     "note": "fp64-VALU-bound, not HBM-bound: ~5.8 VALU lane-instructions per algorithmic byte (libm chains); VALU floor ~57% of the HBM roofline, see DESIGN.md 3.1"},
         "status": int(status),
     }
 
