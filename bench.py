@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16384, help="decision vectors per GPU per step (16384 x 6 = 24 rounds of "
                     "the 4096 wavefronts the chip holds: at 4096 vectors the ramp and tail of a launch cost a quarter)")
+    ap.add_argument("--settle-ms", type=float, default=250.0, dest="settle_ms",
+                    help="untimed launches before the warm-up steps until the power state has settled (0 = none)")
     ap.add_argument("--workload", default="mixed-6x64", help="mixed-6x64 | dense-6x64 | 3x32 | stress-12x128 | example")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "phase-shard"],
                     help="replicas: B vectors per GPU, no collective (weak scaling, the headline). phase-shard: ONE "
@@ -167,6 +169,14 @@ def main():
         if use_dist:
             dist.barrier(device_ids=[local])
 
+    # Power-state settle (untimed, not one of the W warm-up steps): from idle the chip's power management
+    # overshoots -- tools/launch_series.py: 1.36 ms for the first launch, 1.70 ms 3 ms later, back to 1.30 ms
+    # after ~40 ms -- so a window of W + K launches right after start-up mostly measures that transient.  A
+    # batch workload lives in the steady state; ~0.25 s of launches get there.  Same count on every rank.
+    n_settle = 0 if a.settle_ms <= 0 else min(5000, max(10, int(a.settle_ms / 1.3 * 16384 / B)))
+    for _ in range(n_settle):
+        step()
+    torch.cuda.synchronize()
     for _ in range(W):
         step()
     torch.cuda.synchronize()
@@ -216,7 +226,7 @@ def main():
         "ms_per_step": 1e3 * T / K, "ms_per_eval": 1e3 * T / (B * K), "higher_is_better": True,
         "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": a.workload, "phases": int(S), "nodes_per_phase": [int(n) for n in prob["num_nodes"]],
-                   "batch_per_gpu": B, "decision_vars": E.nvars, "residual_rows": E.nres,
+                   "batch_per_gpu": B, "settle_launches_before_warmup": n_settle, "decision_vars": E.nvars, "residual_rows": E.nres,
                    "jacobian_values_per_eval": E.V, "coo_nnz": E.total_nnz, "parallelism": ("phase+column shards x%d + all-reduce" if shard else "replicas x%d") % world,
                    "output": "4 defect residuals + all x-dependent COO Jacobian values (compact), in HBM"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

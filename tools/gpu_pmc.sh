@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() { # name, counters...
   local name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras $BENCH_ARGS > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-extras $BENCH_ARGS > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
   echo "pmc $name rc=$?"
 }
 BENCH_ARGS="$@"
