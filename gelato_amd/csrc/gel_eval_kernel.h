@@ -41,6 +41,10 @@ static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wav
 
 typedef double gel_double4 __attribute__((ext_vector_type(4)));
 
+#ifndef GEL_STORE_AUX
+#define GEL_STORE_AUX 2  // cache policy of the Jacobian stores: 2 = nt (A/B: 0 plain, 1 sc0, 16 sc1, 18 sc1+nt)
+#endif
+
 // JAC: also the FD Jacobian.  MFMA: D.X on the matrix pipe (v_mfma_f64_16x16x4_f64) instead of VALU FMAs.
 // SPLIT (latency form for a handful of decision vectors, e.g. the optimiser's B = 1 callback): every work item
 // becomes four wavefronts -- part 0 does everything except the three position sweeps, parts 1..3 do the
@@ -115,14 +119,18 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   // over global_store another -1.8 %.
   typedef unsigned gel_u2 __attribute__((ext_vector_type(2)));
   const __amdgpu_buffer_rsrc_t jrs =
+#ifdef GEL_ABL_SAMEADDR  // ablation: every vector writes over vector 0's values (same instructions, L2-resident target)
+      __builtin_amdgcn_make_buffer_rsrc(JAC ? (void*)(jvar + ph.voff + j0) : (void*)nullptr, 0, -1, 0x00020000);
+#else
       __builtin_amdgcn_make_buffer_rsrc(JAC ? (void*)(jvar + (size_t)b * P.V + ph.voff + j0) : (void*)nullptr, 0, -1, 0x00020000);
+#endif
   const int jvo = lane * 8;
 #define EMIT(slot, val)                                                                 \
   do {                                                                                  \
     const double _v = (val);                                                            \
     gel_u2 _d;                                                                          \
     __builtin_memcpy(&_d, &_v, 8);                                                      \
-    __builtin_amdgcn_raw_buffer_store_b64(_d, jrs, jvo, (int)(slot) * n * 8, 2 /* nt */); \
+    __builtin_amdgcn_raw_buffer_store_b64(_d, jrs, jvo, (int)(slot) * n * 8, GEL_STORE_AUX); \
     chk += _v;                                                                          \
   } while (0)
 #endif
