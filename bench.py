@@ -27,24 +27,48 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(prob, D, tau, X, gpu_first=None, budget_s=12.0):
+def cpu_baseline(prob, D, tau, X, gpu_first=None, budget_s=12.0, residual_only=False):
     """The oracle (scalar C port of the reference algorithm) timed on this box's host cores, 1 thread,
     on a bounded sample of the same workload.  This leg is the only place bench.py touches oracle/: besides
     the timing it checks element 0 of what the GPU just produced (`gpu_first` = (res, full values)) against
-    it, after the timed region."""
+    it, after the timed region.  residual_only: the four residual functions alone (BASELINE configs[1])."""
     import oracle
     P = oracle.Problem(prob, D=D, tau=tau)
+
+    def run(Xs):
+        if residual_only:
+            for x in Xs:
+                for g in oracle.GROUPS:
+                    P.residual(g, x)
+        else:
+            P.eval_batch(Xs, nthreads=1, keep_vals=False)
+
     t0 = time.perf_counter()
-    P.eval_batch(X[:2], nthreads=1, keep_vals=False)
+    run(X[:2])
     per = (time.perf_counter() - t0) / 2
-    n = int(max(4, min(len(X), budget_s / max(per, 1e-6))))
+    # per-eval distribution first (SURVEY 8d: >= 200 evals, median + p10/p90), one eval per call
+    nd = int(max(8, min(len(X), 256, 0.25 * budget_s / max(per, 1e-6))))
+    ts = np.empty(nd)
+    for k in range(nd):
+        t0 = time.perf_counter()
+        run(X[k:k + 1])
+        ts[k] = time.perf_counter() - t0
+    n = int(max(4, min(len(X), 0.75 * budget_s / max(per, 1e-6))))
     t0 = time.perf_counter()
-    P.eval_batch(X[:n], nthreads=1, keep_vals=False)
+    run(X[:n])
     dt = time.perf_counter() - t0
+    what = "4 residuals" if residual_only else "4 residuals + 4 COO Jacobians each, every COO value computed"
     out = {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-           "sample": "%d evals (4 residuals + 4 COO Jacobians each, every COO value computed) of the same workload, "
-                     "oracle/libgelato_oracle.so, 1 thread, %.1f s" % (n, dt),
-           "ms_per_eval": 1e3 * dt / n}
+           "sample": "%d evals (%s) of the same workload, oracle/libgelato_oracle.so, 1 thread, %.1f s; "
+                     "per-eval distribution over %d single-eval calls" % (n, what, dt, nd),
+           "ms_per_eval": 1e3 * dt / n,
+           "ms_per_eval_median": 1e3 * float(np.median(ts)), "ms_per_eval_p10": 1e3 * float(np.percentile(ts, 10)),
+           "ms_per_eval_p90": 1e3 * float(np.percentile(ts, 90)), "distribution_evals": nd}
+    if residual_only:
+        if gpu_first is not None:
+            ores = np.concatenate([P.residual(g, X[0]) for g in oracle.GROUPS])
+            out["parity_spot_check"] = {"residual_max_abs_diff": float(np.max(np.abs(gpu_first[0] - ores)))}
+        return out
     try:  # informational: many host cores = independent single-thread worker PROCESSES over slices of the
         # sample (threads of one process do not run concurrently in this pool's sandbox: measured).  The
         # workers import only oracle/ and numpy -- nothing that touches the GPU -- and start from a fresh
@@ -106,6 +130,8 @@ def main():
                     help="replicas: B vectors per GPU, no collective (weak scaling, the headline). phase-shard: ONE "
                          "batch of B vectors evaluated by all GPUs together, work items dealt to ranks, one RCCL "
                          "sum all-reduce per step (strong scaling; BASELINE.json config 4)")
+    ap.add_argument("--residual-only", action="store_true", dest="residual_only",
+                    help="RHS + defect residuals only, no Jacobian (BASELINE.json configs[1]: 3x32 residual only vs CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational full-COO and B=1 legs")
     a = ap.parse_args()
@@ -144,7 +170,8 @@ def main():
     X = problem.synthetic_batch(x0, E.M, B, seed=20260313 + (0 if shard else rank * B))
     dX = torch.from_numpy(X).to(dev)
     dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
-    djv = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    djv = None if a.residual_only else torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    djv_ptr = 0 if djv is None else djv.data_ptr()
     stream = torch.cuda.current_stream().cuda_stream  # the engine launches on torch's current stream
 
     if shard:
@@ -163,16 +190,35 @@ def main():
             dist.all_reduce(djv, op=dist.ReduceOp.SUM)
     else:
         def step():
-            E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), stream)
+            E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv_ptr, stream)
 
     def barrier():
         if use_dist:
             dist.barrier(device_ids=[local])
 
-    # Power-state settle (untimed, not one of the W warm-up steps): from idle the chip's power management
-    # overshoots -- tools/launch_series.py: 1.36 ms for the first launch, 1.70 ms 3 ms later, back to 1.30 ms
-    # after ~40 ms -- so a window of W + K launches right after start-up mostly measures that transient.  A
-    # batch workload lives in the steady state; ~0.25 s of launches get there.  Same count on every rank.
+    def timed(K):
+        """barrier + synchronize, K steps, synchronize + barrier -> (wall seconds, HIP-event ms per step)"""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record()
+        for k in range(K):
+            step()
+        ev1.record()
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / K
+
+    # (1) COLD figure: W warm-up steps from an idle GPU, then K timed steps -- what a short burst sees.
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    elapsed_cold, kern_ms_cold = timed(K)
+    # (2) SETTLED figure (`value`): from idle the chip's power management overshoots -- tools/launch_series.py:
+    # 1.36 ms for the first launch, 1.70 ms 3 ms later, back to 1.30 ms after ~40 ms -- so the W + K launches
+    # above sit mostly inside that transient.  A batch workload lives in the steady state; ~0.25 s of untimed
+    # launches get there (same count on every rank), then W warm-up steps again, then exactly K timed steps.
     n_settle = 0 if a.settle_ms <= 0 else min(5000, max(10, int(a.settle_ms / 1.3 * 16384 / B)))
     for _ in range(n_settle):
         step()
@@ -180,25 +226,13 @@ def main():
     for _ in range(W):
         step()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(K):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, kern_ms = timed(K)
     status = E.sync(stream)
-    # HIP events on the launch stream over the timed region: K back-to-back launches of the one kernel
-    kern_ms = ev0.elapsed_time(ev1) / K
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed, elapsed_cold], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    T = float(tmax.item())
+    T, T_cold = float(tmax[0].item()), float(tmax[1].item())
 
     if rank != 0:
         if use_dist:
@@ -208,36 +242,57 @@ def main():
     # element 0 of what was just timed, kept for the oracle check inside the cpu_baseline leg
     gpu_first = None
     if not a.no_cpu_baseline and world == 1:
-        gpu_first = (dres[0].cpu().numpy(), E.expand(djv[0].cpu().numpy()))
+        gpu_first = (dres[0].cpu().numpy(), None if djv is None else E.expand(djv[0].cpu().numpy()))
 
     evals = (1 if shard else world) * B * K
-    abytes = E.algorithmic_bytes * B  # per launch: SURVEY.md 8(d) A_min x evals per launch
+    # per launch: SURVEY.md 8(d) A_min x evals per launch (residual only: read x once, write the residual once)
+    a_min = 8 * (E.nvars + E.nres) if a.residual_only else E.algorithmic_bytes
+    abytes = a_min * B
     achieved = abytes / (kern_ms * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s_B%d.json" % (a.workload, B))
-    if os.path.exists(tpath):  # PMC-derived HBM bytes per launch, written by tools/pmc_traffic.py
+    wl_tag = a.workload + ("_resonly" if a.residual_only else "")
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s_B%d.json" % (wl_tag, B))
+    if os.path.exists(tpath):  # PMC-derived HBM bytes per launch (separate rocprofv3 --pmc passes, tools/gpu_record.sh)
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    info = E.launch_info(B, True, not a.residual_only)   # which instantiation the launcher picked
+    kname = "gel::eval_kernel<%s, %s, %s>" % tuple("true" if v else "false" for v in info[:3])
     out = {
         "metric": "residual+Jacobian evals/sec (and ms/eval), 6-phase x 64-node LGR mesh",
         "value": evals / T, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * T / K, "ms_per_eval": 1e3 * T / (B * K), "higher_is_better": True,
         "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": a.workload, "phases": int(S), "nodes_per_phase": [int(n) for n in prob["num_nodes"]],
+        # the same K steps timed right after the W warm-up steps from an idle GPU, i.e. inside the chip's
+        # start-up power transient; `value` is the settled figure (config.settle_launches_before_warmup)
+        "value_cold": evals / T_cold, "ms_per_step_cold": 1e3 * T_cold / K,
+        "config": {"workload": a.workload + (" (residual only)" if a.residual_only else ""), "phases": int(S),
+                   "nodes_per_phase": [int(n) for n in prob["num_nodes"]],
                    "batch_per_gpu": B, "settle_launches_before_warmup": n_settle, "decision_vars": E.nvars, "residual_rows": E.nres,
-                   "jacobian_values_per_eval": E.V, "coo_nnz": E.total_nnz, "parallelism": ("phase+column shards x%d + all-reduce" if shard else "replicas x%d") % world,
-                   "output": "4 defect residuals + all x-dependent COO Jacobian values (compact), in HBM"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "gel::eval_kernel<true, true, false>",
-                     "kernel_ms": kern_ms, "algorithmic_bytes_per_eval": E.algorithmic_bytes,
-                     "algorithmic_bytes_per_launch": abytes,
-                     "note": "fp64-VALU-bound, not HBM-bound: ~5.8 VALU lane-instructions per algorithmic byte (libm chains); VALU floor ~57% of the HBM roofline, see DESIGN.md 3.1"},
+                   "jacobian_values_per_eval": 0 if a.residual_only else E.V, "coo_nnz": E.total_nnz,
+                   "parallelism": ("phase+column shards x%d + all-gather" if shard else "replicas x%d") % world,
+                   "output": ("4 defect residuals, in HBM" if a.residual_only else
+                              "4 defect residuals + all x-dependent COO Jacobian values (compact), in HBM")},
         "status": int(status),
     }
+    if not shard:
+        # one launch = B evals on this rank; HIP events on the launch stream over the K timed launches
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": None if traffic is None else
+                           "static: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                           "(2*FETCH_SIZE + WRITE_SIZE)*1024; not re-measured in this run)" % os.path.basename(tpath),
+                           "kernel": kname, "kernel_ms": kern_ms,
+                           "frac_cold": abytes / (kern_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_cold": kern_ms_cold,
+                           "algorithmic_bytes_per_eval": a_min, "algorithmic_bytes_per_launch": abytes,
+                           "note": "fp64-VALU-bound, not HBM-bound (libm chains of the RHS sweeps); see DESIGN.md 3.1"}
+    else:
+        out["shard"] = {"step_ms": kern_ms, "step_ms_cold": kern_ms_cold,
+                        "note": "one step = this rank's unit range (split-form kernel) + one all-gather of the owned "
+                                "slices; no roofline block: the step is exchange-latency bound, not a kernel figure"}
 
-    if not a.no_extras:
+    if not a.no_extras and not a.residual_only:
         # informational: materialise every COO value like the reference does (compact -> full expansion)
         try:
             Bf = min(B, 1024)
@@ -312,8 +367,10 @@ def main():
             out["aero_constraints"] = {"error": str(ex)}
 
     if not a.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(prob, D, tau, X, gpu_first)
-        out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        out["cpu_baseline"] = cpu_baseline(prob, D, tau, X, gpu_first, residual_only=a.residual_only)
+        # informational only (the roofline fraction is the kernel-quality figure): the GPU writes compact
+        # Jacobian values, the scalar port materialises every COO value
+        out["cpu_baseline"]["gpu_over_cpu_informational"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

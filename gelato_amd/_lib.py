@@ -71,6 +71,7 @@ SIGNATURES = {
                                          C.c_int32, C.c_void_p]),
     "gel_num_chunks": (C.c_int, [C.c_void_p, _ip]),
     "gel_chunk_phase": (C.c_int, [C.c_void_p, _ip]),
+    "gel_launch_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _ip]),
     "gel_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gel_jac_fd": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
     "gel_aero_configure": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _ip, _ip, _dp]),

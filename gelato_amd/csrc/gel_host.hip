@@ -838,6 +838,14 @@ int gel_chunk_phase(const gel_problem* p, int32_t* phase) {
   return GEL_OK;
 }
 
+int gel_launch_info(const gel_problem* p, int32_t B, int32_t want_res, int32_t want_jac, int32_t* info) {
+  if (!p || !info || B < 1) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  const gel::EvalForm f = gel::eval_form(p->dev, B, want_res != 0, want_jac != 0);
+  info[0] = f.jac; info[1] = f.mfma; info[2] = f.split; info[3] = (int32_t)std::min<long long>(f.waves, INT32_MAX);
+  return GEL_OK;
+}
+
 int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream) {
   if (!p || !d_jvar || !d_jfull || B < 1) return fail(GEL_ERR_ARG, "bad argument");
   NEED_DEVICE(p);

@@ -362,31 +362,39 @@ constexpr long long kSplitMaxWaves = 1024;
 
 static size_t table_lds_bytes(int Kw, int Kc) { return sizeof(double) * (size_t)(kAtmDoubles + 3 * Kw + 2 * Kc); }
 
+// which instantiation a launch takes (also reported through gel_launch_info)
+EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
+  EvalForm f;
+  const long long waves = (long long)B * P.nchunks;
+  f.jac = want_jac;
+  // D.X on the matrix pipe only when residual rows are requested at all and the problem asks for it
+  f.mfma = P.use_mfma && want_res;
+  // a handful of vectors cannot fill 1024 SIMDs: trade recomputation of the centre for a shorter serial chain;
+  // P.nunits > 0: the caller asked for a range of units (unit-sharded launch)
+  f.split = want_jac && (P.nunits > 0 || waves * 4 <= kSplitMaxWaves);
+  f.waves = f.split ? (long long)B * (P.nunits > 0 ? P.nunits : 4 * P.nchunks) : waves;
+  return f;
+}
+
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
   if (B <= 0) return hipSuccess;
-  const long long waves = (long long)B * P.nchunks;
-  const unsigned grid = (unsigned)((waves * 64 + kBlock - 1) / kBlock);
+  const EvalForm f = eval_form(P, B, d_res != nullptr, d_jvar != nullptr);
+  const unsigned grid = (unsigned)((f.waves * 64 + kBlock - 1) / kBlock);
   const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)PK_COUNT * kBlock);  // tables | per-lane park
-  // D.X on the matrix pipe only when residual rows are requested at all (d_res) and the problem asks for it
-  const bool mfma = P.use_mfma && d_res;
-  // a handful of vectors cannot fill 1024 SIMDs: trade recomputation of the centre for a shorter serial chain
-  if (d_jvar && (P.nunits > 0 || waves * 4 <= kSplitMaxWaves)) {
-    // P.nunits > 0: the caller asked for a range of units (unit-sharded launch); else the whole list, split
+  if (f.split) {
     ProblemDev Q = P;
-    if (Q.nunits <= 0) { Q.unit0 = 4 * P.chunk0; Q.nunits = 4 * P.nchunks; }
-    const long long w4 = (long long)B * Q.nunits;
-    const unsigned g4 = (unsigned)((w4 * 64 + kBlock - 1) / kBlock);
-    if (mfma)
-      hipLaunchKernelGGL((eval_kernel<true, true, true>), dim3(g4), dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
+    if (Q.nunits <= 0) { Q.unit0 = 4 * P.chunk0; Q.nunits = 4 * P.nchunks; }  // the whole list, split
+    if (f.mfma)
+      hipLaunchKernelGGL((eval_kernel<true, true, true>), dim3(grid), dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
     else
-      hipLaunchKernelGGL((eval_kernel<true, false, true>), dim3(g4), dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
+      hipLaunchKernelGGL((eval_kernel<true, false, true>), dim3(grid), dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
     return hipGetLastError();
   }
-  if (d_jvar && mfma)
+  if (f.jac && f.mfma)
     hipLaunchKernelGGL((eval_kernel<true, true>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
-  else if (d_jvar)
+  else if (f.jac)
     hipLaunchKernelGGL((eval_kernel<true, false>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
-  else if (mfma)
+  else if (f.mfma)
     hipLaunchKernelGGL((eval_kernel<false, true>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
   else
     hipLaunchKernelGGL((eval_kernel<false, false>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);

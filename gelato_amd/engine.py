@@ -211,6 +211,12 @@ class Engine:
     def expand_full_device(self, B, d_jvar, d_jfull, stream=0):
         check(lib().gel_expand_full_device(self._h, B, d_jvar, d_jfull, stream or None))
 
+    def launch_info(self, B, want_res=True, want_jac=True):
+        """-> [jacobian, mfma, split, wavefronts] of the kernel form a launch of B vectors takes"""
+        info = (C.c_int32 * 4)()
+        check(lib().gel_launch_info(self._h, int(B), int(bool(want_res)), int(bool(want_jac)), info))
+        return [int(v) for v in info]
+
     def sync(self, stream=0):
         return check(lib().gel_sync(self._h, stream or None))
 
