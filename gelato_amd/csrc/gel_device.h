@@ -60,13 +60,16 @@ struct ProblemDev {
   const int4* chunks;        // [nchunks] {phase, first node of the chunk, offset of its MFMA-ordered D in Dsw / 4, 0}:
                              // dearest phase type first for a whole launch, the natural (phase) order for a
                              // phase-sharded one
-  const double* Dsw;         // D in matrix-pipe feed order: [chunk][k-step][lane][row tile 0..3] (see gel_host.hip)
+  const double* Dsw;         // D in matrix-pipe feed order: [chunk][k-step][lane][row tile 0..3] (see gel_host.hip):
+                             // one wavefront feeds all four row tiles (split latency form)
+  const double* Dst;         // the same values as [chunk][k-step][row tile 0..3][lane]: wavefront w of a workgroup
+                             // feeds row tile w only (cooperative throughput form), 512 contiguous bytes per k-step
   int64_t V;                 // compact entries per eval
   const PhaseDev* phases;    // [S]
   const int32_t* node_phase; // [N]
   const double* Dt;          // per phase, transposed: Dt[doff + i*n + j] = D[j][i]
   const double* tau;         // per phase
-  const double* tables;      // atm[44] | wind[Kw*3] | ca[Kc*2]
+  const double* tables;      // atm[77] (gel_physics.h kAtmDoubles) | wind[Kw*3] | ca[Kc*2]
   int32_t* flag;             // non-finite flag
   double um, up, uv, uu, ut, dx, barC20;
 };

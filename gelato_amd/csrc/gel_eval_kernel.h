@@ -34,12 +34,28 @@ enum ParkSlot { PK_Q0 = 0, PK_Q1, PK_Q2, PK_Q3, PK_V0, PK_V1, PK_V2, PK_DJJ, PK_
 constexpr int kStageLd = 17;                     // padded row of the staging tile: conflict-free row reads
 constexpr int kWaveLds = PK_COUNT * 64;          // doubles per wavefront
 static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wave's park region");
+// Workgroup-cooperative D.X (throughput form): the 64 x 11 result rows of decision vector b are handed to
+// wavefront b through slots PK_LV0 .. PK_FP7 of ITS OWN region ([node][11], stride 11 doubles: conflict-free row
+// reads); slots PK_Q0 .. PK_DJJ are never touched by the hand-over, so a wavefront may park there while slower
+// wavefronts of its workgroup still write their tiles.
+constexpr int kCoopStageOff = PK_LV0 * 64;
+static_assert(kWaveLds - kCoopStageOff >= 64 * 11, "the cooperative hand-over area must fit behind the early park slots");
 
 #ifndef GEL_MIN_WAVES_PER_SIMD
 #define GEL_MIN_WAVES_PER_SIMD 4  // 112 VGPRs, no scratch: 4 waves/SIMD (16 per CU, matching the LDS budget); 5 spills
 #endif
 
 typedef double gel_double4 __attribute__((ext_vector_type(4)));
+
+// k-steps of D.X operands in flight ahead of the matrix pipe (cooperative form).  Measured (dense-6x64, B = 16384,
+// same box): the residual-only launch is 5 % shorter with 4 than with 1; the fused launch is 2-3 % LONGER (its other
+// wavefronts already cover the latency, and the extra live registers cost more than the overlap gains).
+#ifndef GEL_DX_PF_JAC
+#define GEL_DX_PF_JAC 1
+#endif
+#ifndef GEL_DX_PF_RES
+#define GEL_DX_PF_RES 4
+#endif
 
 #ifndef GEL_STORE_AUX
 #define GEL_STORE_AUX 2  // cache policy of the Jacobian stores: 2 = nt (A/B: 0 plain, 1 sc0, 16 sc1, 18 sc1+nt)
@@ -62,16 +78,26 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   lds_double* park = wave_lds + lane;
 #define PARK(slot) park[(slot) * 64]
 
-  const long long item = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
-  if (item >= (long long)B * (SPLIT ? P.nunits : P.nchunks)) return;
+  // COOP: the throughput form with D.X on the matrix pipe.  A workgroup = ONE work item x FOUR decision vectors;
+  // its wavefronts share the A operand (D) and form the product together (see phase A).
+  constexpr bool COOP = MFMA && !SPLIT;
+  static_assert(!COOP || kBlock == 256, "the cooperative D.X form is written for four wavefronts per workgroup");
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nb4 = (B + 3) >> 2;  // COOP: workgroups per work item
+  const long long item = COOP ? 0 : __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
+  if (!COOP && item >= (long long)B * (SPLIT ? P.nunits : P.nchunks)) return;
   // work-item major: all B vectors of one (phase, chunk) are neighbours, so the four wavefronts of a
   // workgroup cost the same (its LDS is only released when the slowest ends), and the list is ordered
   // dearest phase type first, so the tail of the launch drains with cheap wavefronts (measured -4 % on
   // the mixed vehicle at B = 4096, -6..9 % at B = 2048)
   // SPLIT: the list is walked in units = (work item, part), unit id = 4 * item + part, again with all B vectors
   // of a unit next to each other; P.unit0 / P.nunits select a range of units (unit-sharded launches)
-  const int q = (int)(item / B);
-  const int b = (int)(item - (long long)q * B);
+  const int q = COOP ? (int)(blockIdx.x / (unsigned)nb4) : (int)(item / B);
+  const int b0 = COOP ? (int)(blockIdx.x - (unsigned)q * (unsigned)nb4) * 4 : 0;  // first vector of the workgroup
+  // COOP: a wavefront past the end of the batch (B not a multiple of 4) still computes its row tile for the
+  // others; it reads vector B - 1 and leaves after the hand-over without writing anything
+  const bool ghost = COOP && b0 + wv >= B;
+  const int b = COOP ? min(b0 + wv, B - 1) : (int)(item - (long long)q * B);
   const int ci = SPLIT ? ((P.unit0 + q) >> 2) : q;
   const int part = SPLIT ? ((P.unit0 + q) & 3) : 0;  // wave-uniform
   const int4 ck = P.chunks[(SPLIT ? 0 : P.chunk0) + ci];
@@ -134,6 +160,11 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     chk += _v;                                                                          \
   } while (0)
 #endif
+#ifdef GEL_ABL_NORES  // ablation: residual rows computed, not stored
+#define RSTORE(idx, val) do { if ((val) == 1.2345e300) rb[idx] = (val); } while (0)
+#else
+#define RSTORE(idx, val) rb[idx] = (val)
+#endif
   // Jacobian entry from a perturbed/centre pair: -(f_p - f_c)/dx*(tf-to)*unit_t/2  (con_dynamics.py:372),
   // as (f_c - f_p) times the wave-uniform scale (tf-to)*unit_t/2/dx
   const double inv_dx = 1.0 / dx;
@@ -156,7 +187,89 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     // D.X rows (lib/con_dynamics.py:54,146,256,524)
     double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
     if (rb) {
-      if (MFMA) {
+      if (COOP) {
+        // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP: A = the work item's rows of D, shared by all four wavefronts;
+        // B = the 11 state columns of the workgroup's four decision vectors side by side (44 of 48 columns used,
+        // against 11 of 16 when every wavefront multiplies alone).  Wavefront w forms row tile w (16 nodes) for all
+        // three column tiles: 3 x ceil((n+1)/4) v_mfma_f64_16x16x4_f64 instead of 4 x, and it fetches a quarter of
+        // D (one coalesced 512-byte row-tile slab per k-step, ProblemDev::Dst).  Operand layout
+        // (cdna_hip_programming.md section 3): A lane l = A[row l&15][k l>>4], B lane l = B[k l>>4][col l&15],
+        // C/D reg i of lane l = C[row (l>>4)+4i][col l&15].
+        const int c16 = lane & 15, kq = lane >> 4;
+        const double* bp[3];
+        unsigned bs[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) {
+          const int c = 16 * ct + c16;            // packed column: vector c / 11, state column c % 11
+          const int vb = min(c / 11, 3);          // columns 44..47 are padding: computed on vector 3, never read
+          const int col = (c < 44) ? c - 11 * vb : 0;
+          const double* xo = x + (size_t)min(b0 + vb, B - 1) * P.nvars;
+          // state column = one of the 11 interleaved columns (mass | pos xyz | vel xyz | quat wxyz)
+          bp[ct] = xo + ph.xa; bs[ct] = 1;
+          if (col >= 1 && col < 4) { bp[ct] = xo + M + 3 * ph.xa + (col - 1); bs[ct] = 3; }
+          if (col >= 4 && col < 7) { bp[ct] = xo + 4 * M + 3 * ph.xa + (col - 4); bs[ct] = 3; }
+          if (col >= 7) { bp[ct] = xo + 7 * M + 4 * ph.xa + (col - 7); bs[ct] = 4; }
+        }
+        gel_double4 acc[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
+        // columns past n hold zeros in Dst, so B is only clamped, never masked
+        const double* ap = P.Dst + (size_t)dsw * 4 + wv * 64 + lane;
+        const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4)
+        const unsigned un = (unsigned)n;
+        // Software pipeline: the operands of k-step ks + kPF are requested while k-step ks multiplies.  Without
+        // it every k-step waits a full memory latency (x comes from HBM on first touch) before its three MFMAs.
+        // Requests past the last k-step repeat it (valid addresses, results unused).
+        constexpr int kPF = JAC ? GEL_DX_PF_JAC : GEL_DX_PF_RES;
+        double ra[kPF], rb0[kPF], rb1[kPF], rb2[kPF];
+#define GEL_DX_LOAD(slot, kstep)                                  \
+  do {                                                            \
+    const int _ks = min((kstep), ksteps - 1);                     \
+    const unsigned _k = min(4u * _ks + kq, un);                   \
+    ra[slot] = ap[_ks * 256];                                     \
+    rb0[slot] = bp[0][_k * bs[0]];                                \
+    rb1[slot] = bp[1][_k * bs[1]];                                \
+    rb2[slot] = bp[2][_k * bs[2]];                                \
+  } while (0)
+#pragma unroll
+        for (int i = 0; i < kPF; i++) GEL_DX_LOAD(i, i);
+#ifdef GEL_ABL_NODX  // ablation (tools/build_variants.sh): no D.X product
+        for (int ks = 0; ks < 0; ks += kPF) {
+#else
+        for (int ks = 0; ks < ksteps; ks += kPF) {
+#endif
+#pragma unroll
+          for (int i = 0; i < kPF; i++) {
+            if (ks + i < ksteps) {  // wave-uniform
+              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i], rb0[i], acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i], rb1[i], acc[1], 0, 0, 0);
+              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i], rb2[i], acc[2], 0, 0, 0);
+            }
+            GEL_DX_LOAD(i, ks + i + kPF);
+          }
+        }
+#undef GEL_DX_LOAD
+        // hand-over: the rows of vector vb go to wavefront vb's own region ([node][11] behind its early park slots)
+        lds_double* wg_lds = (lds_double*)lds + P.park_off + kCoopStageOff;
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) {
+          const int c = 16 * ct + c16;
+          const int vb = c / 11, col = c - 11 * vb;
+          if (c < 44) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) wg_lds[vb * kWaveLds + (16 * wv + kq + 4 * i) * 11 + col] = acc[ct][i];
+          }
+        }
+        __syncthreads();
+        if (ghost) return;
+        lds_double* row = wave_lds + kCoopStageOff + lane * 11;
+        lm = row[0];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
+#pragma unroll
+        for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
+      } else if (MFMA) {
+        // SPLIT (latency form): one wavefront multiplies alone.
         // [64 x (n+1)] . [(n+1) x 11] per wavefront as 4 row tiles of v_mfma_f64_16x16x4_f64.
         // Operand layout (cdna_hip_programming.md section 3): A lane l = A[row l&15][k l>>4],
         // B lane l = B[k l>>4][col l&15], C/D reg i of lane l = C[row (l>>4)+4i][col l&15].
@@ -248,7 +361,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         for (int c = 0; c < 4; c++) {
           const double rh = fq[c] * (tf - to) * ut / 2.0;
           const double cq = lq[c] - rh;
-          rb[7 * N + 4 * g + c] = cq;  // ordinary store: the interleaved residual rows are partial lines that
+          RSTORE(7 * N + 4 * g + c, cq);  // ordinary store: the interleaved residual rows are partial lines that
           chk += cq;                   // L2 merges; written non-temporally they cost 4 % more HBM writes (PMC)
         }
       }
@@ -287,20 +400,20 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
       } else {
         cm = me - m0;
       }
-      rb[g] = cm;
+      RSTORE(g, cm);
       chk += cm;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const double rh = ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
         const double cp = lr[c] - rh;
-        rb[N + 3 * g + c] = cp;
+        RSTORE(N + 3 * g + c, cp);
         chk += cp;
       }
       if (ph.hold) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const double cq = q[c] - q0[c];
-          rb[7 * N + 4 * g + c] = cq;
+          RSTORE(7 * N + 4 * g + c, cq);
           chk += cq;
         }
       }
@@ -324,7 +437,11 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
       PosPart pp;
       double v[3], dir[3], w[3], F[3], T, fp8 = 0.0;
 #pragma unroll 1
+#ifdef GEL_ABL_NOPOS  // ablation: no position sweeps (their Jacobian slots are written with whatever the park holds)
+      for (int k = 3;; k = SPLIT ? 3 : k + 1) {
+#else
       for (int k = SPLIT ? (part ? part - 1 : 3) : (JAC ? 0 : 3);; k = SPLIT ? 3 : k + 1) {
+#endif
         double r[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
@@ -332,7 +449,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] = PARK(PK_V0 + c) * P.uv;
-        aero_force(r, v, pp.rho, pp.a, ea, w, ph.area, tb, F);
+        aero_force(r, v, pp.rho, pp.inv_a, ea, w, ph.area, tb, F);
         T = ph.thrust - ph.nozzle * pp.P;
         {
           const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
@@ -385,7 +502,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
             double vp[3], Fp[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) vp[c] = ((k == c) ? (PARK(PK_V0 + c) + dx) : PARK(PK_V0 + c)) * P.uv;
-            aero_force(r, vp, pp.rho, pp.a, ea, w, ph.area, tb, Fp);
+            aero_force(r, vp, pp.rho, pp.inv_a, ea, w, ph.area, tb, Fp);
             accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
             // submat_vel[3j+c, 3(j+1)+k] = D[j][j+1]*(c==k) + rh_vel   (con_dynamics.py:341-343,415-416)
 #pragma unroll
@@ -418,7 +535,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
           // quaternion, D[j][j+1] and force slots are free now: the rest of what these two sweeps need is
           // parked there, so that only the node position lives in registers across the sincos chains of
           // earth_angle()
-          PARK(PK_Q0) = pp.rho; PARK(PK_Q1) = pp.a; PARK(PK_Q2) = Tdc[0]; PARK(PK_Q3) = Tdc[1]; PARK(PK_DJJ) = Tdc[2];
+          PARK(PK_Q0) = pp.rho; PARK(PK_Q1) = pp.inv_a; PARK(PK_Q2) = Tdc[0]; PARK(PK_Q3) = Tdc[1]; PARK(PK_DJJ) = Tdc[2];
           PARK(PK_FP5) = pp.g[0]; PARK(PK_FP6) = pp.g[1]; PARK(PK_FP7) = pp.g[2];
 #pragma unroll 1
           for (int k = 0; k < 2; k++) {
@@ -506,12 +623,13 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     for (int c = 0; c < 3; c++) {
       const double rh = fc[c] * (tf - to) * ut / 2.0;
       const double cv = PARK(PK_LV0 + c) - rh;
-      rb[4 * N + 3 * g + c] = cv;
+      RSTORE(4 * N + 3 * g + c, cv);
       chk += cv;
     }
   }
 
 #undef EMIT
+#undef RSTORE
 #undef FDQ
 #undef PARK
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1

@@ -145,6 +145,7 @@ struct gel_problem {
   int4* d_chunks = nullptr;         // work items in phase order (what gel_chunk_phase / shard ranges index)
   int4* d_chunks_sorted = nullptr;  // the same items, dearest phase type first (whole launches)
   double* d_Dsw = nullptr;          // D per work item in the feed order of v_mfma_f64_16x16x4_f64
+  double* d_Dst = nullptr;          // the same, row-tile major (one wavefront per row tile)
   double* d_Dt = nullptr;
   double* d_tau = nullptr;
   double* d_tables = nullptr;
@@ -481,7 +482,37 @@ void fill_atmosphere_table(double* atm) {
     atm[55 + k] = g0 / R;
     static const double hb[11] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0, 86000.0, 91000.0, 110000.0, 120000.0};
     atm[66 + k] = hb[k];  // src/Air.cpp:29-30
+    atm[77 + k] = 1.0 / tmb[k];
   }
+}
+
+// validates the interpolation tables (np.interp's precondition; the bracket search and the tabulated slopes of
+// the device lookup rely on >= 2 rows and strictly increasing abscissae) -- nullptr if fine, else the complaint
+const char* check_tables(const double* wind, int Kw, const double* ca, int Kc) {
+  if (!wind || !ca || Kw < 2 || Kc < 2) return "wind and CA tables need at least two rows";
+  for (int k = 1; k < Kw; k++)
+    if (!(wind[3 * k] > wind[3 * (k - 1)])) return "wind table altitudes must increase strictly";
+  for (int k = 1; k < Kc; k++)
+    if (!(ca[2 * k] > ca[2 * (k - 1)])) return "CA table Mach numbers must increase strictly";
+  return nullptr;
+}
+
+// rows [K][w] followed by the slopes (y[k+1][c] - y[k][c]) / (x[k+1] - x[k]) of every interval, c = 1..w-1
+void append_rows_and_slopes(std::vector<double>& rows_out, std::vector<double>& slopes_out, const double* tab, int K, int w) {
+  rows_out.insert(rows_out.end(), tab, tab + (size_t)K * w);
+  for (int k = 0; k + 1 < K; k++)
+    for (int c = 1; c < w; c++)
+      slopes_out.push_back((tab[(size_t)(k + 1) * w + c] - tab[(size_t)k * w + c]) / (tab[(size_t)(k + 1) * w] - tab[(size_t)k * w]));
+}
+
+// atmosphere | wind rows | CA rows | wind slopes | CA slopes  (gel_physics.h table_doubles())
+std::vector<double> build_tables(const double* wind, int Kw, const double* ca, int Kc) {
+  std::vector<double> t(kAtmTableDoubles), slopes;
+  fill_atmosphere_table(t.data());
+  append_rows_and_slopes(t, slopes, wind, Kw, 3);
+  append_rows_and_slopes(t, slopes, ca, Kc, 2);
+  t.insert(t.end(), slopes.begin(), slopes.end());
+  return t;
 }
 }  // namespace gel
 
@@ -510,12 +541,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
       !d->engine_on || !d->attitude_hold || !d->wind_table || !d->ca_table || d->wind_rows < 2 || d->ca_rows < 2)
     return fail(GEL_ERR_ARG, "incomplete problem description");
   if (!(d->dx > 0.0)) return fail(GEL_ERR_ARG, "dx must be positive");
-  // interpolation tables: strictly increasing abscissae (np.interp's precondition; the bracket search and the
-  // guard-free division of the device lookup rely on distinct knots)
-  for (int k = 1; k < d->wind_rows; k++)
-    if (!(d->wind_table[3 * k] > d->wind_table[3 * (k - 1)])) return fail(GEL_ERR_ARG, "wind table altitudes must increase strictly");
-  for (int k = 1; k < d->ca_rows; k++)
-    if (!(d->ca_table[2 * k] > d->ca_table[2 * (k - 1)])) return fail(GEL_ERR_ARG, "CA table Mach numbers must increase strictly");
+  if (const char* why = gel::check_tables(d->wind_table, d->wind_rows, d->ca_table, d->ca_rows)) return fail(GEL_ERR_ARG, why);
   for (int i = 0; i < d->num_sections; i++)
     if (d->num_nodes[i] < 2) return fail(GEL_ERR_ARG, "every phase needs >= 2 LGR nodes (nodes_LGR requires n >= 2)");
   // device == GEL_DEVICE_NONE: a host-only handle (dims, LGR data, sparsity pattern, constant values,
@@ -624,17 +650,14 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     tau.insert(tau.end(), h.tau.begin(), h.tau.end());
     for (int j = 0; j < h.n; j++) node_phase[h.ua + j] = i;
   }
-  std::vector<double> tables(gel::kAtmTableDoubles + 3 * (size_t)d->wind_rows + 2 * (size_t)d->ca_rows);
-  gel::fill_atmosphere_table(tables.data());
-  std::memcpy(tables.data() + gel::kAtmTableDoubles, d->wind_table, sizeof(double) * 3 * d->wind_rows);
-  std::memcpy(tables.data() + gel::kAtmTableDoubles + 3 * d->wind_rows, d->ca_table, sizeof(double) * 2 * d->ca_rows);
+  const std::vector<double> tables = gel::build_tables(d->wind_table, d->wind_rows, d->ca_table, d->ca_rows);
   // Work items, and D laid out the way the matrix pipe consumes it.  A operand of v_mfma_f64_16x16x4_f64:
   // lane l holds A[row l & 15][k l >> 4]; a wavefront covers 64 nodes = 4 row tiles, and k-step ks covers
   // columns 4 ks .. 4 ks + 3 of D.  Dsw[((item_off + ks) * 64 + l) * 4 + t] = D[j0 + 16 t + (l & 15)][4 ks + (l >> 4)]
   // (0 beyond column n; rows beyond the phase repeat its last row: computed, never read back), so that one lane
   // fetches its four tile operands of a k-step with a single 32-byte access at a fixed stride.
   std::vector<int4> chunks;
-  std::vector<double> Dsw;
+  std::vector<double> Dsw, Dst;
   for (int i = 0; i < S; i++) {
     const HostPhase& h = p->ph[i];
     const int n = h.n, ksteps = (n + 4) >> 2;
@@ -646,6 +669,13 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
             const int k = 4 * ks + (l >> 4), row = std::min(j0 + 16 * t + (l & 15), n - 1);
             Dsw.push_back(k <= n ? h.D[(size_t)row * (n + 1) + k] : 0.0);
           }
+      // Dst[((item_off + ks) * 4 + t) * 64 + l]: the same element, row tile t contiguous over the lanes
+      for (int ks = 0; ks < ksteps; ks++)
+        for (int t = 0; t < 4; t++)
+          for (int l = 0; l < 64; l++) {
+            const int k = 4 * ks + (l >> 4), row = std::min(j0 + 16 * t + (l & 15), n - 1);
+            Dst.push_back(k <= n ? h.D[(size_t)row * (n + 1) + k] : 0.0);
+          }
     }
   }
 
@@ -656,7 +686,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   std::stable_sort(sorted_chunks.begin(), sorted_chunks.end(), [&](const int4& a, const int4& b) { return weight(a) > weight(b); });
 
   int rc = GEL_OK;
-  if ((rc = upload(&p->d_chunks, chunks)) || (rc = upload(&p->d_chunks_sorted, sorted_chunks)) || (rc = upload(&p->d_Dsw, Dsw)) || (rc = upload(&p->d_phases, dph)) || (rc = upload(&p->d_node_phase, node_phase)) || (rc = upload(&p->d_Dt, Dt)) ||
+  if ((rc = upload(&p->d_chunks, chunks)) || (rc = upload(&p->d_chunks_sorted, sorted_chunks)) || (rc = upload(&p->d_Dsw, Dsw)) || (rc = upload(&p->d_Dst, Dst)) || (rc = upload(&p->d_phases, dph)) || (rc = upload(&p->d_node_phase, node_phase)) || (rc = upload(&p->d_Dt, Dt)) ||
       (rc = upload(&p->d_tau, tau)) || (rc = upload(&p->d_tables, tables)) || (rc = upload(&p->d_cval, p->cval)) ||
       (rc = upload(&p->d_src, p->src))) {
     gel_problem_destroy(p);
@@ -672,7 +702,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   dv.S = S; dv.N = N; dv.M = M; dv.nvars = dm.num_vars; dv.Kw = d->wind_rows; dv.Kc = d->ca_rows; dv.V = V;
   dv.phases = p->d_phases; dv.node_phase = p->d_node_phase; dv.Dt = p->d_Dt; dv.tau = p->d_tau; dv.tables = p->d_tables;
   dv.flag = p->d_flag;
-  dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks_sorted; dv.Dsw = p->d_Dsw;
+  dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks_sorted; dv.Dsw = p->d_Dsw; dv.Dst = p->d_Dst;
   dv.park_off = (int32_t)((tables.size() + 1) / 2 * 2);
   {
     // D.X path: the matrix pipe runs beside the fp64 VALU pipe that bounds this kernel, so the MFMA form
@@ -692,7 +722,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->device == GEL_DEVICE_NONE) { delete p; return GEL_OK; }
   hipSetDevice(p->device);
   if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
-  hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dsw); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
+  hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dsw); hipFree(p->d_Dst); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag);
   for (int k = 0; k < 3; k++) hipFree(p->d_aero_rows[k]);
   free_slots(p);
@@ -949,10 +979,8 @@ int gel_dynamics_velocity(int32_t n, const double* mass_e, const double* pos_e, 
   if (n == 0) return GEL_OK;
   int rc = need_device();
   if (rc) return rc;
-  std::vector<double> tables(gel::kAtmTableDoubles + 3 * (size_t)Kw + 2 * (size_t)Kc);
-  gel::fill_atmosphere_table(tables.data());
-  std::memcpy(tables.data() + gel::kAtmTableDoubles, wind, sizeof(double) * 3 * Kw);
-  std::memcpy(tables.data() + gel::kAtmTableDoubles + 3 * Kw, ca, sizeof(double) * 2 * Kc);
+  if (const char* why = gel::check_tables(wind, Kw, ca, Kc)) return fail(GEL_ERR_ARG, why);
+  const std::vector<double> tables = gel::build_tables(wind, Kw, ca, Kc);
   DevBuf m, r, v, q, tt, tb, o;
   if ((rc = m.put(mass_e, n)) || (rc = r.put(pos_e, 3 * (size_t)n)) || (rc = v.put(vel_e, 3 * (size_t)n)) ||
       (rc = q.put(quat, 4 * (size_t)n)) || (rc = tt.put(t, n)) || (rc = tb.put(tables.data(), tables.size())) ||
@@ -1108,10 +1136,19 @@ int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux,
   double atm[gel::kAtmTableDoubles];
   size_t naux = 0;
   const double* hax = aux;
+  std::vector<double> ext;  // kinds 5 / 6: the table rows followed by their per-interval slopes
   if (kind == 0) { gel::fill_atmosphere_table(atm); hax = atm; naux = gel::kAtmTableDoubles; aux_rows = 0; }
   else if (kind == 2) { if (!aux) return fail(GEL_ERR_ARG, "kind 2 needs aux[0] = barC20"); naux = 1; aux_rows = 0; }
-  else if (kind == 5) { if (!aux || aux_rows < 2) return fail(GEL_ERR_ARG, "kind 5 needs a wind table"); naux = 3 * (size_t)aux_rows; }
-  else if (kind == 6) { if (!aux || aux_rows < 2) return fail(GEL_ERR_ARG, "kind 6 needs a table"); naux = 2 * (size_t)aux_rows; }
+  else if (kind == 5 || kind == 6) {
+    const int w = (kind == 5) ? 3 : 2;
+    if (!aux || aux_rows < 2) return fail(GEL_ERR_ARG, "kinds 5 and 6 need a table of at least two rows");
+    for (int k = 1; k < aux_rows; k++)
+      if (!(aux[(size_t)w * k] > aux[(size_t)w * (k - 1)])) return fail(GEL_ERR_ARG, "table abscissae must increase strictly");
+    std::vector<double> slopes;
+    gel::append_rows_and_slopes(ext, slopes, aux, aux_rows, w);
+    ext.insert(ext.end(), slopes.begin(), slopes.end());
+    hax = ext.data(); naux = ext.size();
+  }
   else { aux_rows = 0; }
   DevBuf i, a, o;
   if ((rc = i.put(in, (size_t)n * nin[kind])) || (rc = a.put(hax, naux)) || (rc = o.put(nullptr, (size_t)n * nout[kind]))) return rc;

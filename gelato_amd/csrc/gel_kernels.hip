@@ -31,17 +31,23 @@ namespace gel {
 constexpr int kBlock = GEL_BLOCK;  // threads per workgroup of the fused kernel (a multiple of 64)
 static_assert(kAtmDoubles == kAtmTableDoubles, "atmosphere table size mismatch between host and device");
 
+GEL_DEV Tables table_view(const double* base, int Kw, int Kc) {
+  Tables tb;
+  tb.atm = base;
+  tb.wind = base + kAtmDoubles;
+  tb.ca = tb.wind + 3 * Kw;
+  tb.winds = tb.ca + 2 * Kc;
+  tb.cas = tb.winds + 2 * (Kw - 1);
+  tb.Kw = Kw;
+  tb.Kc = Kc;
+  return tb;
+}
+
 GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds) {
-  const int ntab = kAtmDoubles + 3 * P.Kw + 2 * P.Kc;
+  const int ntab = table_doubles(P.Kw, P.Kc);
   for (int i = threadIdx.x; i < ntab; i += blockDim.x) lds[i] = P.tables[i];
   __syncthreads();
-  Tables tb;
-  tb.atm = lds;
-  tb.wind = lds + kAtmDoubles;
-  tb.ca = lds + kAtmDoubles + 3 * P.Kw;
-  tb.Kw = P.Kw;
-  tb.Kc = P.Kc;
-  return tb;
+  return table_view(lds, P.Kw, P.Kc);
 }
 
 }  // namespace gel
@@ -138,7 +144,7 @@ __global__ void rhs_vel_air_kernel(RhsArgs A) {
   const EarthAngle ea = earth_angle(A.t[i]);
   double w[3], F[3], dir[3], f[3];
   wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
-  aero_force(r, v, pp.rho, pp.a, ea, w, A.area, tb, F);
+  aero_force(r, v, pp.rho, pp.inv_a, ea, w, A.area, tb, F);
   thrust_dir(q, dir);
   const double T = A.thrust - A.nozzle * pp.P;
   const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
@@ -172,7 +178,8 @@ __global__ void rhs_quat_kernel(int n, const double* quat, const double* u_e, do
 __global__ void point_kernel(int kind, int n, const double* in, const double* aux, int aux_rows, double* out) {
   extern __shared__ double lds[];
   // aux table (wind [K][3] or generic [K][2]) and the atmosphere table are staged in LDS
-  const int naux = (kind == 5) ? 3 * aux_rows : (kind == 6) ? 2 * aux_rows : (kind == 0 ? kAtmDoubles : 0);
+  // kinds 5 / 6: rows followed by the per-interval slopes (built by the host entry point)
+  const int naux = (kind == 5) ? 3 * aux_rows + 2 * (aux_rows - 1) : (kind == 6) ? 2 * aux_rows + (aux_rows - 1) : (kind == 0 ? kAtmDoubles : 0);
   for (int i = threadIdx.x; i < naux; i += blockDim.x) lds[i] = aux[i];
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,8 +192,8 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
     } break;
     case 1: {
       // latitude and altitude exactly as pos_part forms them; angles reported in degrees
-      double lat, sl, cl, p;
-      geodetic_lat_p(in[3 * i], in[3 * i + 1], in[3 * i + 2], lat, p);
+      double lat, sl, cl, p, ip;
+      geodetic_lat_p(in[3 * i], in[3 * i + 1], in[3 * i + 2], lat, p, ip);
       fsincos(lat, &sl, &cl);
       const double lon = atan2(in[3 * i + 1], in[3 * i]);
       out[3 * i] = lat * 180.0 / kPi; out[3 * i + 1] = lon * 180.0 / kPi;
@@ -202,12 +209,13 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       // wind vector NED -> ECI exactly as the hot path does it: in = pos[3], t, wn, we
       const double* a = in + 6 * i;
       const double r[3] = {a[0], a[1], a[2]};
-      double lat, sl, cl, p, w[3];
-      geodetic_lat_p(r[0], r[1], r[2], lat, p);
+      double lat, sl, cl, p, ip, w[3];
+      geodetic_lat_p(r[0], r[1], r[2], lat, p, ip);
       fsincos(lat, &sl, &cl);
       const EarthAngle ea = earth_angle(a[3]);
-      const double chp = sqrt(0.5 * (1.0 + cl)), shp = 0.5 * sl / chp;
-      wind_eci(r, ea, shp, chp, 1.0 / p, a[4], a[5], w);
+      double chp, irt;
+      fsqrt_rsqrt(0.5 * (1.0 + cl), chp, irt);
+      wind_eci(r, ea, (0.5 * sl) * irt, chp, ip, a[4], a[5], w);
       out[3 * i] = w[0]; out[3 * i + 1] = w[1]; out[3 * i + 2] = w[2];
     } break;
     case 4: {
@@ -221,10 +229,10 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
     } break;
     case 5: {
       double wn, we;
-      wind_ned2(in[i], lds, aux_rows, wn, we);
+      wind_ned2(in[i], lds, lds + 3 * aux_rows, aux_rows, wn, we);
       out[3 * i] = wn; out[3 * i + 1] = we; out[3 * i + 2] = 0.0;
     } break;
-    case 6: out[i] = interp_tab(in[i], lds, aux_rows, 2, 1); break;
+    case 6: out[i] = interp_tab(in[i], lds, lds + 2 * aux_rows, aux_rows, 2, 1); break;
     case 7: {  // the path's guard-free sqrt / division beside the compiler's, for the bit-identity test
       const double a = in[2 * i], b = in[2 * i + 1];
       out[4 * i] = fsqrt(a); out[4 * i + 1] = sqrt(a); out[4 * i + 2] = fdiv(a, b); out[4 * i + 3] = a / b;
@@ -253,15 +261,16 @@ GEL_DEV double aero_value(int kind, const double re[3], const double ve[3], cons
   const double v[3] = {ve[0] * P.uv, ve[1] * P.uv, ve[2] * P.uv};
   const double t = t_e * P.ut;
   // air-relative velocity in ECI: wrapper_utils.hpp:93-100 (same chain as the RHS)
-  double lat, p, sl, cl;
-  geodetic_lat_p(r[0], r[1], r[2], lat, p);
+  double lat, p, ip, sl, cl;
+  geodetic_lat_p(r[0], r[1], r[2], lat, p, ip);
   fsincos(lat, &sl, &cl);
   const double h = geopotential_altitude(geodetic_alt_from(p, sl, cl));
   double wn, we, w[3];
-  wind_ned2(h, tb.wind, tb.Kw, wn, we);
+  wind_ned2(h, tb.wind, tb.winds, tb.Kw, wn, we);
   const EarthAngle ea = earth_angle(t);
-  const double chp = sqrt(0.5 * (1.0 + cl)), shp = 0.5 * sl / chp;
-  wind_eci(r, ea, shp, chp, 1.0 / p, wn, we, w);
+  double chp, irt;
+  fsqrt_rsqrt(0.5 * (1.0 + cl), chp, irt);
+  wind_eci(r, ea, (0.5 * sl) * irt, chp, ip, wn, we, w);
   const double d0 = v[0] + kOmega * r[1], d1 = v[1] - kOmega * r[0];
   const double e0 = d0 * ea.c + d1 * ea.s, e1 = -d0 * ea.s + d1 * ea.c;
   const double a0 = (e0 * ea.c - e1 * ea.s) - w[0], a1 = (e0 * ea.s + e1 * ea.c) - w[1], a2 = v[2] - w[2];
@@ -344,7 +353,7 @@ hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDe
                        double* d_con, double* d_jac, hipStream_t s) {
   if (B <= 0 || nrows <= 0) return hipSuccess;
   const long long threads = (long long)B * nrows;
-  const size_t lds = sizeof(double) * (size_t)(kAtmDoubles + 3 * P.Kw + 2 * P.Kc);
+  const size_t lds = sizeof(double) * staged_table_doubles(P.Kw, P.Kc);
   if (d_jac && threads * 13 <= 64 * 1024)  // fits one wavefront per SIMD even when split: take the short chain
     hipLaunchKernelGGL(aero_kernel<true>, dim3((unsigned)((threads * 13 + 63) / 64)), dim3(64), lds, s, P, kind, nrows,
                        rows, B, d_x, d_con, d_jac);
@@ -360,7 +369,7 @@ hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDe
 // launches with at most this many wavefronts (after the x4) use the split latency form: one per SIMD
 constexpr long long kSplitMaxWaves = 1024;
 
-static size_t table_lds_bytes(int Kw, int Kc) { return sizeof(double) * (size_t)(kAtmDoubles + 3 * Kw + 2 * Kc); }
+static size_t table_lds_bytes(int Kw, int Kc) { return sizeof(double) * staged_table_doubles(Kw, Kc); }
 
 // which instantiation a launch takes (also reported through gel_launch_info)
 EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
@@ -379,7 +388,9 @@ EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
   if (B <= 0) return hipSuccess;
   const EvalForm f = eval_form(P, B, d_res != nullptr, d_jvar != nullptr);
-  const unsigned grid = (unsigned)((f.waves * 64 + kBlock - 1) / kBlock);
+  // cooperative D.X form (matrix pipe, not split): one workgroup = one work item x four decision vectors
+  const unsigned grid = (f.mfma && !f.split) ? (unsigned)P.nchunks * (unsigned)((B + 3) / 4)
+                                             : (unsigned)((f.waves * 64 + kBlock - 1) / kBlock);
   const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)PK_COUNT * kBlock);  // tables | per-lane park
   if (f.split) {
     ProblemDev Q = P;
@@ -449,7 +460,7 @@ hipError_t launch_rhs_quat(int n, const double* quat, const double* u_e, double 
 
 hipError_t launch_point(int kind, int n, const double* in, const double* aux, int aux_rows, double* out,
                         hipStream_t s) {
-  const size_t lds = sizeof(double) * (size_t)(kAtmDoubles + 3 * (aux_rows > 0 ? aux_rows : 0));
+  const size_t lds = sizeof(double) * (size_t)(kAtmDoubles + 5 * (aux_rows > 0 ? aux_rows : 0));
   hipLaunchKernelGGL(point_kernel, dim3((n + 63) / 64), dim3(64), lds, s, kind, n, in, aux, aux_rows, out);
   return hipGetLastError();
 }

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "gel_device.h"
 
 namespace gel {
@@ -27,8 +29,13 @@ hipError_t launch_point(int kind, int n, const double* in, const double* aux, in
 hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDev* rows, int B, const double* d_x,
                        double* d_con, double* d_jac, hipStream_t s);
 
-// US-1976 layer table as the kernels expect it: Lmb[11] | Tmb[11] | Pb[11] | R[11] | pexp[11] | gR[11]
-constexpr int kAtmTableDoubles = 77;  // must equal kAtmDoubles of gel_physics.h (static_assert in gel_kernels.hip)
+// US-1976 layer table as the kernels expect it: Lmb[11] | Tmb[11] | Pb[11] | R[11] | pexp[11] | gR[11] | Hb[11] | 1/Tmb[11]
+constexpr int kAtmTableDoubles = 88;  // must equal kAtmDoubles of gel_physics.h (static_assert in gel_kernels.hip)
 void fill_atmosphere_table(double* atm);
+const char* check_tables(const double* wind, int Kw, const double* ca, int Kc);
+std::vector<double> build_tables(const double* wind, int Kw, const double* ca, int Kc);
+void append_rows_and_slopes(std::vector<double>& rows_out, std::vector<double>& slopes_out, const double* tab, int K, int w);
+// doubles of the staged tables (atmosphere | wind rows | CA rows | wind slopes | CA slopes), as gel_physics.h table_doubles()
+inline size_t staged_table_doubles(int Kw, int Kc) { return (size_t)kAtmTableDoubles + 3 * (size_t)Kw + 2 * (size_t)Kc + 2 * (size_t)(Kw - 1) + (size_t)(Kc - 1); }
 
 }  // namespace gel

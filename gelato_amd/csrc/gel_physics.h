@@ -32,11 +32,16 @@ constexpr double kPi = 3.14159265358979323846;
 // order: pexp = -g0 / Lmb / R (lapse layers), gR = g0 / R (isothermal layers).
 struct Tables {
   const double* atm;
-  const double* wind;  // [Kw][3]
-  const double* ca;    // [Kc][2]
+  const double* wind;   // [Kw][3]
+  const double* ca;     // [Kc][2]
+  const double* winds;  // [Kw-1][2] slopes of the two wind components per table interval (host: (yu - yl) / (xu - xl))
+  const double* cas;    // [Kc-1]    slopes of CA per Mach interval
   int Kw, Kc;
 };
-constexpr int kAtmDoubles = 77;  // Lmb, Tmb, Pb, R, pressure exponent, g0/R, layer base altitude: 11 layers each
+// Lmb, Tmb, Pb, R, pressure exponent, g0/R, layer base altitude, 1/Tmb: 11 layers each
+constexpr int kAtmDoubles = 88;
+// doubles of the staged tables: atmosphere | wind rows | CA rows | wind slopes | CA slopes
+GEL_DEV constexpr int table_doubles(int Kw, int Kc) { return kAtmDoubles + 3 * Kw + 2 * Kc + 2 * (Kw - 1) + (Kc - 1); }
 
 // ---------------------------------------------------------------------------
 // fp64 square root and division without the range guards.
@@ -78,6 +83,45 @@ GEL_DEV double fsqrt(double x) { return sqrt(x); }
 GEL_DEV double fdiv(double a, double b) { return a / b; }
 #endif
 GEL_DEV double frcp(double b) { return fdiv(1.0, b); }
+
+// sqrt and 1/sqrt of the same argument from ONE Goldschmidt iteration: s is bit-identical to fsqrt(x); r comes
+// from one more step on the companion value (<= 1 ulp from 1/sqrt(x)).  13 operations instead of the 18 of
+// fsqrt + frcp, and one quarter-rate instruction (v_rsq_f64) instead of two (v_rsq_f64, v_rcp_f64).  Used where
+// the reciprocal feeds nothing that is later differenced against a 6.4e6 m cancellation (see pos_part()).
+GEL_DEV void fsqrt_rsqrt(double x, double& s, double& r) {
+#ifndef GEL_STD_MATH
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r0 = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r0, g);
+  h = __builtin_fma(h, r0, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  s = __builtin_fma(d, h, g);
+  const double r1 = __builtin_fma(-h, s, 0.5);
+  h = __builtin_fma(h, r1, h);
+  r = h + h;
+#else
+  s = sqrt(x);
+  r = 1.0 / s;
+#endif
+}
+// 1/sqrt(x) alone (9 operations)
+GEL_DEV double frsqrt(double x) {
+#ifndef GEL_STD_MATH
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r0 = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r0, g);
+  h = __builtin_fma(h, r0, h);
+  const double r1 = __builtin_fma(-h, g, 0.5);
+  h = __builtin_fma(h, r1, h);
+  return h + h;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // log of the temperature ratio of a lapse layer, and sin/cos of a latitude or of half the Earth angle.
@@ -160,7 +204,7 @@ GEL_DEV int us76_layer(double h) {  // src/Air.cpp:56-61
   return k;
 }
 
-struct Air { double T, P, rho, a; };
+struct Air { double T, P, rho, a, inv_a; };
 
 GEL_DEV Air atmosphere(double h, const double* atm) {
   const int k = us76_layer(h);
@@ -189,13 +233,15 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
 #ifdef GEL_AB_POW  // A/B switch for tools/variant.sh only
     o.P = Pb * pow((Tmb + Lmb * (h - Hb)) / Tmb, atm[44 + k]);
 #else
-    o.P = Pb * exp(atm[44 + k] * flog_ratio(fdiv(Tmb + Lmb * (h - Hb), Tmb)));
+    // the temperature ratio by the tabulated 1/Tmb (<= 1 ulp from the division; amplified by the exponent, |y| <= 35,
+    // that stays inside the exp(y log x) budget above)
+    o.P = Pb * exp(atm[44 + k] * flog_ratio((Tmb + Lmb * (h - Hb)) * atm[77 + k]));
 #endif
   } else {
-    o.P = Pb * exp(fdiv(atm[55 + k] * (Hb - h), Tmb));                // g0/R from the table
+    o.P = Pb * exp((atm[55 + k] * (Hb - h)) * atm[77 + k]);           // g0/R and 1/Tmb from the table
   }
   o.rho = fdiv(o.P, R * o.T);     // src/Air.cpp:100-105 (P/R/T)
-  o.a = fsqrt(1.4 * R * o.T);   // src/Air.cpp:107-111
+  fsqrt_rsqrt(1.4 * R * o.T, o.a, o.inv_a);   // src/Air.cpp:107-111; 1/a for the Mach number
   return o;
 }
 
@@ -204,13 +250,19 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
 // ---------------------------------------------------------------------------
 // theta = atan2(z Ra, p Rb) is only used through sin(theta), cos(theta): they are formed algebraically
 // (a/h, b/h with h = hypot(a, b)), identical up to rounding to sincos(atan2(a, b)).
-GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p) {
-  p = fsqrt(x * x + y * y);
+// inv_p = 1/p (<= 1 ulp; it only scales the longitude pair of wind_eci()); exactly on the polar axis p = 0 and
+// inv_p = 0, which wind_eci() reads as longitude 0 = the reference's atan2(0, 0)
+GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p, double& inv_p) {
+  const double p2 = x * x + y * y;
+  fsqrt_rsqrt(fmax(p2, 1.0e-300), p, inv_p);
+  if (!(p2 > 0.0)) { p = 0.0; inv_p = 0.0; }
   const double a = z * kRa, b = p * kRb;
-  const double h = fsqrt(a * a + b * b);
-  const double ih = frcp(h);
-  const double st = (h > 0.0) ? a * ih : 0.0;
-  const double ct = (h > 0.0) ? b * ih : 1.0;
+  // only sin/cos(theta) = a/h, b/h are used, and they enter the latitude through the 0.7 % Bowring correction
+  // terms: the reciprocal root directly (<= 1 ulp on st, ct = <= 0.01 ulp on the arguments of atan2)
+  const double h2 = a * a + b * b;
+  const double ih = frsqrt(fmax(h2, 1.0e-300));
+  const double st = (h2 > 0.0) ? a * ih : 0.0;
+  const double ct = (h2 > 0.0) ? b * ih : 1.0;
   lat = atan2(z + kEp2 * kRb * (st * st * st), p - kE2 * kRa * (ct * ct * ct));
 }
 
@@ -221,16 +273,16 @@ GEL_DEV double geodetic_alt_from(double p, double sl, double cl) {
 }
 
 GEL_DEV double geodetic_altitude(double x, double y, double z) {
-  double lat, p;
-  geodetic_lat_p(x, y, z, lat, p);
+  double lat, p, ip;
+  geodetic_lat_p(x, y, z, lat, p, ip);
   double sl, cl;
   fsincos(lat, &sl, &cl);
   return geodetic_alt_from(p, sl, cl);
 }
 
 GEL_DEV void geodetic_full(double x, double y, double z, double& lat, double& lon, double& alt) {
-  double p;
-  geodetic_lat_p(x, y, z, lat, p);
+  double p, ip;
+  geodetic_lat_p(x, y, z, lat, p, ip);
   lon = atan2(y, x);
   double sl, cl;
   fsincos(lat, &sl, &cl);
@@ -245,10 +297,10 @@ GEL_DEV void gravity_eci(const double r3[3], double barC20, double g[3]) {
   const double a = 6378137.0, mu = kMu;
   const double b = a * (1.0 - 1.0 / 298.257223563);
   const double x = r3[0], y = r3[1], z = r3[2];
-  double r = fsqrt(x * x + y * y + z * z);
+  double r, inv_r;  // one reciprocal root serves x/r, y/r, z/r, a/r, mu/r^2 (each <= 1 ulp from the division)
+  fsqrt_rsqrt(fmax(x * x + y * y + z * z, 1.0e-300), r, inv_r);
   double irx = 0.0, iry = 0.0, irz = 0.0;
-  double inv_r = frcp(r);  // one reciprocal serves x/r, y/r, z/r, a/r, mu/r^2 (each <= 1 ulp from the division)
-  if (r != 0.0) { irx = x * inv_r; iry = y * inv_r; irz = z * inv_r; }
+  if (r > 1.0e-150) { irx = x * inv_r; iry = y * inv_r; irz = z * inv_r; }
   const double s5 = 2.23606797749978969641;  // sqrt(5.0)
   const double barP20 = s5 * (3.0 * irz * irz - 1.0) * 0.5;
   const double barP20d = s5 * 3.0 * irz;
@@ -303,23 +355,21 @@ GEL_DEV int lower_count(double x, const double* tab, int n, int stride) {
   return lo;
 }
 
-GEL_DEV double interp_tab(double x, const double* tab, int n, int stride, int ycol) {
+// yl + alpha (yu - yl), alpha = (x - xl)/(xu - xl), as yl + (x - xl) * slope with the slope (yu - yl)/(xu - xl) of the
+// interval tabulated on the host: one division and one LDS read less per lookup, <= 2 ulp of the increment away.
+GEL_DEV double interp_tab(double x, const double* tab, const double* slope, int n, int stride, int ycol) {
   const int idx = min(max(lower_count(x, tab, n, stride) - 1, 0), n - 2);
-  const double xl = tab[idx * stride], xu = tab[(idx + 1) * stride];
-  const double yl = tab[idx * stride + ycol], yu = tab[(idx + 1) * stride + ycol];
-  const double alpha = fdiv(x - xl, xu - xl);  // knots are distinct (checked at problem creation)
-  const double v = yl + alpha * (yu - yl);
+  const double v = tab[idx * stride + ycol] + (x - tab[idx * stride]) * slope[idx];
   // clamps of the reference (and yp[0] at x == xp[0]) as selects instead of early returns
   return (x <= tab[0]) ? tab[ycol] : ((x > tab[(n - 1) * stride]) ? tab[(n - 1) * stride + ycol] : v);
 }
 
 // both wind components share one bracket search (src/wrapper_utils.hpp:82-87 runs it twice)
-GEL_DEV void wind_ned2(double h, const double* tab, int n, double& wn, double& we) {
+GEL_DEV void wind_ned2(double h, const double* tab, const double* slope, int n, double& wn, double& we) {
   const int idx = min(max(lower_count(h, tab, n, 3) - 1, 0), n - 2);
-  const double xl = tab[idx * 3], xu = tab[(idx + 1) * 3];
-  const double alpha = fdiv(h - xl, xu - xl);
-  const double vn = tab[idx * 3 + 1] + alpha * (tab[(idx + 1) * 3 + 1] - tab[idx * 3 + 1]);
-  const double ve = tab[idx * 3 + 2] + alpha * (tab[(idx + 1) * 3 + 2] - tab[idx * 3 + 2]);
+  const double dxl = h - tab[idx * 3];
+  const double vn = tab[idx * 3 + 1] + dxl * slope[2 * idx];
+  const double ve = tab[idx * 3 + 2] + dxl * slope[2 * idx + 1];
   const bool below = h <= tab[0], above = h > tab[(n - 1) * 3];
   wn = below ? tab[1] : (above ? tab[(n - 1) * 3 + 1] : vn);
   we = below ? tab[2] : (above ? tab[(n - 1) * 3 + 2] : ve);

@@ -19,7 +19,7 @@ namespace gel {
 
 // depends on position only
 struct PosPart {
-  double rho, P, a;  // atmosphere at the node
+  double rho, P, inv_a;  // atmosphere at the node: density, pressure, 1 / speed of sound
   double wn, we;     // wind, NED
   double g[3];       // gravity, ECI
   double shp, chp;   // sin, cos of half the geodetic latitude (for the NED quaternion)
@@ -52,21 +52,24 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
   double p, sl, cl;
 #ifdef GEL_AB_LATALG  // A/B switch for tools/variant.sh only: the algebraic pair (see the comment above)
   geodetic_sincos(r[0], r[1], r[2], sl, cl, p);
+  o.inv_p = frcp(p);
 #else
   double lat;
-  geodetic_lat_p(r[0], r[1], r[2], lat, p);
+  geodetic_lat_p(r[0], r[1], r[2], lat, p, o.inv_p);
   fsincos(lat, &sl, &cl);
 #endif
-  o.inv_p = frcp(p);
   // half-angle pair of the NED quaternion (src/Coordinate.cpp:89-90): cos(lat/2) = sqrt((1+cos lat)/2)
-  // (cos lat >= 0), sin(lat/2) = sin lat / (2 cos(lat/2))
-  o.chp = fsqrt(0.5 * (1.0 + cl));
-  o.shp = fdiv(0.5 * sl, o.chp);
+  // (cos lat >= 0), sin(lat/2) = sin lat / (2 cos(lat/2)); root and reciprocal root from one iteration
+  {
+    double irt;
+    fsqrt_rsqrt(0.5 * (1.0 + cl), o.chp, irt);
+    o.shp = (0.5 * sl) * irt;
+  }
   const double alt = geodetic_alt_from(p, sl, cl);
   const double h = geopotential_altitude(alt);
   const Air air = atmosphere(h, tb.atm);
-  o.rho = air.rho; o.P = air.P; o.a = air.a;
-  wind_ned2(h, tb.wind, tb.Kw, o.wn, o.we);  // wind looked up at geopotential altitude (:44,49)
+  o.rho = air.rho; o.P = air.P; o.inv_a = air.inv_a;
+  wind_ned2(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we);  // wind looked up at geopotential altitude (:44,49)
   gravity_eci(r, barC20, o.g);
   return o;
 }
@@ -97,9 +100,10 @@ GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double s_hp, doubl
   // eci2ecef(pos, t): src/Coordinate.cpp:51-59
   const double px = r[0] * e.c + r[1] * e.s;
   const double py = -r[0] * e.s + r[1] * e.c;
-  const double clon = px * inv_p, slon = py * inv_p;
-  const double th = fsqrt(0.5 * (1.0 + fabs(clon)));  // |cos| or |sin| of lon/2, whichever is >= 0.707
-  const double uh = fdiv(0.5 * slon, th);
+  const double clon = (inv_p > 0.0) ? px * inv_p : 1.0, slon = py * inv_p;  // on the polar axis: longitude 0
+  double th, ith;  // |cos| or |sin| of lon/2, whichever is >= 0.707, and its reciprocal from the same iteration
+  fsqrt_rsqrt(0.5 * (1.0 + fabs(clon)), th, ith);
+  const double uh = (0.5 * slon) * ith;
   const double c_hl = (clon >= 0.0) ? th : fabs(uh);
   const double s_hl = (clon >= 0.0) ? uh : copysign(th, slon);
   // quat_ecef2ned: src/Coordinate.cpp:85-98
@@ -122,7 +126,7 @@ GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double s_hp, doubl
 }
 
 // aerodynamic force (ECI): src/pybind_dynamics.cpp:48-59 given the shared parts
-GEL_DEV void aero_force(const double r[3], const double v[3], double rho, double a_sound, const EarthAngle& e,
+GEL_DEV void aero_force(const double r[3], const double v[3], double rho, double inv_a_sound, const EarthAngle& e,
                         const double w[3], double area, const Tables& tb, double F[3]) {
   // vel_eci2ecef: src/Coordinate.cpp:69-73 (omega x r = (-w y, w x, 0)), then ecef2eci (:41-49), minus wind
   const double d0 = v[0] + kOmega * r[1];
@@ -135,8 +139,8 @@ GEL_DEV void aero_force(const double r[3], const double v[3], double rho, double
   // a vehicle at rest in the air (vn = 0) is a legitimate input: clamp below anything physical so that
   // fsqrt stays defined; the force is k * (-a) = 0 either way
   const double vn = fsqrt(fmax(a0 * a0 + a1 * a1 + a2 * a2, 1.0e-200));
-  const double mach = fdiv(vn, a_sound);
-  const double ca = interp_tab(mach, tb.ca, tb.Kc, 2, 1);
+  const double mach = vn * inv_a_sound;
+  const double ca = interp_tab(mach, tb.ca, tb.cas, tb.Kc, 2, 1);
   const double k = 0.5 * rho * area * ca * vn;
   F[0] = k * -a0; F[1] = k * -a1; F[2] = k * -a2;
 }

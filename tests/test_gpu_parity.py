@@ -286,6 +286,46 @@ def test_batch_matches_single_and_oracle():
     assert np.array_equal(r_only, res)
 
 
+@pytest.mark.parametrize("name,Bs", [("example", (1, 2, 3, 5, 30, 31)), ("mixed-6x64", (45, 46, 47, 257)),
+                                     ("stress-12x128", (11, 13))])
+def test_cooperative_dx_form_equals_single_vector_calls(name, Bs):
+    """Throughput launches form D.X per WORKGROUP (four decision vectors side by side on the matrix pipe, one row
+    tile per wavefront); batches that are not a multiple of four leave wavefronts without a vector of their own.
+    Every vector of such a batch must come out bit for bit as its single-vector call (split latency form)."""
+    import torch
+    from gelato_amd import Engine, problem
+    prob, x0, _ = named_problem(name)
+    E = Engine(prob, flags=1)   # GEL_FLAG_DX_MFMA: the matrix-pipe form also for the example's short phases
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    Bmax = max(Bs)
+    X = problem.synthetic_batch(x0, E.M, Bmax, seed=77)
+    singles = {}
+    for B in Bs:
+        info = E.launch_info(B)
+        dX = torch.from_numpy(X[:B].copy()).to(dev)
+        dres = torch.full((B + 1, E.nres), -7.0, dtype=torch.float64, device=dev)   # one guard row behind the batch
+        djv = torch.full((B + 1, E.V), -7.0, dtype=torch.float64, device=dev)
+        E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), s)
+        assert E.sync(s) == 0
+        res, jv = dres.cpu().numpy(), djv.cpu().numpy()
+        assert np.all(res[B] == -7.0) and np.all(jv[B] == -7.0), "a wavefront without a vector wrote something"
+        # residual-only launches never split: always the cooperative form
+        dres2 = torch.full((B + 1, E.nres), -7.0, dtype=torch.float64, device=dev)
+        E.eval_batch_device(B, dX.data_ptr(), dres2.data_ptr(), 0, s)
+        assert E.sync(s) == 0
+        r2 = dres2.cpu().numpy()
+        assert np.array_equal(r2[:B], res[:B]) and np.all(r2[B] == -7.0)
+        for b in sorted({0, B // 2, B - 1}):
+            if b not in singles:
+                r1, v1, rc = E.eval(X[b])
+                assert rc == 0
+                singles[b] = (r1, v1[E.var_index()])
+            assert np.array_equal(res[b], singles[b][0]), (B, b, info)
+            assert np.array_equal(jv[b], singles[b][1]), (B, b, info)
+    assert E.launch_info(Bmax, True, False)[2] == 0 and E.launch_info(1)[2] == 1
+
+
 def test_device_pointer_api_and_full_expansion():
     import torch
     prob, x0, _ = named_problem("mixed-6x64")
