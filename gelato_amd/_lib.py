@@ -43,6 +43,7 @@ class GelDims(C.Structure):
         ("block_nnz", C.c_int64 * NUM_BLOCKS),
         ("block_shape", (C.c_int64 * 2) * NUM_BLOCKS),
         ("total_nnz", C.c_int64), ("num_var_entries", C.c_int64), ("algorithmic_bytes", C.c_int64),
+        ("stored_bytes", C.c_int64),
     ]
 
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     "gel_pattern_all": (C.c_int, [C.c_void_p, _ip, _ip]),
     "gel_const_values": (C.c_int, [C.c_void_p, _dp]),
     "gel_var_index": (C.c_int, [C.c_void_p, _lp]),
+    "gel_full_source": (C.c_int, [C.c_void_p, _ip]),
     "gel_eval_residual": (C.c_int, [C.c_void_p, _dp, _dp]),
     "gel_eval_jacobian": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32]),
     "gel_eval": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int32]),

@@ -41,6 +41,16 @@ static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wav
 constexpr int kCoopStageOff = PK_LV0 * 64;
 static_assert(kWaveLds - kCoopStageOff >= 64 * 11, "the cooperative hand-over area must fit behind the early park slots");
 
+// Compact Jacobian slots of a node (gel_host.hip walk_pattern() maps them to the reference's COO entries).  Only
+// DISTINCT x-dependent values are stored: a tf column that is the exact negative of its t0 column, the node-uniform
+// pos/velocity diagonal value (one scalar per phase, behind the phase's node slots) and the eight entries of the
+// 4 x 4 quaternion block that do not depend on x (D[j][j+1] or 0: dq_c does not contain q_k) are restored by the
+// consumer's gather map (gel_full_source) instead of being written.
+//   0..2 pos/t (t0)   3..5 vel/mass   6..14 vel/position   [15..23 vel/velocity, air_fd]   s_vq +12 vel/quaternion
+//   s_vt +6 vel/t (air_fd: t0, tf) or +3 (t0)   s_qq +8 quat/quaternion (k major: k < 2 -> rows 2,3; else rows 0,1)
+//   s_qq+8 +8 quat/u   s_qq+16 +4 quat/t (t0)
+constexpr int kSlotPT = 0, kSlotVM = 3, kSlotVP = 6;
+
 #ifndef GEL_MIN_WAVES_PER_SIMD
 #define GEL_MIN_WAVES_PER_SIMD 4  // 112 VGPRs, no scratch: 4 waves/SIMD (16 per CU, matching the LDS budget); 5 spills
 #endif
@@ -344,14 +354,10 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     // ---- everything that needs no velocity RHS is finished here, while its inputs are in registers:
     //      position Jacobian entries, the whole quaternion group (:155-213, :499-632) ----
     if (JAC && lead) {
-      const double rh_vel = -P.uv * (tf - to) * ut / 2.0 / P.up;
+      // pos/velocity diagonal (:190-196): the same value for every node and component -> one scalar per phase
+      if (j == 0) EMIT(ph.K, -P.uv * (tf - to) * ut / 2.0 / P.up);
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        EMIT(0 + c, rh_vel);
-        const double rh_to = ve[c] * P.uv * ut / 2.0 / P.up;
-        EMIT(3 + c, rh_to);
-        EMIT(6 + c, -rh_to);
-      }
+      for (int c = 0; c < 3; c++) EMIT(kSlotPT + c, ve[c] * P.uv * ut / 2.0 / P.up);  // t0 column; tf = its negative
     }
     if (!ph.hold && lead) {
       double fq[4];
@@ -367,28 +373,27 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
       }
       if (JAC) {
         double f[4];
-#pragma unroll 1
+        // submat_quat[4j+c, 4(j+1)+k] = D[j][j+1]*(c==k) + rh_quat   (con_dynamics.py:575-589).  dq_c contains q_k only
+        // for (c, k) in {0,1} x {2,3} and {2,3} x {0,1}: the other eight differences are exactly zero in the reference
+        // too (the perturbed component never enters), so those entries are constants of the pattern.
+#pragma unroll
         for (int k = 0; k < 4; k++) {
           double qp[4];
 #pragma unroll
           for (int c = 0; c < 4; c++) qp[c] = (k == c) ? (q[c] + dx) : q[c];
           quat_rate(qp, u0, u1, P.uu, f);
-          // submat_quat[4j+c, 4(j+1)+k] = D[j][j+1]*(c==k) + rh_quat   (con_dynamics.py:575-589)
-#pragma unroll
-          for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 4 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fq[c]));
+          const int c0 = (k < 2) ? 2 : 0;
+          EMIT(ph.s_qq + 2 * k, FDQ(f[c0], fq[c0]));
+          EMIT(ph.s_qq + 2 * k + 1, FDQ(f[c0 + 1], fq[c0 + 1]));
         }
 #pragma unroll 1
         for (int k = 0; k < 2; k++) {
           quat_rate(q, (k == 0) ? u0 + dx : u0, (k == 1) ? u1 + dx : u1, P.uu, f);
 #pragma unroll
-          for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 16 + 4 * k + c, FDQ(f[c], fq[c]));
+          for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 8 + 4 * k + c, FDQ(f[c], fq[c]));
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const double rh_to = fq[c] * ut / 2.0;
-          EMIT(ph.s_qq + 24 + c, rh_to);
-          EMIT(ph.s_qq + 28 + c, -rh_to);
-        }
+        for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 16 + c, fq[c] * ut / 2.0);  // t0 column; tf = its negative
       }
     }
     if (rb) {
@@ -475,14 +480,14 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           const int i = 3 * k + c;
-          EMIT(12 + i, FDQ((i < 8) ? PARK(PK_FP0 + i) : fp8, fc[c]));
+          EMIT(kSlotVP + i, FDQ((i < 8) ? PARK(PK_FP0 + i) : fp8, fc[c]));
         }
       }
       if (JAC && lead) {
         if (!SPLIT) {
 #pragma unroll
-          for (int i = 0; i < 8; i++) EMIT(12 + i, FDQ(PARK(PK_FP0 + i), fc[i % 3]));
-          EMIT(12 + 8, FDQ(fp8, fc[2]));
+          for (int i = 0; i < 8; i++) EMIT(kSlotVP + i, FDQ(PARK(PK_FP0 + i), fc[i % 3]));
+          EMIT(kSlotVP + 8, FDQ(fp8, fc[2]));
         }
 
         // The position-sweep slots are free now.  Values that only LATER blocks need leave the registers:
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         // mass sweep: only the division by mass changes
         accel(Tdc, Fc, frcp((me + dx) * P.um), pp.g, inv_uv, f);
 #pragma unroll
-        for (int c = 0; c < 3; c++) EMIT(9 + c, FDQ(f[c], fc[c]));
+        for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
         // t0 / tf sweeps (con_dynamics.py:452-480): only the Earth angle changes
         if (ph.air_fd) {
           // quaternion, D[j][j+1] and force slots are free now: the rest of what these two sweeps need is
@@ -559,11 +564,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
           }
         } else {
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const double rh_to = fc[c] * ut / 2.0;
-            EMIT(ph.s_vt + c, rh_to);
-            EMIT(ph.s_vt + 3 + c, -rh_to);
-          }
+          for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * ut / 2.0);  // t0 column; tf = its negative (:478-480)
         }
       }
     } else {
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         double f[3];
         accel_noair(Td, frcp((me + dx) * P.um), gc, inv_uv, f);
 #pragma unroll
-        for (int c = 0; c < 3; c++) EMIT(9 + c, FDQ(f[c], fc[c]));
+        for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
 #pragma unroll 1
         for (int k = 0; k < 3; k++) {
           double r[3], gp[3];
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
           gravity_eci(r, P.barC20, gp);
           accel_noair(Td, inv_m, gp, inv_uv, f);
 #pragma unroll
-          for (int c = 0; c < 3; c++) EMIT(12 + 3 * k + c, FDQ(f[c], fc[c]));
+          for (int c = 0; c < 3; c++) EMIT(kSlotVP + 3 * k + c, FDQ(f[c], fc[c]));
         }
         const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
 #pragma unroll 1
@@ -610,11 +611,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
           for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const double rh_to = fc[c] * ut / 2.0;
-          EMIT(ph.s_vt + c, rh_to);
-          EMIT(ph.s_vt + 3 + c, -rh_to);
-        }
+        for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * ut / 2.0);  // t0 column; tf = its negative
       }
     }
   }

@@ -131,10 +131,10 @@ struct gel_problem {
   double um, up, uv, uu, ut, dx, barC20;
   // host copies of the pattern-derived data
   std::vector<double> cval;      // [total_nnz] constants (x-dependent entries 0)
-  std::vector<int32_t> src;      // [total_nnz] -1 or compact slot
-  std::vector<int64_t> var_idx;  // [V] compact slot -> full index
-  struct Run { int64_t dst0, stride, src0, len; };
-  std::vector<Run> var_runs;     // var_idx as constant-stride runs (one per (phase, slot): the n nodes)
+  std::vector<int32_t> src;      // [total_nnz] gather map: -1 constant; s >= 0: compact[s]; s <= -2: -compact[-2 - s]
+  std::vector<int64_t> var_idx;  // [V] compact slot -> the first full index that takes it with a plus sign
+  struct Run { int64_t dst0, dstride, src0, sstride, len; double sign; };
+  std::vector<Run> var_runs;     // the gather map as constant-stride runs (about one per (phase, slot, use): the n nodes)
   std::vector<int32_t> chunk_phase;  // [nchunks] phase of every 64-node work item
   // aero path constraints: kind 0 = AOA_max, 1 = dynamic_pressure_max, 2 = Q_alpha_max
   std::vector<gel::AeroRowDev> aero_rows[3];
@@ -182,11 +182,13 @@ struct gel_problem {
 
 namespace {
 
-// kind: 0 = constant value, 1 = x-dependent (slot = compact index within the eval)
+// kind: 0 = constant value; 1 = x-dependent, value = compact[slot]; 2 = x-dependent, value = -compact[slot]
+// (slot = compact index within the eval; several entries may name the same slot)
 using Visitor = std::function<void(int block, int64_t k, int32_t row, int32_t col, int kind, double cval, int64_t slot)>;
 
 // Walks all 13 blocks in the reference's emission order (lib/con_dynamics.py:66-113,
 // 155-213,292-496,536-632).  k is the index inside the block.
+// Compact slots: see gel_eval_kernel.h (kSlotPT ...); the per-phase scalar sits at voff + K * n.
 void walk_pattern(const gel_problem& P, const Visitor& vis) {
   const int S = (int)P.ph.size();
   int64_t k[GEL_NUM_BLOCKS] = {0};
@@ -194,6 +196,7 @@ void walk_pattern(const gel_problem& P, const Visitor& vis) {
   for (int i = 0; i < S; i++) {
     const HostPhase& h = P.ph[i];
     const int n = h.n, ua = h.ua, xa = h.xa;
+    const int64_t scalar = h.voff + (int64_t)h.K * n;  // pos/velocity diagonal value of this phase
     auto Dji = [&](int j, int c) { return h.D[(size_t)j * (n + 1) + c]; };
     // ---- group 0: mass ----
     if (h.engine_on) {
@@ -210,15 +213,15 @@ void walk_pattern(const gel_problem& P, const Visitor& vis) {
     for (int ki = 0; ki < 3; ki++)
       for (int j = 0; j < n; j++)
         for (int c = 0; c <= n; c++) vis(2, k[2]++, 3 * (ua + j) + ki, 3 * (xa + c) + ki, 0, Dji(j, c), -1);
-    for (int jj = 0; jj < 3 * n; jj++) vis(3, k[3]++, 3 * ua + jj, 3 * (xa + 1) + jj, 1, 0, cs(h, 0 + jj % 3, jj / 3));
-    for (int jj = 0; jj < 3 * n; jj++) vis(4, k[4]++, 3 * ua + jj, i, 1, 0, cs(h, 3 + jj % 3, jj / 3));
-    for (int jj = 0; jj < 3 * n; jj++) vis(4, k[4]++, 3 * ua + jj, i + 1, 1, 0, cs(h, 6 + jj % 3, jj / 3));
+    for (int jj = 0; jj < 3 * n; jj++) vis(3, k[3]++, 3 * ua + jj, 3 * (xa + 1) + jj, 1, 0, scalar);
+    for (int jj = 0; jj < 3 * n; jj++) vis(4, k[4]++, 3 * ua + jj, i, 1, 0, cs(h, 0 + jj % 3, jj / 3));
+    for (int jj = 0; jj < 3 * n; jj++) vis(4, k[4]++, 3 * ua + jj, i + 1, 2, 0, cs(h, 0 + jj % 3, jj / 3));
     // ---- group 2: velocity ----
     for (int j = 0; j < n; j++)
-      for (int c = 0; c < 3; c++) vis(5, k[5]++, 3 * (ua + j) + c, xa + 1 + j, 1, 0, cs(h, 9 + c, j));
+      for (int c = 0; c < 3; c++) vis(5, k[5]++, 3 * (ua + j) + c, xa + 1 + j, 1, 0, cs(h, 3 + c, j));
     for (int kk = 0; kk < 3; kk++)
       for (int j = 0; j < n; j++)
-        for (int c = 0; c < 3; c++) vis(6, k[6]++, 3 * (ua + j) + c, 3 * (xa + 1 + j) + kk, 1, 0, cs(h, 12 + 3 * kk + c, j));
+        for (int c = 0; c < 3; c++) vis(6, k[6]++, 3 * (ua + j) + c, 3 * (xa + 1 + j) + kk, 1, 0, cs(h, 6 + 3 * kk + c, j));
     for (int ki = 0; ki < 3; ki++)
       for (int kj = 0; kj < 3; kj++)
         for (int j = 0; j < n; j++)
@@ -232,8 +235,11 @@ void walk_pattern(const gel_problem& P, const Visitor& vis) {
     for (int kk = 0; kk < 4; kk++)
       for (int j = 0; j < n; j++)
         for (int c = 0; c < 3; c++) vis(8, k[8]++, 3 * (ua + j) + c, 4 * (xa + 1 + j) + kk, 1, 0, cs(h, h.s_vq + 3 * kk + c, j));
+    // t0 column, then tf column: two sweeps when the velocity / time derivatives are finite differences
+    // (reference_area > 0), else the tf column is the exact negative of the t0 column (:478-480)
     for (int jj = 0; jj < 3 * n; jj++) vis(9, k[9]++, 3 * ua + jj, i, 1, 0, cs(h, h.s_vt + jj % 3, jj / 3));
-    for (int jj = 0; jj < 3 * n; jj++) vis(9, k[9]++, 3 * ua + jj, i + 1, 1, 0, cs(h, h.s_vt + 3 + jj % 3, jj / 3));
+    for (int jj = 0; jj < 3 * n; jj++)
+      vis(9, k[9]++, 3 * ua + jj, i + 1, h.air_fd ? 1 : 2, 0, cs(h, h.s_vt + (h.air_fd ? 3 : 0) + jj % 3, jj / 3));
     // ---- group 3: quaternion ----
     if (h.hold) {
       for (int jj = 0; jj < 4 * n; jj++) vis(10, k[10]++, 4 * ua + jj, 4 * xa + jj % 4, 0, -1.0, -1);
@@ -243,16 +249,19 @@ void walk_pattern(const gel_problem& P, const Visitor& vis) {
         for (int c = 0; c < 4; c++)
           for (int cc = 0; cc <= n; cc++)
             for (int kk = 0; kk < 4; kk++) {
-              if (cc == j + 1)
-                vis(10, k[10]++, 4 * (ua + j) + c, 4 * (xa + cc) + kk, 1, 0, cs(h, h.s_qq + 4 * kk + c, j));
+              // on the block diagonal dq_c/dq_kk is a finite difference only where dq_c contains q_kk
+              // (src/pybind_dynamics.cpp:94-106: rows {0,1} x columns {2,3} and rows {2,3} x columns {0,1});
+              // elsewhere the reference's difference is exactly zero and the entry is D[j][j+1] or 0
+              if (cc == j + 1 && ((c < 2) != (kk < 2)))
+                vis(10, k[10]++, 4 * (ua + j) + c, 4 * (xa + cc) + kk, 1, 0, cs(h, h.s_qq + 2 * kk + (c & 1), j));
               else
                 vis(10, k[10]++, 4 * (ua + j) + c, 4 * (xa + cc) + kk, 0, (c == kk) ? Dji(j, cc) : 0.0, -1);
             }
       for (int kk = 0; kk < 2; kk++)
         for (int j = 0; j < n; j++)
-          for (int c = 0; c < 4; c++) vis(11, k[11]++, 4 * (ua + j) + c, 2 * (ua + j) + kk, 1, 0, cs(h, h.s_qq + 16 + 4 * kk + c, j));
-      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i, 1, 0, cs(h, h.s_qq + 24 + jj % 4, jj / 4));
-      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i + 1, 1, 0, cs(h, h.s_qq + 28 + jj % 4, jj / 4));
+          for (int c = 0; c < 4; c++) vis(11, k[11]++, 4 * (ua + j) + c, 2 * (ua + j) + kk, 1, 0, cs(h, h.s_qq + 8 + 4 * kk + c, j));
+      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i, 1, 0, cs(h, h.s_qq + 16 + jj % 4, jj / 4));
+      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i + 1, 2, 0, cs(h, h.s_qq + 16 + jj % 4, jj / 4));
     }
   }
 }
@@ -458,7 +467,8 @@ void scatter_full(const gel_problem* p, const double* jv, double* vals_full, int
   for (const gel_problem::Run& r : p->var_runs) {
     double* d = vals_full + r.dst0;
     const double* v = jv + r.src0;
-    for (int64_t k = 0; k < r.len; k++) d[k * r.stride] = v[k];
+    if (r.sign > 0) for (int64_t k = 0; k < r.len; k++) d[k * r.dstride] = v[k * r.sstride];
+    else for (int64_t k = 0; k < r.len; k++) d[k * r.dstride] = -v[k * r.sstride];
   }
 }
 
@@ -569,9 +579,9 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     h.thrust = d->thrust[i]; h.massflow = d->massflow[i]; h.area = d->reference_area[i]; h.nozzle = d->nozzle_area[i];
     h.air = (h.area != 0.0); h.air_fd = (h.area > 0.0);
     h.engine_on = d->engine_on[i] != 0; h.hold = d->attitude_hold[i] != 0;
-    h.s_vv = 21; h.s_vq = h.air_fd ? 30 : 21; h.s_vt = h.s_vq + 12; h.s_qq = h.s_vt + 6;
-    h.K = h.s_qq + (h.hold ? 0 : 32);
-    h.voff = V; V += (int64_t)h.K * h.n;
+    h.s_vv = 15; h.s_vq = h.air_fd ? 24 : 15; h.s_vt = h.s_vq + 12; h.s_qq = h.s_vt + (h.air_fd ? 6 : 3);
+    h.K = h.s_qq + (h.hold ? 0 : 20);
+    h.voff = V; V += (int64_t)h.K * h.n + 1;  // node slots + the phase's pos/velocity diagonal scalar
     const size_t nd = (size_t)h.n * (h.n + 1);
     if (d->D && d->tau) {
       h.D.assign(d->D + offD, d->D + offD + nd);
@@ -604,25 +614,52 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   p->block_off[GEL_NUM_BLOCKS] = tot;
   dm.total_nnz = tot;
   dm.num_var_entries = V;
-  dm.algorithmic_bytes = 8 * ((int64_t)dm.num_vars + 11 * (int64_t)N + V);
+  {
+    // A_min = read x once + write the residual once + write every x-dependent value the reference
+    // computes once: V_ref = sum over phases of n * (9 [pos] + 39 | 30 [vel with | without velocity / time FD] + 32 [free
+    // attitude]).  The engine's compact vector holds the DISTINCT values among them (stored_bytes).
+    int64_t Vref = 0;
+    for (int i = 0; i < S; i++) Vref += (int64_t)p->ph[i].n * (9 + (p->ph[i].air_fd ? 39 : 30) + (p->ph[i].hold ? 0 : 32));
+    dm.algorithmic_bytes = 8 * ((int64_t)dm.num_vars + 11 * (int64_t)N + Vref);
+    dm.stored_bytes = 8 * (11 * (int64_t)N + V);
+  }
 
   // pattern-derived host arrays
   p->cval.assign((size_t)tot, 0.0);
   p->src.assign((size_t)tot, -1);
   p->var_idx.assign((size_t)V, -1);
+  struct Ref { int64_t slot, f; int kind; int64_t occ; };
+  std::vector<Ref> refs;
   walk_pattern(*p, [&](int blk, int64_t k, int32_t, int32_t, int kind, double cv, int64_t slot) {
     const int64_t f = p->block_off[blk] + k;
-    if (kind == 0) p->cval[(size_t)f] = cv;
-    else { p->src[(size_t)f] = (int32_t)slot; p->var_idx[(size_t)slot] = f; }
+    if (kind == 0) { p->cval[(size_t)f] = cv; return; }
+    p->src[(size_t)f] = (kind == 1) ? (int32_t)slot : (int32_t)(-2 - slot);
+    if (kind == 1 && p->var_idx[(size_t)slot] < 0) p->var_idx[(size_t)slot] = f;
+    refs.push_back({slot, f, kind, 0});
   });
   for (int64_t s = 0; s < V; s++)
     if (p->var_idx[(size_t)s] < 0) { delete p; return fail(GEL_ERR_ARG, "internal: compact slot without a COO entry"); }
-  for (int64_t k = 0; k < V;) {
-    int64_t j = k + 1;
-    const int64_t stride = (j < V) ? p->var_idx[(size_t)j] - p->var_idx[(size_t)k] : 1;
-    while (j < V && p->var_idx[(size_t)j] - p->var_idx[(size_t)j - 1] == stride) j++;
-    p->var_runs.push_back({p->var_idx[(size_t)k], stride, k, j - k});
-    k = j;
+  {
+    // The gather map as constant-stride runs for the host scatter.  A per-node slot is used once or twice (a t0
+    // column and its negated tf column): its k-th use over consecutive nodes is one run.  A phase scalar is used
+    // 3n times: its uses in full order are one run with source stride 0.
+    std::vector<char> is_scalar((size_t)V, 0);
+    for (int i = 0; i < S; i++) is_scalar[(size_t)(p->ph[i].voff + (int64_t)p->ph[i].K * p->ph[i].n)] = 1;
+    std::stable_sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.slot < b.slot; });
+    for (size_t i = 0; i < refs.size(); i++)
+      refs[i].occ = (i > 0 && refs[i - 1].slot == refs[i].slot && !is_scalar[(size_t)refs[i].slot]) ? refs[i - 1].occ + 1 : 0;
+    std::stable_sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.occ < b.occ; });  // (occ, slot, f)
+    for (size_t i = 0; i < refs.size();) {
+      size_t j = i + 1;
+      const bool sc = is_scalar[(size_t)refs[i].slot] != 0;
+      const int64_t ds = (j < refs.size()) ? refs[j].f - refs[i].f : 1;
+      while (j < refs.size() && refs[j].kind == refs[i].kind && refs[j].occ == refs[i].occ &&
+             refs[j].slot == refs[j - 1].slot + (sc ? 0 : 1) && refs[j].f - refs[j - 1].f == ds &&
+             (is_scalar[(size_t)refs[j].slot] != 0) == sc)
+        j++;
+      p->var_runs.push_back({refs[i].f, ds, refs[i].slot, sc ? 0 : 1, (int64_t)(j - i), refs[i].kind == 1 ? 1.0 : -1.0});
+      i = j;
+    }
   }
 
   for (int i = 0; i < S; i++)
@@ -781,6 +818,12 @@ int gel_const_values(const gel_problem* p, double* vals_full) {
 int gel_var_index(const gel_problem* p, int64_t* idx) {
   if (!p || !idx) return fail(GEL_ERR_ARG, "null argument");
   std::memcpy(idx, p->var_idx.data(), p->var_idx.size() * 8);
+  return GEL_OK;
+}
+
+int gel_full_source(const gel_problem* p, int32_t* src) {
+  if (!p || !src) return fail(GEL_ERR_ARG, "null argument");
+  std::memcpy(src, p->src.data(), p->src.size() * sizeof(int32_t));
   return GEL_OK;
 }
 

@@ -55,7 +55,7 @@ GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds) {
 namespace gel {
 
 // ---------------------------------------------------------------------------
-// compact -> full COO values.  src[i] < 0: constant cval[i]; else jvar[b][src[i]].
+// compact -> full COO values.  src[i] = -1: constant cval[i]; s >= 0: jvar[b][s]; s <= -2: -jvar[b][-2 - s].
 // Two doubles (16 B) per lane: wide coalesced stores.  A thread keeps its two template entries
 // (cval, src: 12 B per entry, 7.3 MB at 6x64 -- larger than one XCD's L2) in registers and re-uses them
 // for kExpandGroup decision vectors, so the template is read once per group instead of once per vector
@@ -71,12 +71,13 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(long long nnz, long long
   for (long long i = 2 * ((long long)blockIdx.x * kBlock + threadIdx.x); i < nnz; i += 2LL * gridDim.x * kBlock) {
     const bool two = i + 1 < nnz;
     const int s0 = src[i], s1 = two ? src[i + 1] : -1;
-    const double c0 = (s0 < 0) ? cval[i] : 0.0, c1 = (two && s1 < 0) ? cval[i + 1] : 0.0;
+    const double c0 = (s0 == -1) ? cval[i] : 0.0, c1 = (two && s1 == -1) ? cval[i + 1] : 0.0;
+    const int g0 = (s0 >= 0) ? s0 : -2 - s0, g1 = (s1 >= 0) ? s1 : -2 - s1;  // compact index (unused for constants)
     for (int g = 0; g < nb; g++) {
       const double* jv = jvar + (size_t)(b0 + g) * V;
       double* out = full + (size_t)(b0 + g) * nnz + i;
-      const double v0 = (s0 < 0) ? c0 : jv[s0];
-      const double v1 = (s1 < 0) ? c1 : jv[s1];
+      const double v0 = (s0 == -1) ? c0 : ((s0 >= 0) ? jv[g0] : -jv[g0]);
+      const double v1 = (s1 == -1) ? c1 : ((s1 >= 0) ? jv[g1] : -jv[g1]);
       if (two && (even || ((b0 + g) & 1) == 0)) {
         // written once, read by someone else later: non-temporal (4.2 -> 5.8 TB/s measured)
         typedef double gel_d2 __attribute__((ext_vector_type(2)));

@@ -96,12 +96,14 @@ class Engine:
         self.block_shape = [(int(s[0]), int(s[1])) for s in dims.block_shape]
         self.total_nnz = int(dims.total_nnz)
         self.V = int(dims.num_var_entries)
-        self.algorithmic_bytes = int(dims.algorithmic_bytes)
+        self.algorithmic_bytes = int(dims.algorithmic_bytes)   # SURVEY 8(d) A_min per eval
+        self.stored_bytes = int(dims.stored_bytes)             # residual + compact values actually written
         self.block_off = np.concatenate([[0], np.cumsum(self.block_nnz)]).astype(np.int64)
         self.row_off = {"mass": 0, "pos": self.N, "vel": 4 * self.N, "quat": 7 * self.N}
         self._pattern = None
         self._vals = None      # persistent full COO values (constants pre-filled)
         self._var_idx = None
+        self._src = None
 
     # ------------------------------------------------------------------
     def close(self):
@@ -148,6 +150,18 @@ class Engine:
             check(lib().gel_var_index(self._h, idx.ctypes.data_as(_lp)))
             self._var_idx = idx
         return self._var_idx
+
+    def full_source(self):
+        """gather map full <- compact: -1 constant, s >= 0: compact[s], s <= -2: -compact[-2 - s]"""
+        if self._src is None:
+            src = np.zeros(self.total_nnz, dtype=np.int32)
+            check(lib().gel_full_source(self._h, src.ctypes.data_as(_ip)))
+            self._src = src
+        return self._src
+
+    def var_mask(self):
+        """boolean [total_nnz]: entries that depend on x (everything the gather map takes from the compact vector)"""
+        return self.full_source() != -1
 
     # ------------------------------------------------------------------
     def eval_residual(self, x):
@@ -200,8 +214,11 @@ class Engine:
     def expand(self, jvar):
         """compact [.., V] -> full [.., total_nnz] on the host (numpy), using the constant template."""
         jvar = np.asarray(jvar)
+        src = self.full_source()
         full = np.broadcast_to(self.const_values(), jvar.shape[:-1] + (self.total_nnz,)).copy()
-        full[..., self.var_index()] = jvar
+        pos, neg = np.nonzero(src >= 0)[0], np.nonzero(src <= -2)[0]
+        full[..., pos] = jvar[..., src[pos]]
+        full[..., neg] = -jvar[..., -2 - src[neg]]
         return full
 
     # device-pointer API (pointers are integers, e.g. torch.Tensor.data_ptr())

@@ -35,9 +35,24 @@ int main(int argc, char** argv) {
   gel_dims dm;
   CHECK(gel_problem_dims(p, &dm) == GEL_OK);
   CHECK(dm.S == 2 && dm.N == 75 && dm.M == 77 && dm.num_vars == 11 * 77 + 2 * 75 + 3);
-  /* phase 0: air + hold (48 slots/node), phase 1: NoAir + free (71 slots/node) */
-  CHECK(dm.num_var_entries == 48 * 5 + 71 * 70);
-  CHECK(dm.algorithmic_bytes == 8 * ((int64_t)dm.num_vars + 11 * 75 + dm.num_var_entries));
+  /* distinct x-dependent values: phase 0 air + hold = 42 per node, phase 1 NoAir + free = 50 per node, + 1 scalar per phase */
+  CHECK(dm.num_var_entries == 42 * 5 + 1 + 50 * 70 + 1);
+  CHECK(dm.stored_bytes == 8 * ((int64_t)11 * 75 + dm.num_var_entries));
+  /* SURVEY.md 8(d) A_min: every x-dependent value the reference computes: 48 resp. 71 per node */
+  CHECK(dm.algorithmic_bytes == 8 * ((int64_t)dm.num_vars + 11 * 75 + 48 * 5 + 71 * 70));
+  {
+    /* the gather map covers exactly those 48 * 5 + 71 * 70 entries */
+    int32_t* src = malloc(sizeof(int32_t) * dm.total_nnz);
+    int64_t nvar = 0;
+    CHECK(gel_full_source(p, src) == GEL_OK);
+    for (int64_t k = 0; k < dm.total_nnz; k++) {
+      CHECK(src[k] >= -2 - (int32_t)dm.num_var_entries + 1 && src[k] < (int32_t)dm.num_var_entries);
+      nvar += src[k] != -1;
+    }
+    /* 8 of the 16 diagonal-block quaternion entries per node of the free-attitude phase are constants of the pattern */
+    CHECK(nvar == 48 * 5 + (71 - 8) * 70);
+    free(src);
+  }
   int32_t nch = 0;
   CHECK(gel_num_chunks(p, &nch) == GEL_OK && nch == 3); /* 5 -> 1 item, 70 -> 2 items */
 

@@ -15,7 +15,7 @@ for name in sys.argv[1:] or ["example", "3x32", "mixed-6x64", "dense-6x64", "str
     res, jv, rc = E.eval_batch(X)
     ores, ovals = P.eval_batch(X)
     full = E.expand(jv)
-    vm = np.zeros(E.total_nnz, bool); vm[E.var_index()] = True
+    vm = E.var_mask()
     d = np.abs(full - ovals)[:, vm]; ref = np.abs(ovals)[:, vm]
     excess = d - 1e-6 * ref
     print("%-14s residual %.2e   jac max|d| %.2e   worst (|d| - 1e-6|ref|) %.2e of 1e-5   max|ref| %.1f" %

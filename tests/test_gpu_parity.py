@@ -174,8 +174,7 @@ def check_against_oracle(E, P, x, what):
     assert rc == 0
     R = E.split_res(res)
     J = E.jac_dicts(vals)
-    var_mask = np.zeros(E.total_nnz, dtype=bool)
-    var_mask[E.var_index()] = True
+    var_mask = E.var_mask()
     bound = dx_roundoff_bound(E, x)
     b = 0
     for grp in oracle.GROUPS:
@@ -271,8 +270,7 @@ def test_batch_matches_single_and_oracle():
     ores, ovals = P.eval_batch(X)
     close(res, ores, what="batch residual")
     full = E.expand(jv)
-    vm = np.zeros(E.total_nnz, dtype=bool)
-    vm[E.var_index()] = True
+    vm = E.var_mask()
     d = np.abs(full - ovals)
     assert np.all(d[:, vm] <= 1e-5 + 1e-6 * np.abs(ovals[:, vm]))
     assert np.array_equal(full[:, ~vm], ovals[:, ~vm])
@@ -494,8 +492,7 @@ def test_full_size_batch_properties():
     ores, ovals = P.eval_batch(X[[0, 17, 63]])
     close(r1[[0, 17, 63]].cpu().numpy(), ores, what="full-size residual sample")
     full = E.expand(j1[[0, 17, 63]].cpu().numpy())
-    vm = np.zeros(E.total_nnz, dtype=bool)
-    vm[E.var_index()] = True
+    vm = E.var_mask()
     d = np.abs(full - ovals)
     assert np.all(d[:, vm] <= 1e-5 + 1e-6 * np.abs(ovals[:, vm]))
     assert np.array_equal(full[:, ~vm], ovals[:, ~vm])
@@ -714,7 +711,7 @@ def test_pipelined_host_batch_equals_resident_launch():
     ores, ovals = P.eval_batch(X[rows])
     close(res[rows], ores, what="pipelined residual")
     full = E.expand(jv[rows])
-    vm = np.zeros(E.total_nnz, bool); vm[E.var_index()] = True
+    vm = E.var_mask()
     assert np.all(np.abs(full - ovals)[:, vm] <= 1e-5 + 1e-6 * np.abs(ovals)[:, vm])
     # out= reuse, residual only and Jacobian only
     res2, jv2, _ = E.eval_batch(X, out=(res, jv))

@@ -36,8 +36,7 @@ def test_pattern_bit_exact_vs_reference_golden(name):
     pat = E.pattern()
     cv = E.const_values()
     vidx = E.var_index()
-    is_var = np.zeros(E.total_nnz, dtype=bool)
-    is_var[vidx] = True
+    is_var = E.var_mask()
     assert len(np.unique(vidx)) == E.V                                   # one COO entry per compact slot
     for b, (grp, var) in enumerate(BLOCKS):
         key = "jac_%s_%s" % (grp, var)
@@ -84,7 +83,7 @@ def test_pattern_matches_oracle_on_ragged_problem():
 def test_host_only_handle_cannot_evaluate():
     g = load_golden("g6_3x32.npz")
     E = host_engine(problem_from_golden(g))
-    assert E.nvars == 1285 and E.nres == 1056 and E.algorithmic_bytes == 8 * (1285 + 1056 + E.V)
+    assert E.nvars == 1285 and E.nres == 1056 and E.stored_bytes == 8 * (1056 + E.V)
     with pytest.raises(_lib.GelatoAmdError, match="host-only"):
         E.eval_residual(g["x"])
     with pytest.raises(_lib.GelatoAmdError, match="host-only"):
@@ -100,7 +99,14 @@ def test_algorithmic_bytes_match_survey():
         E = host_engine(con_dynamics.problem_arrays(pdict, unitdict))
         if a_min:
             assert E.algorithmic_bytes == a_min and E.total_nnz == 745728
-        assert E.algorithmic_bytes == 8 * (E.nvars + E.nres + E.V)
+        # every x-dependent value the reference computes; the compact vector holds the distinct
+        # ones among them (negated tf columns, the node-uniform diagonal and the structurally constant half of the
+        # quaternion diagonal blocks are restored by the gather map)
+        n_ref = int(np.count_nonzero(E.var_mask()))
+        hold = np.asarray(E.prob["attitude_hold"]) != 0
+        n_const_quat = int(8 * np.asarray(E.prob["num_nodes"])[~hold].sum())
+        assert E.algorithmic_bytes == 8 * (E.nvars + E.nres + n_ref + n_const_quat)
+        assert E.stored_bytes == 8 * (E.nres + E.V) and E.V < n_ref
 
 
 # --------------------------------------------------------------------------
@@ -249,8 +255,7 @@ def test_random_problem_structures_pattern_and_constants(seed):
         x[M:4 * M] = 0.6 + 0.05 * x[M:4 * M]
         x[-(S + 1):] = np.sort(x[-(S + 1):])
     pat, cv, vidx = E.pattern(), E.const_values(), E.var_index()
-    is_var = np.zeros(E.total_nnz, dtype=bool)
-    is_var[vidx] = True
+    is_var = E.var_mask()
     b = 0
     for grp in oracle.GROUPS:
         J1, J2 = P.jacobian(grp, x1), P.jacobian(grp, x2)
