@@ -36,6 +36,14 @@ class GelProblemDesc(C.Structure):
     ]
 
 
+class GelLinearRow(C.Structure):
+    _fields_ = [("idx0", C.c_int32), ("idx1", C.c_int32), ("coef0", C.c_double), ("coef1", C.c_double), ("c0", C.c_double)]
+
+
+class GelNodefnRow(C.Structure):
+    _fields_ = [("fn", C.c_int32), ("node", C.c_int32), ("p0", C.c_double), ("p1", C.c_double)]
+
+
 class GelDims(C.Structure):
     _fields_ = [
         ("S", C.c_int32), ("N", C.c_int32), ("M", C.c_int32), ("num_vars", C.c_int32),
@@ -80,6 +88,11 @@ SIGNATURES = {
     "gel_aero_dims": (C.c_int, [C.c_void_p, C.c_int32, _ip, _lp]),
     "gel_aero_pattern": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _ip, _ip]),
     "gel_eval_aero": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp]),
+    "gel_rows_configure": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GelLinearRow), C.c_int32, C.POINTER(GelNodefnRow)]),
+    "gel_rows_dims": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "gel_rows_eval": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
+    "gel_rows_eval_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gel_initial_guess": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp]),
     "gel_dynamics_velocity": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32,
                                          _dp, C.c_double, _dp]),
     "gel_dynamics_velocity_NoAir": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]),

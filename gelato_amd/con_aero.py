@@ -50,7 +50,7 @@ def _values(xdict, pdict, unitdict, condition, kind):
     if nspec == 0:
         return None
     con, _, rc = st.engine.eval_aero(kind, pack_x(xdict), want_jac=False)
-    st.status = rc
+    st.status |= rc
     return con[0]
 
 
@@ -69,7 +69,7 @@ def _jacobian(xdict, pdict, unitdict, condition, kind):
         pats[kind] = eng.aero_pattern(kind)
     nrow, nnz = eng.aero_dims(kind)
     _, jv, rc = eng.eval_aero(kind, pack_x(xdict), want_jac=True)
-    st.status = rc
+    st.status |= rc
     shapes = [(nrow, pdict["M"] * 3), (nrow, pdict["M"] * 3), (nrow, pdict["M"] * 4),
               (nrow, pdict["num_sections"] + 1)]
     jac, off = {}, 0

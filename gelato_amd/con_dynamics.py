@@ -62,17 +62,17 @@ class _State:
     def residuals(self, xdict):
         x = pack_x(xdict)
         if self.x_res is None or not np.array_equal(x, self.x_res):
-            self.res, rc = self.engine.eval_residual(x)
+            self.res, self.rc_res = self.engine.eval_residual(x)
             self.x_res = x
-            self.status = rc
+        self.status |= self.rc_res          # also when the cached result is handed out again
         return self.engine.split_res(self.res)
 
     def jacobians(self, xdict):
         x = pack_x(xdict)
         if self.x_jac is None or not np.array_equal(x, self.x_jac):
-            self.vals, rc = self.engine.eval_jacobian(x, out=self.vals)
+            self.vals, self.rc_jac = self.engine.eval_jacobian(x, out=self.vals)
             self.x_jac = x
-            self.status = rc
+        self.status |= self.rc_jac
         return self.engine.jac_dicts(self.vals)
 
 
@@ -89,8 +89,23 @@ def engine_of(pdict, unitdict):
 
 
 def last_status(pdict):
+    """Status of the evaluations since the last reset_status(): 0 fine, 1 some output was NaN / Inf.  It is STICKY: every
+    device evaluation of this pdict (defect groups, aero path constraints, knot / terminal / user rows) ORs its status
+    in, so it can be read once at the end of objfunc / sens whatever the order of the calls."""
     st = pdict.get(_KEY)
     return 0 if st is None else st.status
+
+
+def reset_status(pdict):
+    st = pdict.get(_KEY)
+    if st is not None:
+        st.status = 0
+
+
+def note_status(pdict, rc):
+    st = pdict.get(_KEY)
+    if st is not None:
+        st.status |= int(rc)
 
 
 def _copy_jac(j, pdict=None):

@@ -1,0 +1,255 @@
+"""Initial, knot-time, knotting, terminal and time-ordering constraints on the GPU.
+
+Drop-in for the reference's lib/con_init_terminal_knot.py: the same ten functions with the same
+``fn(xdict, pdict, unitdict, condition)`` signature and the same return layouts
+
+  equality_init / equality_time / equality_knot_LGR / equality_6DoF_LGR_terminal / inequality_time   -> 1-D ndarray
+  equality_jac_* / inequality_jac_time   -> {var: {"coo": [rows i4, cols i4, vals f8], "shape": (r, c)}}
+
+(lib/con_init_terminal_knot.py:39-52,55-115,118-141,144-171,174-252,255-326,329-375,378-405,408-421,424-452).
+
+All five groups are rows of ONE device table on the handle of the defect path (gel_rows_configure): four of them are
+differences of single decision variables plus a constant ("linear rows", constant Jacobians laid out here in the
+reference's emission order); the terminal group is three functions of the last state node with a six-column forward
+difference formed in the kernel ("node-function rows").  The first call for a new xdict evaluates every row in one
+launch; the other calls return slices of it.  xdict is never mutated.
+"""
+import math
+
+import numpy as np
+
+from . import con_dynamics
+from .engine import pack_x
+
+_MU = 3.986004418e14
+_RA = 6378137.0
+
+
+def _i4(a):
+    return np.asarray(a, dtype=np.int32)
+
+
+def _coo(rows, cols, vals, shape):
+    return {"coo": [_i4(rows), _i4(cols), np.asarray(vals, dtype=np.float64)], "shape": tuple(int(v) for v in shape)}
+
+
+def _terminal_targets(condition):
+    """c_target, e_target of equality_6DoF_LGR_terminal (:343-360; src/wrapper_coordinate.hpp:252-265)."""
+    hp, ha = condition.get("altitude_perigee"), condition.get("altitude_apogee")
+    if hp is not None and ha is not None:
+        ra, rp = _RA + hp, _RA + ha               # the reference passes (perigee, apogee) as (ha, hp)
+        a = (ra + rp) / 2.0
+        return rp * math.sqrt(_MU * (2.0 / rp - 1.0 / a)), -_MU / 2.0 / a
+    c_target = condition["radius"] * condition["vel_tangential_geocentric"]
+    vf = condition["vel_tangential_geocentric"] / math.cos(math.radians(condition["flightpath_vel_inertial_geocentric"]))
+    return c_target, vf ** 2 / 2.0 - _MU / condition["radius"]
+
+
+class _Rows:
+    """The row table of one (pdict, unitdict, condition): linear rows of the init / time / knot / time-ordering groups,
+    node-function rows of the terminal group (and of the user constraints, see con_user.py), their constant COO blocks."""
+
+    def __init__(self, pdict, unitdict, condition, user_rows=()):
+        eng = con_dynamics.engine_of(pdict, unitdict)
+        S, M = pdict["num_sections"], pdict["M"]
+        ps, P, ev = pdict["ps_params"], pdict["params"], pdict["event_index"]
+        o = {k: eng.var_offset(k) for k in ("mass", "position", "velocity", "quaternion", "t")}
+        xa = [ps.index_start_x(i) for i in range(S)]
+        lin = []            # (idx0, coef0, idx1, coef1, c0): (coef0 x[idx0] + coef1 x[idx1]) + c0
+        self.slices = {}
+        self.jac = {}
+
+        def ref_of(i):
+            tr = P[i].get("time_ref")
+            return ev[tr] if isinstance(tr, str) and tr in ev else -1
+
+        # ---- equality_init (:39-52): first state node minus the launch state; ones in the Jacobian (:55-115)
+        k0 = len(lin)
+        payload = condition["OptimizationMode"] == "Payload"
+        init = condition["init"]
+        if not payload:
+            lin.append((o["mass"], 1.0, -1, 0.0, -(init["mass"] / unitdict["mass"])))
+        for key, w in (("position", 3), ("velocity", 3), ("quaternion", 4)):
+            unit = 1.0 if key == "quaternion" else unitdict[key]
+            for c in range(w):
+                lin.append((o[key] + c, 1.0, -1, 0.0, -(np.asarray(init[key], dtype=np.float64)[c] / unit)))
+        self.slices["init"] = (k0, len(lin))
+        r0 = 0 if payload else 1
+        nrow = 10 + r0
+        j = {} if payload else {"mass": _coo([0], [0], [1.0], (nrow, M))}
+        j["position"] = _coo(range(r0, r0 + 3), range(3), np.ones(3), (nrow, 3 * M))
+        j["velocity"] = _coo(range(r0 + 3, r0 + 6), range(3), np.ones(3), (nrow, 3 * M))
+        j["quaternion"] = _coo(range(r0 + 6, r0 + 10), range(4), np.ones(4), (nrow, 4 * M))
+        self.jac["init"] = j
+
+        # ---- equality_time (:118-141): t0 fixed; knots tied to their reference event keep their offset (:144-171)
+        k0 = len(lin)
+        lin.append((o["t"], 1.0, -1, 0.0, -(P[0]["time"] / unitdict["t"])))
+        rows, cols, vals = [0], [0], [1.0]
+        for i in range(1, S + 1):
+            k = ref_of(i)
+            if k >= 0:
+                lin.append((o["t"] + i, 1.0, o["t"] + k, -1.0, -((P[i]["time"] - P[k]["time"]) / unitdict["t"])))
+                r = len(lin) - k0 - 1
+                rows += [r, r]; cols += [i, k]; vals += [1.0, -1.0]
+        self.slices["time"] = (k0, len(lin))
+        self.jac["time"] = {"t": _coo(rows, cols, vals, (len(lin) - k0, S + 1))}
+
+        # ---- equality_knot_LGR (:174-252): stage mass between ignition and separation; continuity at every knot,
+        #      mass with the jettisoned amount; +-1 in the Jacobian (:255-326)
+        k0 = len(lin)
+        E = {k: ([], [], []) for k in ("mass", "position", "velocity", "quaternion")}
+        seps = []
+        for stage in pdict["RocketStage"].values():
+            if stage["separation_at"] is None:
+                continue
+            ig, sep = ev[stage["ignition_at"]], ev[stage["separation_at"]]
+            seps.append(sep)
+            mass_stage = stage["mass_dry"] + stage["mass_propellant"] + sum(it["mass"] for it in (stage["dropMass"] or {}).values())
+            r = len(lin) - k0
+            lin.append((o["mass"] + xa[ig], 1.0, o["mass"] + xa[sep], -1.0, -(mass_stage / unitdict["mass"])))
+            E["mass"][0].extend([r, r]); E["mass"][1].extend([xa[ig], xa[sep]]); E["mass"][2].extend([1.0, -1.0])
+        for i in range(1, S):
+            a = xa[i]
+            if i not in seps:
+                r = len(lin) - k0
+                lin.append((o["mass"] + a, 1.0, o["mass"] + a - 1, -1.0, P[i]["mass_jettison"] / unitdict["mass"]))
+                E["mass"][0].extend([r, r]); E["mass"][1].extend([a - 1, a]); E["mass"][2].extend([-1.0, 1.0])
+            for key, w in (("position", 3), ("velocity", 3), ("quaternion", 4)):
+                r = len(lin) - k0
+                for c in range(w):
+                    lin.append((o[key] + a * w + c, 1.0, o[key] + (a - 1) * w + c, -1.0, 0.0))
+                rr = list(range(r, r + w))
+                E[key][0].extend(rr + rr)
+                E[key][1].extend(list(range((a - 1) * w, a * w)) + list(range(a * w, (a + 1) * w)))
+                E[key][2].extend([-1.0] * w + [1.0] * w)
+        self.slices["knot"] = (k0, len(lin))
+        nrow = len(lin) - k0
+        width = {"mass": M, "position": 3 * M, "velocity": 3 * M, "quaternion": 4 * M}
+        self.jac["knot"] = {k: _coo(E[k][0], E[k][1], E[k][2], (nrow, width[k])) for k in E}
+
+        # ---- inequality_time (:408-421): knots not both tied to reference events stay ordered (:424-452)
+        k0 = len(lin)
+        rows, cols, vals = [], [], []
+        for i in range(S):
+            if not (ref_of(i) >= 0 and ref_of(i + 1) >= 0):
+                r = len(lin) - k0
+                lin.append((o["t"] + i + 1, 1.0, o["t"] + i, -1.0, 0.0))
+                rows += [r, r]; cols += [i, i + 1]; vals += [-1.0, 1.0]
+        self.slices["tineq"] = (k0, len(lin))
+        self.jac["tineq"] = {"t": _coo(rows, cols, vals, (len(lin) - k0, S + 1))}
+
+        # ---- equality_6DoF_LGR_terminal (:329-375): energy, angular momentum (and inclination) of the LAST state node
+        fn = []
+        if any(condition.get(k) is not None for k in ("altitude_perigee", "radius")):
+            c_target, e_target = _terminal_targets(condition)
+            fn += [("orbit_energy", M - 1, e_target, 1.0), ("angular_momentum", M - 1, c_target, 1.0)]
+            if condition.get("inclination") is not None:
+                fn.append(("inclination_rad", M - 1, 1.0, math.radians(condition["inclination"])))
+        self.n_terminal = len(fn)
+        # (:378-405) one COO column per perturbed variable, all rows of it: position columns then velocity columns
+        nT = self.n_terminal
+        self.terminal_pattern = (_i4(np.tile(np.arange(nT), 3)), _i4(np.repeat(np.arange(3 * M - 3, 3 * M), nT)))
+        # ---- user rows (con_user.py): node functions at the first state node of a named section
+        self.user_rows = list(user_rows)
+        for (f, section, p0, p1) in self.user_rows:
+            fn.append((f, xa[ev[section]], p0, p1))
+        self.nlin, self.nfn = len(lin), len(fn)
+        self.lin, self.fn = lin, fn
+        self.user_nodes = [xa[ev[section]] for (_, section, _, _) in self.user_rows]
+        eng.rows_configure(lin, fn)
+        self.engine = eng
+        self.M = M
+        self.x = None
+        self.con = self.jfn = None
+
+    def evaluate(self, xdict, pdict):
+        x = pack_x(xdict)
+        if self.x is None or not np.array_equal(x, self.x):
+            con, jfn, rc = self.engine.rows_eval(x, want_jac=True)
+            self.con, self.jfn, self.x, self.rc = con[0], jfn[0], x, rc
+        con_dynamics.note_status(pdict, self.rc)     # also when the cached result is handed out again
+        return self.con, self.jfn
+
+
+def rows_of(pdict, unitdict, condition):
+    """The (cached) row table of this problem; rebuilt when the terminal targets or the user rows change."""
+    st = con_dynamics._state(pdict, unitdict)
+    user = tuple(tuple(r) for r in (pdict.get("gelato_amd_user_rows") or ()))
+    key = (id(condition), condition["OptimizationMode"], tuple(condition.get(k) for k in (
+        "altitude_perigee", "altitude_apogee", "inclination", "radius", "vel_tangential_geocentric",
+        "flightpath_vel_inertial_geocentric")), user)
+    cached = st.__dict__.get("rows")
+    if cached is None or cached[0] != key:
+        st.rows = (key, _Rows(pdict, unitdict, condition, user))
+    return st.rows[1]
+
+
+def _values(xdict, pdict, unitdict, condition, group):
+    R = rows_of(pdict, unitdict, condition)
+    con, _ = R.evaluate(xdict, pdict)
+    a, b = R.slices[group]
+    return con[a:b].copy()
+
+
+def _const_jac(pdict, unitdict, condition, group):
+    j = rows_of(pdict, unitdict, condition).jac[group]
+    return {var: {"coo": [b["coo"][0], b["coo"][1], b["coo"][2].copy()], "shape": b["shape"]} for var, b in j.items()}
+
+
+def equality_init(xdict, pdict, unitdict, condition):
+    """Equality constraint about initial conditions."""
+    return _values(xdict, pdict, unitdict, condition, "init")
+
+
+def equality_jac_init(xdict, pdict, unitdict, condition):
+    """Jacobian of equality_init."""
+    return _const_jac(pdict, unitdict, condition, "init")
+
+
+def equality_time(xdict, pdict, unitdict, condition):
+    """Equality constraint about time of knots."""
+    return _values(xdict, pdict, unitdict, condition, "time")
+
+
+def equality_jac_time(xdict, pdict, unitdict, condition):
+    """Jacobian of equality_time."""
+    return _const_jac(pdict, unitdict, condition, "time")
+
+
+def equality_knot_LGR(xdict, pdict, unitdict, condition):
+    """Equality constraint about knotting conditions."""
+    return _values(xdict, pdict, unitdict, condition, "knot")
+
+
+def equality_jac_knot_LGR(xdict, pdict, unitdict, condition):
+    """Jacobian of equality_knot."""
+    return _const_jac(pdict, unitdict, condition, "knot")
+
+
+def equality_6DoF_LGR_terminal(xdict, pdict, unitdict, condition):
+    """Equality constraint about terminal condition."""
+    R = rows_of(pdict, unitdict, condition)
+    con, _ = R.evaluate(xdict, pdict)
+    return con[R.nlin:R.nlin + R.n_terminal].copy()
+
+
+def equality_jac_6DoF_LGR_terminal(xdict, pdict, unitdict, condition):
+    """Jacobian of equality_terminal."""
+    R = rows_of(pdict, unitdict, condition)
+    _, jfn = R.evaluate(xdict, pdict)
+    nT, M = R.n_terminal, R.M
+    rows, cols = R.terminal_pattern
+    J = jfn[:nT]                                           # [row][position xyz, velocity xyz]
+    return {"position": {"coo": [rows, cols, J[:, 0:3].T.ravel().copy()], "shape": (nT, 3 * M)},
+            "velocity": {"coo": [rows, cols, J[:, 3:6].T.ravel().copy()], "shape": (nT, 3 * M)}}
+
+
+def inequality_time(xdict, pdict, unitdict, condition):
+    """Inequality constraint about time at knots."""
+    return _values(xdict, pdict, unitdict, condition, "tineq")
+
+
+def inequality_jac_time(xdict, pdict, unitdict, condition):
+    """Jacobian of inequality_time."""
+    return _const_jac(pdict, unitdict, condition, "tineq")

@@ -49,6 +49,10 @@ struct AeroRowDev {
   double limit;                // units[3] of con_aero.py
 };
 
+// knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py): see gel_kernels.hip rows_kernel
+struct LinRowDev { int32_t idx0, idx1; double coef0, coef1, c0; };  // (coef0 x[idx0] + coef1 x[idx1]) + c0; idx1 < 0: one term
+struct FnRowDev { int32_t fn, node; double p0, p1; };               // f(position, velocity of state node) / p0 - p1
+
 struct ProblemDev {
   int32_t S, N, M, nvars;
   int32_t Kw, Kc;

@@ -163,6 +163,15 @@ struct gel_problem {
   size_t jfd_J_cap = 0;                                       // doubles
   std::vector<double> jfd_last_x;                             // empty = nothing cached
   int jfd_status = GEL_OK;
+  // knot / terminal / user rows (gel_rows_configure)
+  std::vector<gel::LinRowDev> lin_rows;
+  std::vector<gel::FnRowDev> fn_rows;
+  gel::LinRowDev* d_lin_rows = nullptr;
+  gel::FnRowDev* d_fn_rows = nullptr;
+  double* h_rows = nullptr;                                   // pinned outputs of small gel_rows_eval calls: con | jfn
+  size_t h_rows_cap = 0;                                      // doubles
+  double *d_rows_x = nullptr, *d_rows_out = nullptr;          // working set of large host-buffer calls
+  size_t d_rows_x_cap = 0, d_rows_out_cap = 0;                // doubles
   double* h_aero = nullptr;                                   // pinned outputs of small gel_eval_aero calls
   size_t h_aero_cap = 0;                                      // doubles
   // large host batches (gel_eval_batch): two staging slots of kPipeEvals decision vectors each, every
@@ -769,6 +778,8 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->h_jv) hipHostFree(p->h_jv);
   if (p->h_flag) hipHostFree(p->h_flag);
   if (p->h_aero) hipHostFree(p->h_aero);
+  if (p->h_rows) hipHostFree(p->h_rows);
+  hipFree(p->d_lin_rows); hipFree(p->d_fn_rows); hipFree(p->d_rows_x); hipFree(p->d_rows_out);
   hipFree(p->jfd_x); hipFree(p->jfd_Xp); hipFree(p->jfd_res); hipFree(p->jfd_J);
   delete p;
   return GEL_OK;
@@ -1167,6 +1178,135 @@ int gel_eval_aero(gel_problem* p, int32_t kind, int32_t B, const double* x, doub
 #undef HIPCHK3
   cleanup();
   if (*p->h_flag) { hipMemsetAsync(p->d_flag, 0, 4, p->stream); return GEL_NONFINITE; }
+  return GEL_OK;
+}
+
+// ------------- knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py) -------------
+int gel_rows_configure(gel_problem* p, int32_t nlin, const gel_linear_row* lin, int32_t nfn, const gel_nodefn_row* fn) {
+  if (!p || nlin < 0 || nfn < 0 || (nlin && !lin) || (nfn && !fn)) return fail(GEL_ERR_ARG, "bad argument");
+  for (int i = 0; i < nlin; i++)
+    if (lin[i].idx0 < 0 || lin[i].idx0 >= p->dims.num_vars || lin[i].idx1 >= p->dims.num_vars)
+      return fail(GEL_ERR_ARG, "linear row: variable index out of range");
+  for (int i = 0; i < nfn; i++)
+    if (fn[i].fn < 0 || fn[i].fn > 8 || fn[i].node < 0 || fn[i].node >= p->dims.M || !(fn[i].p0 != 0.0))
+      return fail(GEL_ERR_ARG, "node-function row: unknown function, node out of range, or zero scale");
+  p->lin_rows.resize(nlin);
+  p->fn_rows.resize(nfn);
+  for (int i = 0; i < nlin; i++) p->lin_rows[i] = gel::LinRowDev{lin[i].idx0, lin[i].idx1 < 0 ? -1 : lin[i].idx1, lin[i].coef0, lin[i].coef1, lin[i].c0};
+  for (int i = 0; i < nfn; i++) p->fn_rows[i] = gel::FnRowDev{fn[i].fn, fn[i].node, fn[i].p0, fn[i].p1};
+  if (p->device == GEL_DEVICE_NONE) return GEL_OK;
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  hipFree(p->d_lin_rows); hipFree(p->d_fn_rows);
+  p->d_lin_rows = nullptr; p->d_fn_rows = nullptr;
+  int rc = GEL_OK;
+  if ((rc = upload(&p->d_lin_rows, p->lin_rows)) || (rc = upload(&p->d_fn_rows, p->fn_rows))) return rc;
+  return GEL_OK;
+}
+
+int gel_rows_dims(const gel_problem* p, int32_t* nlin, int32_t* nfn) {
+  if (!p || !nlin || !nfn) return fail(GEL_ERR_ARG, "null argument");
+  *nlin = (int32_t)p->lin_rows.size();
+  *nfn = (int32_t)p->fn_rows.size();
+  return GEL_OK;
+}
+
+int gel_rows_eval_device(gel_problem* p, int32_t B, const double* d_x, double* d_con, double* d_jfn, void* stream) {
+  if (!p || B < 1 || !d_x || !d_con) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  HIPCHK(gel::launch_rows(p->dev, (int)p->lin_rows.size(), p->d_lin_rows, (int)p->fn_rows.size(), p->d_fn_rows, B, d_x,
+                          d_con, d_jfn, stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
+namespace {
+// grows a device or pinned buffer; on failure the buffer is gone and its capacity is 0 (never a stale pointer)
+int grow(double** buf, size_t* cap, size_t need, bool pinned) {
+  if (*cap >= need) return GEL_OK;
+  if (*buf) { if (pinned) hipHostFree(*buf); else hipFree(*buf); }
+  *buf = nullptr; *cap = 0;
+  HIPCHK(pinned ? hipHostMalloc((void**)buf, need * 8) : hipMalloc((void**)buf, need * 8));
+  *cap = need;
+  return GEL_OK;
+}
+}  // namespace
+
+int gel_rows_eval(gel_problem* p, int32_t B, const double* x, double* con, double* jfn) {
+  if (!p || B < 1 || !x || !con) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  const size_t R = p->lin_rows.size() + p->fn_rows.size(), nf = p->fn_rows.size();
+  if (R == 0) return GEL_OK;
+  HIPCHK(hipSetDevice(p->device));
+  const size_t nx = (size_t)B * p->dims.num_vars, nc = (size_t)B * R, nj = jfn ? (size_t)B * nf * 6 : 0;
+  int rc;
+  if ((nx + nc + nj) * 8 <= kZeroCopyBytes) {
+    // the optimiser's callback: the kernel reads x from and writes to pinned host memory, one launch + one synchronise
+    if ((rc = ensure_capacity(p, B)) || (rc = grow(&p->h_rows, &p->h_rows_cap, nc + nj + 1, true))) return rc;
+    std::memcpy(p->h_x, x, nx * 8);
+    gel::ProblemDev dv = p->dev;
+    dv.flag = p->h_flag;
+    HIPCHK(gel::launch_rows(dv, (int)p->lin_rows.size(), p->d_lin_rows, (int)nf, p->d_fn_rows, B, p->h_x, p->h_rows,
+                            jfn ? p->h_rows + nc : nullptr, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    std::memcpy(con, p->h_rows, nc * 8);
+    if (jfn) std::memcpy(jfn, p->h_rows + nc, nj * 8);
+    if (*p->h_flag) { *p->h_flag = 0; return GEL_NONFINITE; }
+    return GEL_OK;
+  }
+  if ((rc = grow(&p->d_rows_x, &p->d_rows_x_cap, nx, false)) || (rc = grow(&p->d_rows_out, &p->d_rows_out_cap, nc + nj + 1, false))) return rc;
+  HIPCHK(hipMemcpyAsync(p->d_rows_x, x, nx * 8, hipMemcpyHostToDevice, p->stream));
+  HIPCHK(gel::launch_rows(p->dev, (int)p->lin_rows.size(), p->d_lin_rows, (int)nf, p->d_fn_rows, B, p->d_rows_x,
+                          p->d_rows_out, jfn ? p->d_rows_out + nc : nullptr, p->stream));
+  HIPCHK(hipMemcpyAsync(con, p->d_rows_out, nc * 8, hipMemcpyDeviceToHost, p->stream));
+  if (jfn) HIPCHK(hipMemcpyAsync(jfn, p->d_rows_out + nc, nj * 8, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (*p->h_flag) { *p->h_flag = 0; HIPCHK(hipMemsetAsync(p->d_flag, 0, 4, p->stream)); return GEL_NONFINITE; }
+  return GEL_OK;
+}
+
+// ------------- from-file initial guess on the host (initialize.py:322-409) -------------
+int gel_initial_guess(const gel_problem* p, int32_t nref, const double* t_ref, const double* table,
+                      const double* knot_times, double* x) {
+  if (!p || !t_ref || !table || !knot_times || !x || nref < 2) return fail(GEL_ERR_ARG, "bad argument (>= 2 reference rows)");
+  // repeated times are legal (the example's table repeats every knot: end of one section = start of the next); a
+  // bracket [lo, hi] found by lower_bound never has zero width unless the table STARTS with a repeat
+  for (int k = 1; k < nref; k++)
+    if (!(t_ref[k] >= t_ref[k - 1])) return fail(GEL_ERR_ARG, "reference times must not decrease");
+  const int S = p->dims.S, M = p->dims.M, N = p->dims.N;
+  // scipy interp1d(kind="linear", fill_value="extrapolate"): hi = first knot >= t clipped to [1, nref - 1], lo = hi - 1,
+  // y = slope * (t - t_lo) + y_lo with slope = (y_hi - y_lo) / (t_hi - t_lo): the end intervals extend beyond the table
+  auto interp = [&](double t, int col0, int ncol, double unit, double* out) {
+    int hi = (int)(std::lower_bound(t_ref, t_ref + nref, t) - t_ref);
+    hi = std::min(std::max(hi, 1), nref - 1);
+    const int lo = hi - 1;
+    for (int c = 0; c < ncol; c++) {
+      const double ylo = table[(size_t)lo * 13 + col0 + c], yhi = table[(size_t)hi * 13 + col0 + c];
+      const double slope = (yhi - ylo) / (t_ref[hi] - t_ref[lo]);
+      const double rise = slope * (t - t_ref[lo]);  // its own statement: no fused multiply-add, the bits scipy produces
+      out[c] = (rise + ylo) / unit;
+    }
+  };
+  double* xm = x; double* xr = x + M; double* xv = x + 4 * (size_t)M; double* xq = x + 7 * (size_t)M;
+  double* xu = x + 11 * (size_t)M; double* xt = x + 11 * (size_t)M + 2 * (size_t)N;
+  for (int i = 0; i < S; i++) {
+    const HostPhase& h = p->ph[i];
+    const double to = knot_times[i], tf = knot_times[i + 1];
+    for (int k = 0; k <= h.n; k++) {  // state nodes: tau_x = [-1, tau]
+      const double tau = (k == 0) ? -1.0 : h.tau[k - 1];
+      const double t = tau * (tf - to) / 2.0 + (tf + to) / 2.0;
+      const int node = h.xa + k;
+      interp(t, 0, 1, p->um, xm + node);
+      interp(t, 1, 3, p->up, xr + 3 * (size_t)node);
+      interp(t, 4, 3, p->uv, xv + 3 * (size_t)node);
+      interp(t, 7, 4, 1.0, xq + 4 * (size_t)node);
+    }
+    for (int k = 0; k < h.n; k++) {   // control nodes: tau
+      const double t = h.tau[k] * (tf - to) / 2.0 + (tf + to) / 2.0;
+      interp(t, 11, 2, p->uu, xu + 2 * (size_t)(h.ua + k));
+    }
+  }
+  for (int i = 0; i <= S; i++) xt[i] = knot_times[i] / p->ut;
   return GEL_OK;
 }
 

@@ -350,6 +350,91 @@ __global__ void aero_kernel(ProblemDev P, int kind, int nrows, const AeroRowDev*
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 
+// ---------------------------------------------------------------------------
+// Knot / terminal / user rows.
+//
+// Linear rows: (coef0 x[idx0] + coef1 x[idx1]) + c0 -- equality_init, equality_time, inequality_time and
+// equality_knot_LGR (lib/con_init_terminal_knot.py:39-52,118-141,174-252,422-436) are differences of single decision
+// variables plus a constant; with coefficients +-1 the expression rounds exactly like the reference's
+// (a - b) - c.  Their Jacobians are the coefficients (constant COO, laid out by the caller).
+//
+// Node-function rows: g = f(r, v) / p0 - p1 at ONE state node, r = position * unit, v = velocity * unit, and the forward
+// difference (g(x + dx e_c) - g(x)) / dx over exactly the six columns the row can see (lib/con_init_terminal_knot.py:
+// 378-405 perturbs the last node's six columns; lib/jac_fd.py:29-62 perturbs every column of x, and every column but
+// these six returns an exact zero).  Eight lanes per row: lane 0 the centre, lanes 1..6 one perturbed column each,
+// formed in the kernel -- no perturbed copies of x exist anywhere.
+//   fn 0 orbit energy (src/wrapper_coordinate.hpp:246-250)   1 |angular momentum| (:222-228)   2 inclination [rad] (:229-236)
+//   fn 3 a   4 e   5 a (1 - e)   6 a (1 + e)   (src/Coordinate.cpp:197-245: p = c.c/mu, e = |f|/mu, a = p/(1 - e^2))
+//   fn 7 |r|   8 |v|
+// ---------------------------------------------------------------------------
+GEL_DEV double node_fn(int fn, const double r[3], const double v[3]) {
+  const double rn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (fn == 0) return 0.5 * vn * vn - kMu / rn;
+  if (fn == 7) return rn;
+  if (fn == 8) return vn;
+  const double c[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};  // r x v
+  const double c2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+  if (fn == 1) return sqrt(c2);
+  if (fn == 2) return acos(c[2] / sqrt(c2));
+  // Laplace vector f = v x c - mu r/|r|
+  const double f[3] = {v[1] * c[2] - v[2] * c[1] - kMu * (r[0] / rn), v[2] * c[0] - v[0] * c[2] - kMu * (r[1] / rn),
+                       v[0] * c[1] - v[1] * c[0] - kMu * (r[2] / rn)};
+  const double e = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]) / kMu;
+  if (fn == 4) return e;
+  const double a = (c2 / kMu) / (1.0 - e * e);
+  if (fn == 3) return a;
+  return (fn == 5) ? a * (1.0 - e) : a * (1.0 + e);
+}
+
+__global__ void rows_kernel(ProblemDev P, int nlin, const LinRowDev* __restrict__ lin, int nfn,
+                            const FnRowDev* __restrict__ fr, int B, int lin_blocks, const double* __restrict__ x,
+                            double* __restrict__ con, double* __restrict__ jfn) {
+  const int R = nlin + nfn;
+  double chk = 0.0;
+  if ((int)blockIdx.x < lin_blocks) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)B * nlin) return;
+    const int b = (int)(t / nlin), r = (int)(t - (long long)b * nlin);
+    const LinRowDev L = lin[r];
+    const double* xb = x + (size_t)b * P.nvars;
+    double s = L.coef0 * xb[L.idx0];
+    if (L.idx1 >= 0) s += L.coef1 * xb[L.idx1];
+    chk = con[(size_t)b * R + r] = s + L.c0;
+  } else {
+    const long long t = (long long)(blockIdx.x - lin_blocks) * blockDim.x + threadIdx.x;
+    const long long grp = t >> 3;
+    const int sw = (int)(t & 7);                       // 0 centre, 1..3 position xyz + dx, 4..6 velocity xyz + dx, 7 idle
+    const bool live = grp < (long long)B * nfn;
+    const long long g2 = live ? grp : 0;
+    const int b = (int)(g2 / nfn), row = (int)(g2 - (long long)b * nfn);
+    const FnRowDev F = fr[row];
+    const double* xb = x + (size_t)b * P.nvars;
+    double r[3], v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      // xdict[key][j] += dx, then * unit (con_init_terminal_knot.py:340-341,392-394)
+      const double pe = xb[P.M + 3 * F.node + c], ve = xb[4 * P.M + 3 * F.node + c];
+      r[c] = ((sw == 1 + c) ? pe + P.dx : pe) * P.up;
+      v[c] = ((sw == 4 + c) ? ve + P.dx : ve) * P.uv;
+    }
+    const double g = node_fn(F.fn, r, v) / F.p0 - F.p1;
+    const double gc = __shfl(g, (int)(threadIdx.x & 63 & ~7), 64);  // the centre value of this row's lane group
+    if (!live || sw == 7) return;
+    if (sw == 0) chk = con[(size_t)b * R + nlin + row] = g;
+    else if (jfn) chk = jfn[((size_t)b * nfn + row) * 6 + (sw - 1)] = (g - gc) / P.dx;
+  }
+  if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
+}
+
+hipError_t launch_rows(const ProblemDev& P, int nlin, const LinRowDev* lin, int nfn, const FnRowDev* fr, int B,
+                       const double* d_x, double* d_con, double* d_jfn, hipStream_t s) {
+  if (B <= 0 || nlin + nfn <= 0) return hipSuccess;
+  const int lb = (int)(((long long)B * nlin + 255) / 256), fb = (int)(((long long)B * nfn * 8 + 255) / 256);
+  hipLaunchKernelGGL(rows_kernel, dim3((unsigned)(lb + fb)), dim3(256), 0, s, P, nlin, lin, nfn, fr, B, lb, d_x, d_con, d_jfn);
+  return hipGetLastError();
+}
+
 hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDev* rows, int B, const double* d_x,
                        double* d_con, double* d_jac, hipStream_t s) {
   if (B <= 0 || nrows <= 0) return hipSuccess;

@@ -29,6 +29,9 @@ hipError_t launch_point(int kind, int n, const double* in, const double* aux, in
 hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDev* rows, int B, const double* d_x,
                        double* d_con, double* d_jac, hipStream_t s);
 
+hipError_t launch_rows(const ProblemDev& P, int nlin, const LinRowDev* lin, int nfn, const FnRowDev* fr, int B,
+                       const double* d_x, double* d_con, double* d_jfn, hipStream_t s);
+
 // US-1976 layer table as the kernels expect it: Lmb[11] | Tmb[11] | Pb[11] | R[11] | pexp[11] | gR[11] | Hb[11] | 1/Tmb[11]
 constexpr int kAtmTableDoubles = 88;  // must equal kAtmDoubles of gel_physics.h (static_assert in gel_kernels.hip)
 void fill_atmosphere_table(double* atm);

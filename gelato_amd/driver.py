@@ -9,7 +9,8 @@ timers the reference prints (:511-517).
 """
 import time
 
-from . import con_aero, con_dynamics
+from . import con_aero, con_dynamics, con_user
+from . import con_init_terminal_knot as con_a
 from .cost_gradient import cost_6DoF, cost_jac
 
 # wrt map of the four groups (Trajectory_Optimization.py:361-364)
@@ -25,33 +26,50 @@ def make_callbacks(pdict, unitdict, condition):
     # the aero path constraints take part when the condition dict carries any of their tables
     aero = any(k in condition for k in ("AOA_max", "dynamic_pressure_max", "Q_alpha_max"))
 
+    # the init / time / knot / terminal rows (and user rows) take part when the problem description carries what they read
+    rows = all(k in pdict for k in ("event_index", "RocketStage")) and "init" in condition
+
     def objfunc(xdict):
+        con_dynamics.reset_status(pdict)         # the status is sticky over ALL device evaluations of this callback
         funcs = {"obj": cost_6DoF(xdict, condition)}
+        if rows:  # Trajectory_Optimization.py:197-198,212-216,220,233,241
+            funcs["eqcon_init"] = con_a.equality_init(xdict, pdict, unitdict, condition)
+            funcs["eqcon_time"] = con_a.equality_time(xdict, pdict, unitdict, condition)
+            funcs["eqcon_knot"] = con_a.equality_knot_LGR(xdict, pdict, unitdict, condition)
+            funcs["eqcon_terminal"] = con_a.equality_6DoF_LGR_terminal(xdict, pdict, unitdict, condition)
+            funcs["eqcon_user"] = con_user.equality_user(xdict, pdict, unitdict, condition)
+            funcs["ineqcon_time"] = con_a.inequality_time(xdict, pdict, unitdict, condition)
+            funcs["ineqcon_user"] = con_user.inequality_user(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_mass"] = con_dynamics.equality_dynamics_mass(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_pos"] = con_dynamics.equality_dynamics_position(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_vel"] = con_dynamics.equality_dynamics_velocity(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_quat"] = con_dynamics.equality_dynamics_quaternion(xdict, pdict, unitdict, condition)
-        fail = con_dynamics.last_status(pdict)
         if aero:  # Trajectory_Optimization.py:214-221 (None when a kind has no entry, like the reference)
             funcs["ineqcon_alpha"] = con_aero.inequality_max_alpha(xdict, pdict, unitdict, condition)
             funcs["ineqcon_q"] = con_aero.inequality_max_q(xdict, pdict, unitdict, condition)
             funcs["ineqcon_qalpha"] = con_aero.inequality_max_qalpha(xdict, pdict, unitdict, condition)
-            fail |= con_dynamics.last_status(pdict)
-        return funcs, bool(fail)
+        return funcs, bool(con_dynamics.last_status(pdict))
 
     def sens(xdict, funcs):
+        con_dynamics.reset_status(pdict)
         fs = {"obj": cost_jac(xdict, condition)}
+        if rows:  # Trajectory_Optimization.py:248-249,264-269,279-281,297-299,309-311
+            fs["eqcon_init"] = con_a.equality_jac_init(xdict, pdict, unitdict, condition)
+            fs["eqcon_time"] = con_a.equality_jac_time(xdict, pdict, unitdict, condition)
+            fs["eqcon_knot"] = con_a.equality_jac_knot_LGR(xdict, pdict, unitdict, condition)
+            fs["eqcon_terminal"] = con_a.equality_jac_6DoF_LGR_terminal(xdict, pdict, unitdict, condition)
+            fs["eqcon_user"] = con_user.equality_jac_user(xdict, pdict, unitdict, condition)
+            fs["ineqcon_time"] = con_a.inequality_jac_time(xdict, pdict, unitdict, condition)
+            fs["ineqcon_user"] = con_user.inequality_jac_user(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_mass"] = con_dynamics.equality_jac_dynamics_mass(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_pos"] = con_dynamics.equality_jac_dynamics_position(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_vel"] = con_dynamics.equality_jac_dynamics_velocity(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_quat"] = con_dynamics.equality_jac_dynamics_quaternion(xdict, pdict, unitdict, condition)
-        fail = con_dynamics.last_status(pdict)
         if aero:  # Trajectory_Optimization.py:286-295
             fs["ineqcon_alpha"] = con_aero.inequality_jac_max_alpha(xdict, pdict, unitdict, condition)
             fs["ineqcon_q"] = con_aero.inequality_jac_max_q(xdict, pdict, unitdict, condition)
             fs["ineqcon_qalpha"] = con_aero.inequality_jac_max_qalpha(xdict, pdict, unitdict, condition)
-            fail |= con_dynamics.last_status(pdict)
-        return fs, bool(fail)
+        return fs, bool(con_dynamics.last_status(pdict))
 
     return objfunc, sens
 

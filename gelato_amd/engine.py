@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import GelDims, GelProblemDesc, check, lib
+from ._lib import GelDims, GelLinearRow, GelNodefnRow, GelProblemDesc, check, lib
 
 GROUPS = ["mass", "pos", "vel", "quat"]
 # funcs / funcsSens keys of the reference callbacks (Trajectory_Optimization.py:199-210,250-261)
@@ -104,6 +104,7 @@ class Engine:
         self._vals = None      # persistent full COO values (constants pre-filled)
         self._var_idx = None
         self._src = None
+        self._nlin = self._nfn = 0
 
     # ------------------------------------------------------------------
     def close(self):
@@ -304,6 +305,48 @@ class Engine:
         rc = check(lib().gel_eval_aero(self._h, self.AERO_KINDS.index(kind), B, _d(X), _d(con),
                                        _d(jv) if want_jac else None))
         return con, jv, rc
+
+    def initial_guess(self, t_ref, table, knot_times):
+        """initialize.py:322-409 behind the C-ABI: reference trajectory (t_ref [n], table [n, 13] = mass | pos 3 | vel 3 |
+        quat 4 | body rates y, z) interpolated at the mesh's node times -> packed decision vector"""
+        t_ref, table, knot_times = _f64(t_ref), _f64(table), _f64(knot_times)
+        assert table.shape == (t_ref.size, 13) and knot_times.size == self.S + 1
+        x = np.empty(self.nvars)
+        check(lib().gel_initial_guess(self._h, t_ref.size, _d(t_ref), _d(table), _d(knot_times), _d(x)))
+        return x
+
+    # ---- knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py) ----
+    NODE_FUNCTIONS = {"orbit_energy": 0, "angular_momentum": 1, "inclination_rad": 2, "semi_major_axis": 3,
+                      "eccentricity": 4, "periapsis_radius": 5, "apoapsis_radius": 6, "radius": 7, "speed": 8}
+
+    def var_offset(self, key):
+        """first index of xdict[key] inside the packed decision vector"""
+        M, N = self.M, self.N
+        return {"mass": 0, "position": M, "velocity": 4 * M, "quaternion": 7 * M, "u": 11 * M, "t": 11 * M + 2 * N}[key]
+
+    def rows_configure(self, linear, nodefn):
+        """linear: rows (idx0, coef0, idx1 | -1, coef1, c0) -> (coef0 x[idx0] + coef1 x[idx1]) + c0;
+        nodefn: rows (fn, node, p0, p1) -> f(r, v at state node) / p0 - p1 with its six-column forward difference."""
+        lin = (GelLinearRow * max(1, len(linear)))()
+        for k, (i0, c0_, i1, c1_, cc) in enumerate(linear):
+            lin[k] = GelLinearRow(int(i0), int(i1), float(c0_), float(c1_), float(cc))
+        fn = (GelNodefnRow * max(1, len(nodefn)))()
+        for k, (f, node, p0, p1) in enumerate(nodefn):
+            fn[k] = GelNodefnRow(int(self.NODE_FUNCTIONS.get(f, f)), int(node), float(p0), float(p1))
+        check(lib().gel_rows_configure(self._h, len(linear), lin, len(nodefn), fn))
+        self._nlin, self._nfn = len(linear), len(nodefn)
+
+    def rows_eval(self, X, want_jac=True):
+        """X [B, nvars] (or [nvars]) -> (con [B, nlin + nfn], jfn [B, nfn, 6] | None, status)"""
+        X = _f64(X).reshape(-1, self.nvars)
+        B = X.shape[0]
+        con = np.empty((B, self._nlin + self._nfn))
+        jfn = np.empty((B, self._nfn, 6)) if want_jac else None
+        rc = check(lib().gel_rows_eval(self._h, B, _d(X), _d(con), _d(jfn) if want_jac else None))
+        return con, jfn, rc
+
+    def rows_eval_device(self, B, d_x, d_con, d_jfn, stream=0):
+        check(lib().gel_rows_eval_device(self._h, B, d_x, d_con, d_jfn or None, stream or None))
 
     # ------------------------------------------------------------------
     def split_x(self, x):

@@ -43,6 +43,6 @@ def jac_fd(con, xdict, pdict, unitdict, condition):
         return _jac_fd_user_callable(con, xdict, pdict, unitdict, condition)
     eng = con_dynamics.engine_of(pdict, unitdict)
     J, rc = eng.jac_fd(group, pack_x(xdict))
-    pdict[con_dynamics._KEY].status = rc
+    con_dynamics.note_status(pdict, rc)
     cols = eng.split_x(range(eng.nvars))
     return {k: J[:, cols[k].start:cols[k].stop] for k in XKEYS if k in xdict}

@@ -51,6 +51,15 @@ def build_pdict(vehicle, rows, knots, nodes, ps_params=None):
     ca_table = np.asarray(vehicle["ca_mach_ca"], dtype=np.float64)
     events = {e["name"]: e for e in vehicle["events"]}
     stages = vehicle["stages"]
+    # mass dropped at an event: a stage's dry mass at its separation, a dropMass item at its own event
+    # (Trajectory_Optimization.py:84-97)
+    jettison = {}
+    for stage in stages.values():
+        if stage.get("separation_at") in events:
+            jettison[stage["separation_at"]] = stage["mass_dry"]
+        for item in (stage.get("dropMass") or {}).values():
+            if item["separation_at"] in events:
+                jettison[item["separation_at"]] = item["mass"]
     params = []
     for i, name in enumerate(rows):
         ev = events[name]
@@ -63,6 +72,7 @@ def build_pdict(vehicle, rows, knots, nodes, ps_params=None):
             "reference_area": float(st["reference_area"]),
             # Trajectory_Optimization.py:109-112
             "massflow": float(ev["thrust"]) / st["Isp_vac"] / 9.80665 if ev["engineOn"] else 0.0,
+            "time_ref": ev.get("time_ref"), "mass_jettison": float(jettison.get(name, 0.0)),
         })
     S = len(rows) - 1
     nodes = [int(n) for n in nodes]
@@ -73,48 +83,45 @@ def build_pdict(vehicle, rows, knots, nodes, ps_params=None):
         "ps_params": ps_params if ps_params is not None else PSparams(nodes),
         "wind_table": wind_table, "ca_table": ca_table,
         "N": N, "M": N + S, "num_sections": S, "dx": 1.0e-8,
+        # what the knot / time / user constraints read (Trajectory_Optimization.py:116-124)
+        "event_index": {p["name"]: i for i, p in enumerate(params)},
+        "RocketStage": {k: st for k, st in stages.items()},
     }
     m_init = sum(s["mass_dry"] + s["mass_propellant"] for s in stages.values())
     if vehicle["OptimizationMode"] != "Payload":
         m_init += vehicle["mass_payload"]
     unitdict = {"mass": m_init, "position": 6378137, "velocity": 1000.0, "u": 1.0, "t": params[-1]["time"]}
+    # Trajectory_Optimization.py:167-176: terminal targets + the initial state (the launch site in ECI at t = 0, the
+    # velocity of the ground there and the launcher's attitude: plain numbers in the vehicle file)
     condition = {"OptimizationMode": vehicle["OptimizationMode"]}
+    condition.update(vehicle.get("TerminalCondition", {}))
+    if "init" in vehicle:
+        condition["init"] = {"mass": m_init, "position": np.array(vehicle["init"]["position"]),
+                             "velocity": np.array(vehicle["init"]["velocity"]),
+                             "quaternion": np.array(vehicle["init"]["quaternion"]), "u": np.zeros(2)}
+        condition["flight_azimuth_init"] = vehicle["LaunchCondition"]["flight_azimuth_init"]
     return pdict, unitdict, condition
 
 
-def _interp_cols(t, tab, cols, tq):
-    # linear interpolation with linear extrapolation, like scipy interp1d(fill_value="extrapolate")
-    out = np.empty((len(tq), len(cols)))
-    idx = np.clip(np.searchsorted(t, tq, side="right") - 1, 0, len(t) - 2)
-    w = (tq - t[idx]) / (t[idx + 1] - t[idx])
-    for k, c in enumerate(cols):
-        y = tab[:, c]
-        out[:, k] = y[idx] + w * (y[idx + 1] - y[idx])
-    return out
+_TRAJ_COLS = (["mass"] + ["pos_ECI_" + a for a in "XYZ"] + ["vel_ECI_" + a for a in "XYZ"] +
+              ["quat_ECI2BODY_%d" % k for k in range(4)] + ["rate_BODY_Y", "rate_BODY_Z"])
 
 
 def initial_xdict(vehicle, pdict, unitdict):
-    """initialize.py:322-409 (LGR mode): interpolate the reference trajectory at the node times."""
+    """initialize.py:322-409 (LGR mode): the reference trajectory interpolated at the node times, by the engine's host
+    entry point gel_initial_guess (a host-only handle is enough: no GPU is touched)."""
+    from .con_dynamics import problem_arrays
+    from .engine import Engine
     tab = np.asarray(vehicle["trajectory"], dtype=np.float64)
     col = {c: i for i, c in enumerate(vehicle["trajectory_columns"])}
-    t = tab[:, col["time"]]
     ps = pdict["ps_params"]
-    tn, txn = [], []
-    for i in range(pdict["num_sections"]):
-        to, tf = pdict["params"][i]["time"], pdict["params"][i]["timeFinishAt"]
-        tau = ps.tau(i)
-        tn.append(tau * (tf - to) / 2.0 + (tf + to) / 2.0)
-        txn.append(np.hstack((-1.0, tau)) * (tf - to) / 2.0 + (tf + to) / 2.0)
-    tn, txn = np.concatenate(tn), np.concatenate(txn)
-    x = {
-        "mass": _interp_cols(t, tab, [col["mass"]], txn).ravel() / unitdict["mass"],
-        "position": _interp_cols(t, tab, [col["pos_ECI_" + a] for a in "XYZ"], txn).ravel() / unitdict["position"],
-        "velocity": _interp_cols(t, tab, [col["vel_ECI_" + a] for a in "XYZ"], txn).ravel() / unitdict["velocity"],
-        "quaternion": _interp_cols(t, tab, [col["quat_ECI2BODY_%d" % k] for k in range(4)], txn).ravel(),
-        "u": _interp_cols(t, tab, [col["rate_BODY_Y"], col["rate_BODY_Z"]], tn).ravel() / unitdict["u"],
-        "t": np.array([p["time"] for p in pdict["params"]]) / unitdict["t"],
-    }
-    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in x.items()}
+    S = pdict["num_sections"]
+    E = Engine(problem_arrays(pdict, unitdict), D=[ps.D(i) for i in range(S)], tau=[ps.tau(i) for i in range(S)], device=-1)
+    knots = [p["time"] for p in pdict["params"]]
+    x = E.initial_guess(tab[:, col["time"]], tab[:, [col[c] for c in _TRAJ_COLS]], knots)
+    out = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in E.split_x(x).items()}
+    E.close()
+    return out
 
 
 def synthetic_batch(x0, M, B, seed=20260313):

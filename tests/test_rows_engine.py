@@ -1,0 +1,172 @@
+"""GPU parity tests of SURVEY.md 8f rows f-4 / f-2: the init / time / knot / terminal / time-ordering rows and the
+device-form user constraint, through the C-ABI (gel_rows_*) and the reference-named Python functions, against the
+golden fixtures of the imported reference (tests/golden/g11_knot_terminal.npz) and the numpy oracle.
+
+Tolerances: linear rows bit-exact (differences of single variables plus a constant); node functions 1e-12 relative
+(ocml vs libm); their forward-difference entries |d| <= 1e-5 + 1e-6 |ref| like every FD Jacobian entry of the path."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+CONDS = {"Payload": {}, "Other_incl": {"OptimizationMode": "Other", "inclination": 42.3},
+         "radius": {"altitude_perigee": None, "altitude_apogee": None}}
+
+
+def example(extra=None):
+    from gelato_amd import problem
+    pdict, unitdict, condition, xdict = problem.make_problem("example")
+    return pdict, unitdict, dict(condition, **(extra or {})), xdict
+
+
+def xdict_of(E, x):
+    return {k: np.ascontiguousarray(v) for k, v in E.split_x(x).items()}
+
+
+@pytest.mark.parametrize("cname", list(CONDS))
+def test_row_groups_vs_reference_golden_and_oracle(cname):
+    from gelato_amd import con_dynamics
+    from gelato_amd import con_init_terminal_knot as ck
+    from oracle import knot_terminal as kt
+    g = load_golden("g11_knot_terminal.npz")
+    pdict, unitdict, condition, _ = example(CONDS[cname])
+    E = con_dynamics.engine_of(pdict, unitdict)
+    sp = kt.make_spec(pdict, unitdict, condition)
+    fns = {"init": (ck.equality_init, ck.equality_jac_init), "time": (ck.equality_time, ck.equality_jac_time),
+           "knot": (ck.equality_knot_LGR, ck.equality_jac_knot_LGR),
+           "terminal": (ck.equality_6DoF_LGR_terminal, ck.equality_jac_6DoF_LGR_terminal),
+           "tineq": (ck.inequality_time, ck.inequality_jac_time)}
+    for xname in ("init", "moved"):
+        xd = xdict_of(E, g["x_" + xname])
+        before = {k: v.copy() for k, v in xd.items()}
+        for tag, (f, jf) in fns.items():
+            base = "%s_%s_%s" % (xname, cname, tag)
+            con, ref = f(xd, pdict, unitdict, condition), g[base + "_con"]
+            J = jf(xd, pdict, unitdict, condition)
+            if tag != "terminal":
+                assert np.array_equal(con, ref), base
+            else:
+                assert np.all(np.abs(con - ref) <= 1e-13 + 1e-12 * np.abs(ref)), base
+                assert np.all(np.abs(con - kt.equality_terminal(g["x_" + xname], sp)) <= 1e-13 + 1e-12 * np.abs(ref))
+            for var, blk in J.items():
+                k = base + "_jac_" + var
+                assert np.array_equal(blk["coo"][0], g[k + "_rows"]) and np.array_equal(blk["coo"][1], g[k + "_cols"]), k
+                assert blk["shape"] == tuple(g[k + "_shape"]) and blk["coo"][2].dtype == np.float64
+                if tag != "terminal":
+                    assert np.array_equal(blk["coo"][2], g[k + "_vals"]), k
+                else:
+                    d = np.abs(blk["coo"][2] - g[k + "_vals"])
+                    assert np.all(d <= 1e-5 + 1e-6 * np.abs(g[k + "_vals"])), (k, d.max())
+        assert all(np.array_equal(xd[k], before[k]) for k in xd)           # xdict is never modified
+        assert con_dynamics.last_status(pdict) == 0
+
+
+def test_device_form_user_constraint_vs_reference_jac_fd_golden():
+    from gelato_amd import con_dynamics, con_user
+    from gelato_amd.examples import user_constraints as uc
+    g = load_golden("g11_knot_terminal.npz")
+    pdict, unitdict, condition, _ = example()
+    E = con_dynamics.engine_of(pdict, unitdict)
+    con_user.set_user_module(uc)
+    try:
+        for xname in ("init", "moved"):
+            xd = xdict_of(E, g["x_" + xname])
+            val = con_user.equality_user(xd, pdict, unitdict, condition)
+            assert np.ndim(val) == 0 and abs(val - g[xname + "_user_con"][0]) <= 1e-13      # a scalar, like the reference's
+            assert con_user.inequality_user(xd, pdict, unitdict, condition) is None
+            assert con_user.inequality_jac_user(xd, pdict, unitdict, condition) is None
+            J = con_user.equality_jac_user(xd, pdict, unitdict, condition)
+            assert sorted(J) == sorted(xd) and all(J[k].shape == (1, xd[k].size) for k in xd)   # dense, every key
+            for key in xd:
+                nz = np.nonzero(J[key][0])[0]
+                assert np.array_equal(nz, g["%s_user_jac_%s_nzcols" % (xname, key)]), key
+                ref = g["%s_user_jac_%s_nzvals" % (xname, key)]
+                assert np.all(np.abs(J[key][0, nz] - ref) <= 1e-5 + 1e-6 * np.abs(ref)), key
+        # a callable-form module keeps working (the reference's loop, column by column, on the user's Python)
+        class Callable:
+            @staticmethod
+            def equality_user(xdict, pdict, unitdict, condition):
+                return np.array([xdict["mass"][3] * 2.0 - xdict["t"][1]])
+
+            @staticmethod
+            def inequality_user(xdict, pdict, unitdict, condition):
+                return None
+        con_user.set_user_module(Callable)
+        xd = xdict_of(E, g["x_init"])
+        J = con_user.equality_jac_user(xd, pdict, unitdict, condition)
+        assert abs(J["mass"][0, 3] - 2.0) < 1e-6 and abs(J["t"][0, 1] + 1.0) < 1e-6 and np.count_nonzero(J["position"]) == 0
+    finally:
+        con_user.set_user_module(None)
+
+
+def test_rows_batch_device_api_and_nonfinite_status():
+    import torch
+    from gelato_amd import con_dynamics
+    from gelato_amd import con_init_terminal_knot as ck
+    from gelato_amd import problem
+    pdict, unitdict, condition, xdict = example({"inclination": 40.0})
+    pdict["gelato_amd_user_rows"] = (("periapsis_radius", "IIP_END", 6378137.0, 1.0), ("speed", "SEIG", 1000.0, 0.0))
+    E = con_dynamics.engine_of(pdict, unitdict)
+    R = ck.rows_of(pdict, unitdict, condition)
+    from gelato_amd import pack_x
+    x0 = pack_x(xdict)
+    B = 37
+    X = problem.synthetic_batch(x0, E.M, B, seed=5)
+    con, jfn, rc = E.rows_eval(X)
+    assert rc == 0 and con.shape == (B, R.nlin + R.nfn) and jfn.shape == (B, R.nfn, 6)
+    for b in (0, 11, B - 1):                                 # element b of a batch == the single-vector call, bit for bit
+        c1, j1, _ = E.rows_eval(X[b])
+        assert np.array_equal(c1[0], con[b]) and np.array_equal(j1[0], jfn[b])
+    dev = torch.device("cuda:0")
+    dX = torch.from_numpy(X).to(dev)
+    dcon = torch.empty((B, R.nlin + R.nfn), dtype=torch.float64, device=dev)
+    djfn = torch.empty((B, R.nfn, 6), dtype=torch.float64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    E.rows_eval_device(B, dX.data_ptr(), dcon.data_ptr(), djfn.data_ptr(), s)
+    assert E.sync(s) == 0
+    assert np.array_equal(dcon.cpu().numpy(), con) and np.array_equal(djfn.cpu().numpy(), jfn)
+    # large host batch: the copy path instead of the zero-copy path, same bits
+    Xl = np.tile(X, (8, 1))
+    cl, jl, rc = E.rows_eval(Xl)
+    assert rc == 0 and np.array_equal(cl[:B], con) and np.array_equal(jl[B:2 * B], jfn)
+    # the speed row: |v| / 1000 of SEIG's first node; its position columns are exact zeros
+    node = pdict["ps_params"].index_start_x(pdict["event_index"]["SEIG"])
+    v = X[0, 4 * E.M + 3 * node:4 * E.M + 3 * node + 3] * unitdict["velocity"]
+    assert abs(con[0, -1] - np.linalg.norm(v) / 1000.0) <= 1e-12 and np.all(jfn[0, -1, 0:3] == 0.0)
+    # non-finite input -> status 1, reported through the sticky status of the callbacks
+    xb = x0.copy()
+    xb[E.M + 3 * (E.M - 1)] = np.nan
+    _, _, rc = E.rows_eval(xb)
+    assert rc == 1
+    _, _, rc = E.rows_eval(x0)
+    assert rc == 0
+
+
+def test_callbacks_carry_every_row_group_and_a_sticky_status():
+    from gelato_amd import con_dynamics, con_user, driver
+    from gelato_amd.examples import user_constraints as uc
+    pdict, unitdict, condition, xdict = example()
+    con_user.set_user_module(uc)
+    try:
+        objfunc, sens = driver.make_callbacks(pdict, unitdict, condition)
+        funcs, fail = objfunc(xdict)
+        fs, fail2 = sens(xdict, funcs)
+        assert not fail and not fail2
+        for key in ("eqcon_init", "eqcon_time", "eqcon_knot", "eqcon_terminal", "eqcon_user", "ineqcon_time",
+                    "eqcon_dyn_mass", "eqcon_dyn_pos", "eqcon_dyn_vel", "eqcon_dyn_quat"):
+            assert funcs[key] is not None and fs[key] is not None, key
+        assert funcs["ineqcon_user"] is None and fs["ineqcon_user"] is None
+        assert funcs["eqcon_knot"].shape == (121,) and funcs["eqcon_terminal"].shape == (2,)
+        # a NaN that only the terminal rows see (velocity of the very last node feeds no defect row's RHS ... but does
+        # feed D.X of the last phase): whatever group sees it first, the callback reports it once, at the end
+        bad = {k: v.copy() for k, v in xdict.items()}
+        bad["velocity"][-1] = np.nan
+        _, fail = objfunc(bad)
+        assert fail
+        _, fail = objfunc(xdict)                                  # and the flag does not stick to the next x
+        assert not fail
+        assert con_dynamics.last_status(pdict) == 0
+    finally:
+        con_user.set_user_module(None)
