@@ -128,8 +128,8 @@ def main():
     ap.add_argument("--workload", default="mixed-6x64", help="mixed-6x64 | dense-6x64 | 3x32 | stress-12x128 | example")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "phase-shard"],
                     help="replicas: B vectors per GPU, no collective (weak scaling, the headline). phase-shard: ONE "
-                         "batch of B vectors evaluated by all GPUs together, work items dealt to ranks, one RCCL "
-                         "sum all-reduce per step (strong scaling; BASELINE.json config 4)")
+                         "batch of B vectors evaluated by all GPUs together, units (work item, FD column part) dealt to "
+                         "ranks, one RCCL all-gather of the owned entries per step (strong scaling; BASELINE.json config 4)")
     ap.add_argument("--residual-only", action="store_true", dest="residual_only",
                     help="RHS + defect residuals only, no Jacobian (BASELINE.json configs[1]: 3x32 residual only vs CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,17 +177,16 @@ def main():
     if shard:
         from gelato_amd import parallel
         # units = (work item, part): the position-sweep columns of the FD Jacobian are dealt to ranks too, so
-        # that 8 GPUs have something to do on a 6-phase mesh (BASELINE.json configs[3])
-        ranges = parallel.shard_chunks(parallel.unit_costs(E), world)
-        c0, cn = ranges[rank]
+        # that 8 GPUs have something to do on a 6-phase mesh (BASELINE.json configs[3]).  Every output entry has one
+        # owning unit; a rank evaluates its units, packs what it owns, and ONE all-gather completes res / jvar on
+        # every rank (no fills, (N-1)/N of the outputs received per rank).
+        shards = parallel.UnitShards(E, world, rank)
+
+        def evaluate(u0, cnt, res_t, jv_t):
+            E.eval_shard_units_device(B, dX.data_ptr(), res_t.data_ptr(), jv_t.data_ptr(), u0, cnt, stream)
 
         def step():
-            # every entry of res / jvar has exactly one owning rank: zero, fill own work items, sum all-reduce
-            dres.zero_()
-            djv.zero_()
-            E.eval_shard_units_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), c0, cn, stream)
-            dist.all_reduce(dres, op=dist.ReduceOp.SUM)
-            dist.all_reduce(djv, op=dist.ReduceOp.SUM)
+            shards.step(evaluate, dres, djv)
     else:
         def step():
             E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv_ptr, stream)
@@ -289,6 +288,8 @@ def main():
                            "note": "fp64-VALU-bound, not HBM-bound (libm chains of the RHS sweeps); see DESIGN.md 3.1"}
     else:
         out["shard"] = {"step_ms": kern_ms, "step_ms_cold": kern_ms_cold,
+                        "units_per_rank": [c for _, c in shards.ranges],
+                        "all_gather_bytes_received_per_rank_per_step": shards.bytes_received_per_vector() * B,
                         "note": "one step = this rank's unit range (split-form kernel) + one all-gather of the owned "
                                 "slices; no roofline block: the step is exchange-latency bound, not a kernel figure"}
 

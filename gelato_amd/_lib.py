@@ -79,6 +79,7 @@ SIGNATURES = {
                                          C.c_int32, C.c_void_p]),
     "gel_eval_shard_units_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_void_p]),
+    "gel_unit_owner": (C.c_int, [C.c_void_p, _ip, _ip]),
     "gel_num_chunks": (C.c_int, [C.c_void_p, _ip]),
     "gel_chunk_phase": (C.c_int, [C.c_void_p, _ip]),
     "gel_launch_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _ip]),

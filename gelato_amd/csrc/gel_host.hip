@@ -930,6 +930,33 @@ int gel_launch_info(const gel_problem* p, int32_t B, int32_t want_res, int32_t w
   return GEL_OK;
 }
 
+int gel_unit_owner(const gel_problem* p, int32_t* res_owner, int32_t* jvar_owner) {
+  if (!p || !res_owner || !jvar_owner) return fail(GEL_ERR_ARG, "null argument");
+  // unit = 4 * work item + part (phase-ordered work items): part 0 writes the residual rows of the item's nodes and
+  // every compact value of those nodes except the position-sweep columns of an aerodynamic phase, which parts 1..3
+  // write (one column = three slots each); the phase scalar belongs to part 0 of the phase's first work item
+  const int N = p->dims.N;
+  int item = 0;
+  for (size_t i = 0; i < p->ph.size(); i++) {
+    const HostPhase& h = p->ph[i];
+    for (int j0 = 0; j0 < h.n; j0 += 64, item++) {
+      const int j1 = std::min(j0 + 64, h.n);
+      for (int j = j0; j < j1; j++) {
+        const int g = h.ua + j;
+        res_owner[g] = 4 * item;
+        for (int c = 0; c < 3; c++) { res_owner[N + 3 * g + c] = 4 * item; res_owner[4 * N + 3 * g + c] = 4 * item; }
+        for (int c = 0; c < 4; c++) res_owner[7 * N + 4 * g + c] = 4 * item;
+        for (int s = 0; s < h.K; s++) {
+          const int part = (h.air && s >= 6 && s < 15) ? 1 + (s - 6) / 3 : 0;
+          jvar_owner[h.voff + (int64_t)s * h.n + j] = 4 * item + part;
+        }
+      }
+      if (j0 == 0) jvar_owner[h.voff + (int64_t)h.K * h.n] = 4 * item;
+    }
+  }
+  return GEL_OK;
+}
+
 int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream) {
   if (!p || !d_jvar || !d_jfull || B < 1) return fail(GEL_ERR_ARG, "bad argument");
   NEED_DEVICE(p);

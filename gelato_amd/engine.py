@@ -249,6 +249,13 @@ class Engine:
         check(lib().gel_chunk_phase(self._h, out.ctypes.data_as(_ip)))
         return out
 
+    def unit_owner(self):
+        """(res_owner [11N], jvar_owner [V]): the unit (4 * work item + part) that writes each output entry"""
+        ro = np.zeros(self.nres, dtype=np.int32)
+        jo = np.zeros(self.V, dtype=np.int32)
+        check(lib().gel_unit_owner(self._h, ro.ctypes.data_as(_ip), jo.ctypes.data_as(_ip)))
+        return ro, jo
+
     def eval_shard_device(self, B, d_x, d_res, d_jvar, chunk_begin, chunk_count, stream=0):
         check(lib().gel_eval_shard_device(self._h, B, d_x, d_res or None, d_jvar or None, int(chunk_begin),
                                           int(chunk_count), stream or None))

@@ -575,6 +575,42 @@ def test_unit_shards_compose_to_the_full_evaluation(name, B):
 # --------------------------------------------------------------------------
 # D.X on the matrix pipe (v_mfma_f64_16x16x4_f64) vs wavefront dot-products (VALU)
 # --------------------------------------------------------------------------
+@pytest.mark.parametrize("name,world", [("mixed-6x64", 8), ("mixed-6x64", 3), ("example", 2)])
+def test_unit_shard_exchange_on_one_gpu(name, world):
+    """parallel.UnitShards (what bench.py --mode phase-shard and the gloo test drive) with the ENGINE as the evaluator:
+    every rank's units are evaluated into NaN-filled buffers, the owned entries are packed, the stacked packs stand in
+    for the all-gather, and unpacking must reproduce the unsharded launch bit for bit -- on every rank."""
+    import torch
+    from gelato_amd import Engine, parallel, problem
+    prob, x0, _ = named_problem(name)
+    E = Engine(prob)
+    B = 5
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    dX = torch.from_numpy(problem.synthetic_batch(x0, E.M, B, seed=3)).to(dev)
+    ref_r = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    ref_j = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    E.eval_batch_device(B, dX.data_ptr(), ref_r.data_ptr(), ref_j.data_ptr(), s)
+    assert E.sync(s) == 0
+    shards = [parallel.UnitShards(E, world, r) for r in range(world)]
+    bufs, packs = [], []
+    for r, sh in enumerate(shards):
+        res = torch.full((B, E.nres), float("nan"), dtype=torch.float64, device=dev)
+        jv = torch.full((B, E.V), float("nan"), dtype=torch.float64, device=dev)
+        u0, cnt = sh.ranges[r]
+        if cnt:
+            E.eval_shard_units_device(B, dX.data_ptr(), res.data_ptr(), jv.data_ptr(), u0, cnt, s)
+        send, _ = sh._buffers(B, res)
+        packs.append(sh.pack(res, jv, send).clone())
+        bufs.append((res, jv))
+    assert E.sync(s) == 0
+    recv = torch.stack(packs)                                  # what all_gather_into_tensor delivers
+    for r, sh in enumerate(shards):
+        res, jv = sh.unpack(recv, *bufs[r], skip=r)
+        assert torch.equal(res, ref_r) and torch.equal(jv, ref_j), r
+    assert shards[0].bytes_received_per_vector() <= 8 * (E.nres + E.V) * (world - 1) / world * 1.6
+
+
 @pytest.mark.parametrize("name", ["example", "mixed-6x64", "stress-12x128"])
 def test_dx_mfma_and_valu_paths_agree(name):
     oracle = _setup()

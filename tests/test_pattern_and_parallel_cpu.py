@@ -153,34 +153,36 @@ P = oracle.Problem(prob)
 E = Engine(prob, D=[P.D(i) for i in range(P.S)], tau=[P.tau(i) for i in range(P.S)], device=-1)
 x = g["x"]
 
-# ---- phase-shard mode: each rank "evaluates" only its work items (oracle as the stand-in evaluator) ----
-ranges = parallel.shard_chunks(parallel.chunk_costs(E), world)
-full_res = np.concatenate([P.residual(grp, x) for grp in oracle.GROUPS])
-vals = np.concatenate([np.concatenate([b["coo"][2] for b in P.jacobian(grp, x).values()]) for grp in oracle.GROUPS])
-full_jv = vals[E.var_index()]
-ph_of_chunk = E.chunk_phase()
-nn = prob["num_nodes"]; ua = np.concatenate([[0], np.cumsum(nn)[:-1]])
-# recover the phase owning each compact slot from the COO row (= collocation node) of its entry
-pat = E.pattern()
-rows_all = np.concatenate([r // k for (r, c), k in zip(pat, [1,1,3,3,3,3,3,3,3,3,4,4,4])])
-node_of_slot = rows_all[E.var_index()]
-phase_of_node = np.repeat(np.arange(len(nn)), nn)
+# ---- phase-shard mode: the SAME object bench.py --mode phase-shard drives (parallel.UnitShards), on the unit partition
+#      of a host-only handle.  The oracle is only the source of the values a rank "computes": the stand-in evaluator
+#      writes exactly the entries its units own (gel_unit_owner) into buffers that are otherwise NaN, so nothing can
+#      lean on a zero fill, and one all-gather must complete them. ----
+B = 3
+X = np.tile(x, (B, 1)) * (1 + 1e-7 * np.arange(B))[:, None]
+ores, ovals = P.eval_batch(X)
+full_jv = ovals[:, E.var_index()]
+ro, jo = E.unit_owner()
+assert ro.min() == 0 and jo.max() < 4 * E.num_chunks()
+sh = parallel.UnitShards(E, world, rank)
+assert len(sh.ranges) == world and sum(c for _, c in sh.ranges) == 4 * E.num_chunks()
+calls = []
 
-def evaluate_range(begin, count, res, jvar):
-    mine = set(ph_of_chunk[begin:begin + count].tolist())
-    N = E.N
-    for grp, k, o in [("mass", 1, 0), ("pos", 3, N), ("vel", 3, 4 * N), ("quat", 4, 7 * N)]:
-        for i in mine:
-            lo, hi = o + k * ua[i], o + k * (ua[i] + nn[i])
-            res[lo:hi] = torch.from_numpy(full_res[lo:hi])
-    sel = np.isin(phase_of_node[node_of_slot], list(mine))
-    jvar[torch.from_numpy(sel)] = torch.from_numpy(full_jv[sel])
+def evaluate_units(u0, cnt, res, jvar):
+    calls.append((u0, cnt))
+    mr = torch.from_numpy((ro >= u0) & (ro < u0 + cnt))
+    mj = torch.from_numpy((jo >= u0) & (jo < u0 + cnt))
+    res[:, mr] = torch.from_numpy(ores)[:, mr]
+    jvar[:, mj] = torch.from_numpy(full_jv)[:, mj]
 
-res = torch.full((E.nres,), 7.0, dtype=torch.float64)
-jv = torch.full((E.V,), 7.0, dtype=torch.float64)
-parallel.phase_sharded_eval(evaluate_range, res, jv, ranges, rank)
-assert np.array_equal(res.numpy(), full_res), "residual after all-reduce"
-assert np.array_equal(jv.numpy(), full_jv), "jacobian after all-reduce"
+res = torch.full((B, E.nres), float("nan"), dtype=torch.float64)
+jv = torch.full((B, E.V), float("nan"), dtype=torch.float64)
+for _ in range(2):                       # twice: the exchange buffers are reused
+    sh.step(evaluate_units, res, jv)
+assert calls == [sh.ranges[rank]] * 2
+assert np.array_equal(res.numpy(), ores), "residual after the all-gather"
+assert np.array_equal(jv.numpy(), full_jv), "jacobian after the all-gather"
+# one collective per step, delivering (world-1)/world of the outputs up to padding to the largest share
+assert sh.bytes_received_per_vector() <= 8 * (E.nres + E.V) * (world - 1) / world * 1.6
 
 # ---- replica mode: vectors split across ranks, slowest rank defines the time ----
 B = 5
