@@ -45,13 +45,34 @@ def _configured(pdict, unitdict, condition, kind):
     return st, len(spec)
 
 
+def _configure_all(pdict, unitdict, condition):
+    """every kind configured for this condition dict -> (state, {kind: number of specs})"""
+    st = None
+    n = {}
+    for kind in _KINDS:
+        st, n[kind] = _configured(pdict, unitdict, condition, kind)
+    return st, n
+
+
+def _evaluate(xdict, pdict, unitdict, condition, want_jac):
+    """The first of the three functions called for a new xdict evaluates ALL configured kinds in one launch (a state
+    node constrained by several kinds runs the air-velocity chain once); the others return their share of it."""
+    st, nspec = _configure_all(pdict, unitdict, condition)
+    x = pack_x(xdict)
+    slot = "aero_jac_cache" if want_jac else "aero_con_cache"
+    cache = st.__dict__.get(slot)
+    key = tuple(sorted(st.__dict__.get("aero_spec", {}).items()))
+    if cache is None or cache[0] != key or not np.array_equal(cache[1], x):
+        con, jac, rc = st.engine.eval_aero_all(x, want_jac=want_jac, reuse=True)   # copies are handed out below
+        cache = (key, x, con, jac, rc)
+        st.__dict__[slot] = cache
+    st.status |= cache[4]                       # also when the cached result is handed out again
+    return st, nspec, cache[2], cache[3]
+
+
 def _values(xdict, pdict, unitdict, condition, kind):
-    st, nspec = _configured(pdict, unitdict, condition, kind)
-    if nspec == 0:
-        return None
-    con, _, rc = st.engine.eval_aero(kind, pack_x(xdict), want_jac=False)
-    st.status |= rc
-    return con[0]
+    st, nspec, con, _ = _evaluate(xdict, pdict, unitdict, condition, False)
+    return con[kind][0].copy() if nspec[kind] else None
 
 
 def _length(pdict, unitdict, condition, kind):
@@ -60,22 +81,20 @@ def _length(pdict, unitdict, condition, kind):
 
 
 def _jacobian(xdict, pdict, unitdict, condition, kind):
-    st, nspec = _configured(pdict, unitdict, condition, kind)
-    if nspec == 0:
+    st, nspec, _, jv = _evaluate(xdict, pdict, unitdict, condition, True)
+    if nspec[kind] == 0:
         return None
     eng = st.engine
     pats = st.__dict__.setdefault("aero_pattern", {})
     if kind not in pats:
         pats[kind] = eng.aero_pattern(kind)
     nrow, nnz = eng.aero_dims(kind)
-    _, jv, rc = eng.eval_aero(kind, pack_x(xdict), want_jac=True)
-    st.status |= rc
     shapes = [(nrow, pdict["M"] * 3), (nrow, pdict["M"] * 3), (nrow, pdict["M"] * 4),
               (nrow, pdict["num_sections"] + 1)]
     jac, off = {}, 0
     for v, var in enumerate(eng.AERO_VARS):
         r, c = pats[kind][v]
-        jac[var] = {"coo": [r, c, jv[0, off:off + nnz[v]].copy()], "shape": shapes[v]}
+        jac[var] = {"coo": [r, c, jv[kind][0, off:off + nnz[v]].copy()], "shape": shapes[v]}
         off += nnz[v]
     return jac
 

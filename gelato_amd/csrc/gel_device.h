@@ -48,6 +48,13 @@ struct AeroRowDev {
   int32_t phase, k, nk, row0;  // phase, node 0..nk-1 inside it, rows of its spec, first row of its spec
   double limit;                // units[3] of con_aero.py
 };
+// one constrained state node, shared by the kinds that constrain it (kind 0 alpha, 1 q, 2 q-alpha): row = its row in
+// that kind's constraint vector (-1: not constrained by that kind), nk / row0 / limit as in AeroRowDev
+struct AeroNodeDev {
+  int32_t phase, k;
+  int32_t row[3], nk[3], row0[3];
+  double limit[3];
+};
 
 // knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py): see gel_kernels.hip rows_kernel
 struct LinRowDev { int32_t idx0, idx1; double coef0, coef1, c0; };  // (coef0 x[idx0] + coef1 x[idx1]) + c0; idx1 < 0: one term

@@ -138,7 +138,10 @@ struct gel_problem {
   std::vector<int32_t> chunk_phase;  // [nchunks] phase of every 64-node work item
   // aero path constraints: kind 0 = AOA_max, 1 = dynamic_pressure_max, 2 = Q_alpha_max
   std::vector<gel::AeroRowDev> aero_rows[3];
-  gel::AeroRowDev* d_aero_rows[3] = {nullptr, nullptr, nullptr};
+  std::vector<gel::AeroNodeDev> aero_nodes;                   // the constrained state nodes, shared by the kinds
+  gel::AeroNodeDev* d_aero_nodes = nullptr;
+  double *d_aero_x = nullptr, *d_aero_out = nullptr;          // working set of large host-buffer calls
+  size_t d_aero_x_cap = 0, d_aero_out_cap = 0;                // doubles
   // device buffers (static)
   gel::PhaseDev* d_phases = nullptr;
   int32_t* d_node_phase = nullptr;
@@ -770,7 +773,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
   hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dsw); hipFree(p->d_Dst); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag);
-  for (int k = 0; k < 3; k++) hipFree(p->d_aero_rows[k]);
+  hipFree(p->d_aero_nodes); hipFree(p->d_aero_x); hipFree(p->d_aero_out);
   free_slots(p);
   hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv);
   if (p->h_x) hipHostFree(p->h_x);
@@ -1103,6 +1106,18 @@ int gel_dynamics_quaternion(int32_t n, const double* quat, const double* u_e, do
   return GEL_OK;
 }
 
+namespace {
+// grows a device or pinned buffer; on failure the buffer is gone and its capacity is 0 (never a stale pointer)
+int grow(double** buf, size_t* cap, size_t need, bool pinned) {
+  if (*cap >= need) return GEL_OK;
+  if (*buf) { if (pinned) hipHostFree(*buf); else hipFree(*buf); }
+  *buf = nullptr; *cap = 0;
+  HIPCHK(pinned ? hipHostMalloc((void**)buf, need * 8) : hipMalloc((void**)buf, need * 8));
+  *cap = need;
+  return GEL_OK;
+}
+}  // namespace
+
 // ------------------ aero path constraints (lib/con_aero.py) ------------------
 int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_t* phase, const int32_t* range_all,
                        const double* limit) {
@@ -1121,13 +1136,30 @@ int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_
     for (int k = 0; k < nk; k++) rows.push_back(gel::AeroRowDev{phase[s], k, nk, row0, limit[s]});
   }
   p->aero_rows[kind] = rows;
+  // the union of the constrained state nodes over the three kinds, in (phase, node) order
+  std::vector<gel::AeroNodeDev> nodes;
+  for (int i = 0; i + 1 < (int)p->ph.size(); i++)
+    for (int k = 0; k <= p->ph[i].n; k++) {
+      gel::AeroNodeDev nd{i, k, {-1, -1, -1}, {0, 0, 0}, {0, 0, 0}, {1.0, 1.0, 1.0}};
+      bool any = false;
+      for (int kd = 0; kd < 3; kd++) {
+        const auto& A = p->aero_rows[kd];
+        for (size_t r = 0; r < A.size(); r++)
+          if (A[r].phase == i && A[r].k == k) {
+            nd.row[kd] = (int32_t)r; nd.nk[kd] = A[r].nk; nd.row0[kd] = A[r].row0; nd.limit[kd] = A[r].limit;
+            any = true;
+          }
+      }
+      if (any) nodes.push_back(nd);
+    }
+  p->aero_nodes = nodes;
   if (p->device != GEL_DEVICE_NONE) {
     HIPCHK(hipSetDevice(p->device));
-    if (p->d_aero_rows[kind]) { hipFree(p->d_aero_rows[kind]); p->d_aero_rows[kind] = nullptr; }
-    if (!rows.empty()) {
-      HIPCHK(hipMalloc((void**)&p->d_aero_rows[kind], rows.size() * sizeof(gel::AeroRowDev)));
-      HIPCHK(hipMemcpy(p->d_aero_rows[kind], rows.data(), rows.size() * sizeof(gel::AeroRowDev), hipMemcpyHostToDevice));
-    }
+    HIPCHK(hipStreamSynchronize(p->stream));
+    hipFree(p->d_aero_nodes);
+    p->d_aero_nodes = nullptr;
+    int rc = upload(&p->d_aero_nodes, p->aero_nodes);
+    if (rc) return rc;
   }
   return GEL_OK;
 }
@@ -1159,53 +1191,88 @@ int gel_aero_pattern(const gel_problem* p, int32_t kind, int32_t var, int32_t* r
   return GEL_OK;
 }
 
+namespace {
+size_t aero_jac_len(const gel_problem* p, int kind) { return p->aero_rows[kind].size() * ((kind == 1) ? 8 : 12); }
+}  // namespace
+
+int gel_eval_aero_all_device(gel_problem* p, int32_t B, const double* d_x, double* const* d_con, double* const* d_jac,
+                             void* stream) {
+  if (!p || B < 1 || !d_x || !d_con) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  gel::AeroLaunchOut out;
+  for (int k = 0; k < 3; k++) {
+    out.nrows[k] = (int32_t)p->aero_rows[k].size();
+    out.con[k] = out.nrows[k] ? d_con[k] : nullptr;
+    out.jac[k] = (out.con[k] && d_jac) ? d_jac[k] : nullptr;
+  }
+  HIPCHK(gel::launch_aero(p->dev, (int)p->aero_nodes.size(), p->d_aero_nodes, B, d_x, out, stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
+int gel_eval_aero_all(gel_problem* p, int32_t B, const double* x, double* const* con, double* const* jac) {
+  if (!p || B < 1 || !x || !con) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  if (p->aero_nodes.empty()) return GEL_OK;
+  HIPCHK(hipSetDevice(p->device));
+  // one contiguous output area: con[0] | jac[0] | con[1] | jac[1] | con[2] | jac[2] (only what was asked for)
+  size_t off_c[3], off_j[3], total = 0;
+  for (int k = 0; k < 3; k++) {
+    const size_t R = p->aero_rows[k].size();
+    off_c[k] = total; total += (con[k] && R) ? (size_t)B * R : 0;
+    off_j[k] = total; total += (con[k] && R && jac && jac[k]) ? (size_t)B * aero_jac_len(p, k) : 0;
+  }
+  if (total == 0) return GEL_OK;
+  const size_t nx = (size_t)B * p->dims.num_vars;
+  const bool zero_copy = (nx + total) * 8 <= kZeroCopyBytes;
+  int rc;
+  double* base;
+  if (zero_copy) {
+    // the optimiser's callback: x and every output in pinned host memory, one launch + one synchronise
+    if ((rc = ensure_capacity(p, B)) || (rc = grow(&p->h_aero, &p->h_aero_cap, total, true))) return rc;
+    std::memcpy(p->h_x, x, nx * 8);
+    base = p->h_aero;
+  } else {
+    if ((rc = grow(&p->d_aero_x, &p->d_aero_x_cap, nx, false)) || (rc = grow(&p->d_aero_out, &p->d_aero_out_cap, total, false))) return rc;
+    HIPCHK(hipMemcpyAsync(p->d_aero_x, x, nx * 8, hipMemcpyHostToDevice, p->stream));
+    base = p->d_aero_out;
+  }
+  gel::AeroLaunchOut out;
+  for (int k = 0; k < 3; k++) {
+    const size_t R = p->aero_rows[k].size();
+    out.nrows[k] = (int32_t)R;
+    out.con[k] = (con[k] && R) ? base + off_c[k] : nullptr;
+    out.jac[k] = (out.con[k] && jac && jac[k]) ? base + off_j[k] : nullptr;
+  }
+  gel::ProblemDev dv = p->dev;
+  if (zero_copy) dv.flag = p->h_flag;
+  HIPCHK(gel::launch_aero(dv, (int)p->aero_nodes.size(), p->d_aero_nodes, B, zero_copy ? p->h_x : p->d_aero_x, out, p->stream));
+  if (!zero_copy) {
+    for (int k = 0; k < 3; k++) {
+      if (out.con[k]) HIPCHK(hipMemcpyAsync(con[k], out.con[k], (size_t)B * p->aero_rows[k].size() * 8, hipMemcpyDeviceToHost, p->stream));
+      if (out.jac[k]) HIPCHK(hipMemcpyAsync(jac[k], out.jac[k], (size_t)B * aero_jac_len(p, k) * 8, hipMemcpyDeviceToHost, p->stream));
+    }
+    HIPCHK(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
+  }
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (zero_copy)
+    for (int k = 0; k < 3; k++) {
+      if (out.con[k]) std::memcpy(con[k], out.con[k], (size_t)B * p->aero_rows[k].size() * 8);
+      if (out.jac[k]) std::memcpy(jac[k], out.jac[k], (size_t)B * aero_jac_len(p, k) * 8);
+    }
+  if (*p->h_flag) {
+    *p->h_flag = 0;
+    if (!zero_copy) HIPCHK(hipMemsetAsync(p->d_flag, 0, 4, p->stream));
+    return GEL_NONFINITE;
+  }
+  return GEL_OK;
+}
+
 int gel_eval_aero(gel_problem* p, int32_t kind, int32_t B, const double* x, double* con, double* jac_vals) {
   if (!p || kind < 0 || kind > 2 || B < 1 || !x || !con) return fail(GEL_ERR_ARG, "bad argument");
-  NEED_DEVICE(p);
-  const int R = (int)p->aero_rows[kind].size();
-  if (R == 0) return GEL_OK;
-  HIPCHK(hipSetDevice(p->device));
-  const size_t nx = (size_t)B * p->dims.num_vars, nc = (size_t)B * R, nj = (size_t)B * R * ((kind == 1) ? 8 : 12);
-  if ((nx + nc + (jac_vals ? nj : 0)) * 8 <= kZeroCopyBytes) {
-    // small call (the optimiser's callback): zero-copy through pinned host memory like run_host
-    int rc = ensure_capacity(p, B);
-    if (rc) return rc;
-    if (p->h_aero_cap < nc + nj) {
-      if (p->h_aero) hipHostFree(p->h_aero);
-      p->h_aero = nullptr; p->h_aero_cap = 0;
-      HIPCHK(hipHostMalloc((void**)&p->h_aero, (nc + nj) * 8));
-      p->h_aero_cap = nc + nj;
-    }
-    std::memcpy(p->h_x, x, nx * 8);
-    gel::ProblemDev dv = p->dev;
-    dv.flag = p->h_flag;
-    HIPCHK(gel::launch_aero(dv, kind, R, p->d_aero_rows[kind], B, p->h_x, p->h_aero, jac_vals ? p->h_aero + nc : nullptr, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
-    std::memcpy(con, p->h_aero, nc * 8);
-    if (jac_vals) std::memcpy(jac_vals, p->h_aero + nc, nj * 8);
-    if (*p->h_flag) { *p->h_flag = 0; return GEL_NONFINITE; }
-    return GEL_OK;
-  }
-  double *d_x = nullptr, *d_c = nullptr, *d_j = nullptr;
-  auto cleanup = [&]() { hipFree(d_x); hipFree(d_c); hipFree(d_j); };
-#define HIPCHK3(expr)                                                                                          \
-  do {                                                                                                         \
-    hipError_t _e = (expr);                                                                                    \
-    if (_e != hipSuccess) { cleanup(); return fail(GEL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } \
-  } while (0)
-  HIPCHK3(hipMalloc((void**)&d_x, nx * 8));
-  HIPCHK3(hipMalloc((void**)&d_c, nc * 8));
-  if (jac_vals) HIPCHK3(hipMalloc((void**)&d_j, nj * 8));
-  HIPCHK3(hipMemcpyAsync(d_x, x, nx * 8, hipMemcpyHostToDevice, p->stream));
-  HIPCHK3(gel::launch_aero(p->dev, kind, R, p->d_aero_rows[kind], B, d_x, d_c, d_j, p->stream));
-  HIPCHK3(hipMemcpyAsync(con, d_c, nc * 8, hipMemcpyDeviceToHost, p->stream));
-  if (jac_vals) HIPCHK3(hipMemcpyAsync(jac_vals, d_j, nj * 8, hipMemcpyDeviceToHost, p->stream));
-  HIPCHK3(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
-  HIPCHK3(hipStreamSynchronize(p->stream));
-#undef HIPCHK3
-  cleanup();
-  if (*p->h_flag) { hipMemsetAsync(p->d_flag, 0, 4, p->stream); return GEL_NONFINITE; }
-  return GEL_OK;
+  double* c[3] = {nullptr, nullptr, nullptr};
+  double* j[3] = {nullptr, nullptr, nullptr};
+  c[kind] = con; j[kind] = jac_vals;
+  return gel_eval_aero_all(p, B, x, c, j);
 }
 
 // ------------- knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py) -------------
@@ -1246,17 +1313,6 @@ int gel_rows_eval_device(gel_problem* p, int32_t B, const double* d_x, double* d
   return GEL_OK;
 }
 
-namespace {
-// grows a device or pinned buffer; on failure the buffer is gone and its capacity is 0 (never a stale pointer)
-int grow(double** buf, size_t* cap, size_t need, bool pinned) {
-  if (*cap >= need) return GEL_OK;
-  if (*buf) { if (pinned) hipHostFree(*buf); else hipFree(*buf); }
-  *buf = nullptr; *cap = 0;
-  HIPCHK(pinned ? hipHostMalloc((void**)buf, need * 8) : hipMalloc((void**)buf, need * 8));
-  *cap = need;
-  return GEL_OK;
-}
-}  // namespace
 
 int gel_rows_eval(gel_problem* p, int32_t B, const double* x, double* con, double* jfn) {
   if (!p || B < 1 || !x || !con) return fail(GEL_ERR_ARG, "bad argument");

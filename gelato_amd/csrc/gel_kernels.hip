@@ -251,103 +251,184 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
 
 // ---------------------------------------------------------------------------
 // Aero path constraints: lib/con_aero.py:90-252 (values) and :311-756 (forward-
-// difference gradients), device functions of src/wrapper_utils.hpp:89-206.  One lane = one constraint
-// row (a state node of a constrained phase); the 12 perturbed evaluations of its gradient re-run the
-// whole (cheap) chain, like the reference.  kind 0 = angle of attack, 1 = dynamic pressure, 2 = q*alpha.
+// difference gradients), device functions of src/wrapper_utils.hpp:89-206.  kind 0 = angle of attack,
+// 1 = dynamic pressure, 2 = q*alpha.
+//
+// ONE launch serves all three kinds.  A constrained state node (phase, k) appears once, whatever kinds constrain it,
+// and the chain (geodetic -> wind -> Earth angle -> wind in ECI -> air-relative velocity; thrust direction / atmosphere)
+// is split by what each piece depends on, as in gel_rhs_parts.h: a sweep recomputes only what its perturbed variable
+// enters (a reused piece is bit-identical to what the reference's full re-evaluation produces, because the perturbed
+// variable does not enter it).  Eight lanes per node: lane 0 the centre value plus the light sweeps (velocity 3:
+// only the air-relative velocity changes; quaternion 4: only the thrust direction), lanes 1..3 one position sweep
+// each (the whole chain), lanes 4..5 the t0 / tf sweeps (Earth angle -> wind rotation -> air-relative velocity).  The
+// centre values reach the other lanes by a wavefront shuffle.  4 + 2 heavy evaluations per node instead of the
+// 3 kinds x 13 of one-lane-per-row.
 // ---------------------------------------------------------------------------
-GEL_DEV double aero_value(int kind, const double re[3], const double ve[3], const double q[4], double t_e,
-                          const ProblemDev& P, const Tables& tb, double limit) {
-  // con_aero.py:39-87: scale, evaluate, divide by units[3]
-  const double r[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
-  const double v[3] = {ve[0] * P.uv, ve[1] * P.uv, ve[2] * P.uv};
-  const double t = t_e * P.ut;
-  // air-relative velocity in ECI: wrapper_utils.hpp:93-100 (same chain as the RHS)
-  double lat, p, ip, sl, cl;
-  geodetic_lat_p(r[0], r[1], r[2], lat, p, ip);
+struct AeroPos {            // depends on position only
+  double rho;               // density at the node
+  double wn, we;            // wind, NED
+  double shp, chp, inv_p;   // NED half-latitude pair, 1/p
+};
+
+GEL_DEV AeroPos aero_pos_part(const double r[3], const Tables& tb) {
+  AeroPos o;
+  double lat, p, sl, cl;
+  geodetic_lat_p(r[0], r[1], r[2], lat, p, o.inv_p);
   fsincos(lat, &sl, &cl);
   const double h = geopotential_altitude(geodetic_alt_from(p, sl, cl));
-  double wn, we, w[3];
-  wind_ned2(h, tb.wind, tb.winds, tb.Kw, wn, we);
-  const EarthAngle ea = earth_angle(t);
-  double chp, irt;
-  fsqrt_rsqrt(0.5 * (1.0 + cl), chp, irt);
-  wind_eci(r, ea, (0.5 * sl) * irt, chp, ip, wn, we, w);
-  const double d0 = v[0] + kOmega * r[1], d1 = v[1] - kOmega * r[0];
-  const double e0 = d0 * ea.c + d1 * ea.s, e1 = -d0 * ea.s + d1 * ea.c;
-  const double a0 = (e0 * ea.c - e1 * ea.s) - w[0], a1 = (e0 * ea.s + e1 * ea.c) - w[1], a2 = v[2] - w[2];
-  const double nv = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-  double alpha = 0.0, qdyn = 0.0;
-  if (kind != 1) {  // wrapper_utils.hpp:89-111
-    double dir[3];
-    thrust_dir(q, dir);
-    const double nd = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-    const double c_alpha = (a0 / nv) * (dir[0] / nd) + (a1 / nv) * (dir[1] / nd) + (a2 / nv) * (dir[2] / nd);
-    alpha = (c_alpha > 1.0) ? 0.0 : ((nv < 1e-6) ? 0.0 : acos(c_alpha));
-  }
-  if (kind != 0) {  // wrapper_utils.hpp:163-175
-    const Air air = atmosphere(h, tb.atm);
-    qdyn = 0.5 * air.rho * nv * nv;
-  }
-  const double f = (kind == 0) ? alpha : (kind == 1) ? qdyn : qdyn * alpha;
-  return f / limit;
+  wind_ned2(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we);
+  double irt;
+  fsqrt_rsqrt(0.5 * (1.0 + cl), o.chp, irt);
+  o.shp = (0.5 * sl) * irt;
+  o.rho = atmosphere(h, tb.atm).rho;      // wrapper_utils.hpp:163-175
+  return o;
 }
 
-// SPLIT (latency form for small launches): 13 lanes per row -- lane group 0 writes the value, group s + 1 the
-// gradient entry of sweep s (re-evaluating the centre) -- so a lane runs the chain twice instead of 13 times.
-template <bool SPLIT>
-__global__ void aero_kernel(ProblemDev P, int kind, int nrows, const AeroRowDev* __restrict__ rows, int B,
-                            const double* __restrict__ x, double* __restrict__ con, double* __restrict__ jac) {
+// air-relative velocity in ECI (wrapper_utils.hpp:93-100) and its norm
+GEL_DEV double aero_vair(const double r[3], const double v[3], const EarthAngle& ea, const double w[3], double a[3]) {
+  const double d0 = v[0] + kOmega * r[1], d1 = v[1] - kOmega * r[0];
+  const double e0 = d0 * ea.c + d1 * ea.s, e1 = -d0 * ea.s + d1 * ea.c;
+  a[0] = (e0 * ea.c - e1 * ea.s) - w[0]; a[1] = (e0 * ea.s + e1 * ea.c) - w[1]; a[2] = v[2] - w[2];
+  return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+}
+
+// angle of attack (wrapper_utils.hpp:89-111)
+GEL_DEV double aero_alpha(const double a[3], double nv, const double q[4]) {
+  double dir[3];
+  thrust_dir(q, dir);
+  const double nd = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+  const double c_alpha = (a[0] / nv) * (dir[0] / nd) + (a[1] / nv) * (dir[1] / nd) + (a[2] / nv) * (dir[2] / nd);
+  return (c_alpha > 1.0) ? 0.0 : ((nv < 1e-6) ? 0.0 : acos(c_alpha));
+}
+
+struct AeroOut {
+  double* con[3];   // [B][nrows[kind]]
+  double* jac[3];   // [B][nrows[kind] * (8 + 4 (kind != 1))]: position | velocity | quaternion | t blocks
+  int32_t nrows[3];
+};
+
+// Workgroup = 64 consecutive constrained nodes of one decision vector x 6 roles, one wavefront per role (wave-uniform: no
+// divergence): role 0 the centre value + the light sweeps (velocity 3: only the air-relative velocity changes;
+// quaternion 4: only the thrust direction), roles 1..3 one position sweep each (the whole chain), roles 4..5 the t0 / tf
+// sweeps.  The centre values reach the other wavefronts through LDS.  Consecutive lanes are consecutive nodes of a spec,
+// so every store of a gradient block is one contiguous segment (which is what lets the B = 1 callback write straight into
+// pinned host memory).
+constexpr int kAeroRoles = 6;
+__global__ __launch_bounds__(64 * kAeroRoles) void aero_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
+                                                                 int tiles, const double* __restrict__ x, AeroOut O) {
   extern __shared__ double lds[];
   const Tables tb = stage_tables(P, lds);
-  long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long per = (long long)B * nrows;
-  int sp = 0;  // sweep group, lane-group major so that a wavefront mostly shares one sweep
-  if (SPLIT) { sp = (int)(tid / per); tid -= (long long)sp * per; if (sp > 12 || (sp && !jac)) return; }
-  if (tid >= per) return;
-  const int b = (int)(tid / nrows), row = (int)(tid - (long long)b * nrows);
-  const AeroRowDev R = rows[row];
-  const PhaseDev& ph = P.phases[R.phase];
+  double* centre = lds + ((table_doubles(P.Kw, P.Kc) + 1) & ~1);   // [2][64]: alpha, q of the centre evaluation
+  const int sw = (int)(threadIdx.x >> 6);              // 0 centre + light sweeps, 1..3 position, 4 t0, 5 tf
+  const int lane = (int)(threadIdx.x & 63);
+  const int b = (int)(blockIdx.x / (unsigned)tiles), tile = (int)(blockIdx.x - (unsigned)b * (unsigned)tiles);
+  const int ni_raw = tile * 64 + lane;
+  const bool live = ni_raw < nnodes;
+  const int ni = live ? ni_raw : nnodes - 1;
+  const AeroNodeDev Nd = nodes[ni];
+  const PhaseDev& ph = P.phases[Nd.phase];
   const double* xb = x + (size_t)b * P.nvars;
-  const int M = P.M, N = P.N, xi = ph.xa + R.k;
-  const double* pr = xb + M + 3 * xi;
-  const double* pv = xb + 4 * M + 3 * xi;
-  const double* pq = xb + 7 * M + 4 * xi;
-  const double to = xb[11 * M + 2 * N + R.phase], tf = xb[11 * M + 2 * N + R.phase + 1];
-  const double tau = (R.k == 0) ? 0.0 : P.tau[ph.toff + R.k - 1];
-  // PSparams.time_nodes (SectionParameters.py:77-81): node 0 is t0 itself
-#define TNODE(a, bb) ((R.k == 0) ? (a) : (tau * ((bb) - (a)) / 2 + ((bb) + (a)) / 2))
-  const double re[3] = {pr[0], pr[1], pr[2]}, ve[3] = {pv[0], pv[1], pv[2]}, q[4] = {pq[0], pq[1], pq[2], pq[3]};
+  const int M = P.M, N = P.N, xi = ph.xa + Nd.k;
   const double dx = P.dx;
-  const double fc = aero_value(kind, re, ve, q, TNODE(to, tf), P, tb, R.limit);
-  double chk = 1.0 - fc;
-  if (!SPLIT || sp == 0) con[(size_t)b * nrows + row] = 1.0 - fc;  // con_aero.py:127-139
-  if (jac && !(SPLIT && sp == 0)) {
-    const int nq = (kind == 1) ? 0 : 4;
-    double* jb = jac + (size_t)b * nrows * (8 + nq);
-    double* jp = jb + 3 * R.row0 + R.k;                         // position block, [j][k] per spec
-    double* jv = jb + 3 * nrows + 3 * R.row0 + R.k;             // velocity block
-    double* jq = jb + 6 * nrows + 4 * R.row0 + R.k;             // quaternion block
-    double* jt = jb + (6 + nq) * nrows + 2 * R.row0 + R.k;      // t block: t0 column then tf column
-#pragma unroll 1
-    for (int s = SPLIT ? sp - 1 : 0; s < (SPLIT ? sp : 12); s++) {
-      double rp[3], vp[3], qp[4];
+  double re[3], ve[3], q[4];
 #pragma unroll
-      for (int c = 0; c < 3; c++) { rp[c] = (s == c) ? re[c] + dx : re[c]; vp[c] = (s == 3 + c) ? ve[c] + dx : ve[c]; }
+  for (int c = 0; c < 3; c++) { re[c] = xb[M + 3 * xi + c]; ve[c] = xb[4 * M + 3 * xi + c]; }
 #pragma unroll
-      for (int c = 0; c < 4; c++) qp[c] = (s == 6 + c) ? q[c] + dx : q[c];
-      if (s >= 6 && s < 10 && kind == 1) continue;               // dynamic pressure has no quaternion block
-      const double tn = (s == 10) ? TNODE(to + dx, tf) : (s == 11) ? TNODE(to, tf + dx) : TNODE(to, tf);
-      const double fp = aero_value(kind, rp, vp, qp, tn, P, tb, R.limit);
-      const double gval = -((fp - fc) / dx);                      // jac = -dfdx  (con_aero.py:437-463)
-      chk += gval;
-      if (s < 3) jp[s * R.nk] = gval;
-      else if (s < 6) jv[(s - 3) * R.nk] = gval;
-      else if (s < 10) jq[(s - 6) * R.nk] = gval;
-      else jt[(s - 10) * R.nk] = gval;
+  for (int c = 0; c < 4; c++) q[c] = xb[7 * M + 4 * xi + c];
+  double to = xb[11 * M + 2 * N + Nd.phase], tf = xb[11 * M + 2 * N + Nd.phase + 1];
+  const double tau = (Nd.k == 0) ? 0.0 : P.tau[ph.toff + Nd.k - 1];
+  if (sw == 4) to += dx;
+  if (sw == 5) tf += dx;
+  // PSparams.time_nodes (SectionParameters.py:77-81): node 0 is t0 itself; t in seconds here (con_aero.py:45)
+  const double t = ((Nd.k == 0) ? to : (tau * (tf - to) / 2 + (tf + to) / 2)) * P.ut;
+  // con_aero.py:39-87: scale, evaluate
+  double r[3], v[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) { r[c] = ((sw == 1 + c) ? re[c] + dx : re[c]) * P.up; v[c] = ve[c] * P.uv; }
+  const AeroPos pp = aero_pos_part(r, tb);
+  const EarthAngle ea = earth_angle(t);
+  double w[3], a0[3];
+  wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
+  const double nv0 = aero_vair(r, v, ea, w, a0);
+  const double alpha = aero_alpha(a0, nv0, q);
+  const double rho = pp.rho;
+  const double qdyn = 0.5 * rho * nv0 * nv0;
+  if (sw == 0) { centre[lane] = alpha; centre[64 + lane] = qdyn; }
+  __syncthreads();
+  if (!live) return;
+  const double alpha_c = centre[lane], qdyn_c = centre[64 + lane];
+  double chk = 0.0;
+  // role 0: the light sweeps, once for all kinds
+  double al_v[3] = {0, 0, 0}, qd_v[3] = {0, 0, 0}, al_q[4] = {0, 0, 0, 0};
+  const bool want_jac = O.jac[0] || O.jac[1] || O.jac[2];
+  if (sw == 0 && want_jac) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double vp[3], a[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) vp[d] = ((d == c) ? ve[d] + dx : ve[d]) * P.uv;
+      const double nv = aero_vair(r, vp, ea, w, a);
+      al_v[c] = aero_alpha(a, nv, q);
+      qd_v[c] = 0.5 * rho * nv * nv;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      double qp[4];
+#pragma unroll
+      for (int d = 0; d < 4; d++) qp[d] = (d == c) ? q[d] + dx : q[d];
+      al_q[c] = aero_alpha(a0, nv0, qp);
     }
   }
-#undef TNODE
+#pragma unroll
+  for (int kind = 0; kind < 3; kind++) {
+    const int row = Nd.row[kind];
+    if (row < 0 || !O.con[kind]) continue;
+    const int R = O.nrows[kind], nk = Nd.nk[kind], row0 = Nd.row0[kind], nq = (kind == 1) ? 0 : 4;
+    const double lim = Nd.limit[kind];
+    // f / units[3] (con_aero.py:85-87); con = 1 - f (:127-139); jac = -(f_p - f_c)/dx (:437-463)
+#define GEL_AERO_F(al, qd) (((kind == 0) ? (al) : (kind == 1) ? (qd) : (qd) * (al)) / lim)
+    const double fc = GEL_AERO_F(alpha_c, qdyn_c);
+    double* jb = O.jac[kind] ? O.jac[kind] + (size_t)b * R * (8 + nq) : nullptr;
+    if (sw == 0) {
+      const double cv = 1.0 - fc;
+      O.con[kind][(size_t)b * R + row] = cv;
+      chk += cv;
+      if (jb) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const double gv = -((GEL_AERO_F(al_v[c], qd_v[c]) - fc) / dx);
+          jb[3 * R + 3 * row0 + c * nk + Nd.k] = gv;                         // velocity block
+          chk += gv;
+        }
+        if (kind != 1) {                                                     // dynamic pressure has no quaternion block
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const double gv = -((GEL_AERO_F(al_q[c], qdyn_c) - fc) / dx);
+            jb[6 * R + 4 * row0 + c * nk + Nd.k] = gv;
+            chk += gv;
+          }
+        }
+      }
+    } else if (jb) {
+      const double gv = -((GEL_AERO_F(alpha, qdyn) - fc) / dx);
+      if (sw <= 3) jb[3 * row0 + (sw - 1) * nk + Nd.k] = gv;                  // position block, [component][node] per spec
+      else jb[(6 + nq) * R + 2 * row0 + (sw - 4) * nk + Nd.k] = gv;            // t block: t0 column then tf column
+      chk += gv;
+    }
+#undef GEL_AERO_F
+  }
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
+}
+
+hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
+                       const AeroLaunchOut& out, hipStream_t s) {
+  if (B <= 0 || nnodes <= 0) return hipSuccess;
+  AeroOut O;
+  for (int k = 0; k < 3; k++) { O.con[k] = out.con[k]; O.jac[k] = out.jac[k]; O.nrows[k] = out.nrows[k]; }
+  const int tiles = (nnodes + 63) / 64;
+  const size_t lds = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + 128);
+  hipLaunchKernelGGL(aero_kernel, dim3((unsigned)B * (unsigned)tiles), dim3(64 * kAeroRoles), lds, s, P, nnodes, nodes, tiles, d_x, O);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -432,20 +513,6 @@ hipError_t launch_rows(const ProblemDev& P, int nlin, const LinRowDev* lin, int 
   if (B <= 0 || nlin + nfn <= 0) return hipSuccess;
   const int lb = (int)(((long long)B * nlin + 255) / 256), fb = (int)(((long long)B * nfn * 8 + 255) / 256);
   hipLaunchKernelGGL(rows_kernel, dim3((unsigned)(lb + fb)), dim3(256), 0, s, P, nlin, lin, nfn, fr, B, lb, d_x, d_con, d_jfn);
-  return hipGetLastError();
-}
-
-hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDev* rows, int B, const double* d_x,
-                       double* d_con, double* d_jac, hipStream_t s) {
-  if (B <= 0 || nrows <= 0) return hipSuccess;
-  const long long threads = (long long)B * nrows;
-  const size_t lds = sizeof(double) * staged_table_doubles(P.Kw, P.Kc);
-  if (d_jac && threads * 13 <= 64 * 1024)  // fits one wavefront per SIMD even when split: take the short chain
-    hipLaunchKernelGGL(aero_kernel<true>, dim3((unsigned)((threads * 13 + 63) / 64)), dim3(64), lds, s, P, kind, nrows,
-                       rows, B, d_x, d_con, d_jac);
-  else
-    hipLaunchKernelGGL(aero_kernel<false>, dim3((unsigned)((threads + 63) / 64)), dim3(64), lds, s, P, kind, nrows, rows,
-                       B, d_x, d_con, d_jac);
   return hipGetLastError();
 }
 

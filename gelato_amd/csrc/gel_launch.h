@@ -26,8 +26,10 @@ hipError_t launch_rhs_quat(int n, const double* quat, const double* u_e, double 
 hipError_t launch_point(int kind, int n, const double* in, const double* aux, int aux_rows, double* out,
                         hipStream_t s);
 
-hipError_t launch_aero(const ProblemDev& P, int kind, int nrows, const AeroRowDev* rows, int B, const double* d_x,
-                       double* d_con, double* d_jac, hipStream_t s);
+// outputs of one aero launch: per kind (0 alpha, 1 q, 2 q-alpha) the constraint vector and the COO values, or null
+struct AeroLaunchOut { double* con[3]; double* jac[3]; int32_t nrows[3]; };
+hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
+                       const AeroLaunchOut& out, hipStream_t s);
 
 hipError_t launch_rows(const ProblemDev& P, int nlin, const LinRowDev* lin, int nfn, const FnRowDev* fr, int B,
                        const double* d_x, double* d_con, double* d_jfn, hipStream_t s);

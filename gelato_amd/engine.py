@@ -284,12 +284,17 @@ class Engine:
         lim = _f64(spec[:, 2])
         check(lib().gel_aero_configure(self._h, self.AERO_KINDS.index(kind), len(ph), ph.ctypes.data_as(_ip),
                                        ra.ctypes.data_as(_ip), _d(lim)))
+        self._aero_dims = {}
+        self._aero_out = {}
 
     def aero_dims(self, kind):
-        n = C.c_int32()
-        nnz = (C.c_int64 * 4)()
-        check(lib().gel_aero_dims(self._h, self.AERO_KINDS.index(kind), C.byref(n), nnz))
-        return n.value, [int(v) for v in nnz]
+        d = self.__dict__.setdefault("_aero_dims", {})
+        if kind not in d:
+            n = C.c_int32()
+            nnz = (C.c_int64 * 4)()
+            check(lib().gel_aero_dims(self._h, self.AERO_KINDS.index(kind), C.byref(n), nnz))
+            d[kind] = (n.value, [int(v) for v in nnz])
+        return d[kind]
 
     def aero_pattern(self, kind):
         nrow, nnz = self.aero_dims(kind)
@@ -312,6 +317,38 @@ class Engine:
         rc = check(lib().gel_eval_aero(self._h, self.AERO_KINDS.index(kind), B, _d(X), _d(con),
                                        _d(jv) if want_jac else None))
         return con, jv, rc
+
+    def eval_aero_all(self, X, want_jac=True, kinds=None, reuse=False):
+        """all configured kinds in one launch: X [B, nvars] (or [nvars]) -> ({kind: con [B, nrows]}, {kind: jac_vals} | None,
+        status); kinds without rows are left out.  reuse=True hands out the engine's own output arrays (overwritten by
+        the next call of the same shape) instead of fresh ones."""
+        X = _f64(X).reshape(-1, self.nvars)
+        B = X.shape[0]
+        key = (B, bool(want_jac), None if kinds is None else tuple(kinds))
+        slot = self.__dict__.setdefault("_aero_out", {}).get(key) if reuse else None
+        if slot is None:
+            con, jac = {}, {}
+            cp, jp = (_dp * 3)(), (_dp * 3)()
+            for i, kind in enumerate(self.AERO_KINDS):
+                nrow, nnz = self.aero_dims(kind)
+                if nrow and (kinds is None or kind in kinds):
+                    con[kind] = np.empty((B, nrow))
+                    cp[i] = _d(con[kind])
+                    if want_jac:
+                        jac[kind] = np.empty((B, sum(nnz)))
+                        jp[i] = _d(jac[kind])
+            slot = (con, jac, cp, jp)
+            if reuse:
+                self._aero_out[key] = slot
+        con, jac, cp, jp = slot
+        rc = check(lib().gel_eval_aero_all(self._h, B, _d(X), cp, jp if want_jac else None))
+        return con, (jac if want_jac else None), rc
+
+    def eval_aero_all_device(self, B, d_x, d_con, d_jac=None, stream=0):
+        """device pointers (ints): d_con / d_jac = 3 entries per kind (0 = not wanted)"""
+        cp = (C.c_void_p * 3)(*[p or None for p in d_con])
+        jp = (C.c_void_p * 3)(*[p or None for p in d_jac]) if d_jac is not None else None
+        check(lib().gel_eval_aero_all_device(self._h, B, d_x, cp, jp, stream or None))
 
     def initial_guess(self, t_ref, table, knot_times):
         """initialize.py:322-409 behind the C-ABI: reference trajectory (t_ref [n], table [n, 13] = mass | pos 3 | vel 3 |

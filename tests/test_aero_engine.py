@@ -109,3 +109,43 @@ def test_con_aero_shim_like_reference():
     assert np.array_equal(funcs["ineqcon_alpha"], con_aero.inequality_max_alpha(xd, pdict, unitdict, full))
     assert funcs["ineqcon_qalpha"].shape == (17,) and list(fs["ineqcon_qalpha"]) == VARS
     assert "eqcon_dyn_vel" in funcs and "eqcon_dyn_vel" in fs
+
+
+@pytest.mark.gpu
+def test_all_kinds_in_one_launch_equal_the_single_kind_calls():
+    """gel_eval_aero_all: host buffers (small zero-copy call and large copy call) and device buffers give the bits of the
+    per-kind calls; a kind without rows is left out; values-only calls leave the gradient buffers alone."""
+    import torch
+    from gelato_amd import Engine, problem
+    g = load_golden("g9_aero_example.npz")
+    prob = problem_from_golden(g)
+    D, tau = D_tau_from_golden(g, prob)
+    E = Engine(prob, D=D, tau=tau)
+    for kind in KINDS:
+        E.aero_configure(kind, spec_from_golden(g, "synthetic", kind))
+    x = g["x"]
+    for B in (1, 7, 400):                                   # 400 vectors: beyond the zero-copy size
+        X = problem.synthetic_batch(x, E.M, B, seed=9)
+        con, jac, rc = E.eval_aero_all(X)
+        assert rc == 0 and sorted(con) == sorted(KINDS)
+        for kind in KINDS:
+            c1, j1, _ = E.eval_aero(kind, X)
+            assert np.array_equal(con[kind], c1) and np.array_equal(jac[kind], j1), (B, kind)
+        c2, j2, _ = E.eval_aero_all(X, want_jac=False)
+        assert j2 is None and all(np.array_equal(c2[k], con[k]) for k in KINDS)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    dX = torch.from_numpy(X).to(dev)
+    dims = [E.aero_dims(k) for k in E.AERO_KINDS]
+    dcon = [torch.empty((B, d[0]), dtype=torch.float64, device=dev) for d in dims]
+    djac = [torch.full((B, sum(d[1])), -3.0, dtype=torch.float64, device=dev) for d in dims]
+    E.eval_aero_all_device(B, dX.data_ptr(), [t.data_ptr() for t in dcon], None, s)
+    assert E.sync(s) == 0 and all(torch.all(t == -3.0) for t in djac)
+    E.eval_aero_all_device(B, dX.data_ptr(), [t.data_ptr() for t in dcon], [t.data_ptr() for t in djac], s)
+    assert E.sync(s) == 0
+    for i, kind in enumerate(E.AERO_KINDS):
+        assert np.array_equal(dcon[i].cpu().numpy(), con[kind]) and np.array_equal(djac[i].cpu().numpy(), jac[kind])
+    # a kind loses its rows: it drops out of the joint call, the others are unchanged
+    E.aero_configure("q", [])
+    con3, jac3, _ = E.eval_aero_all(X)
+    assert sorted(con3) == ["alpha", "qalpha"] and np.array_equal(con3["alpha"], con["alpha"]) and np.array_equal(jac3["qalpha"], jac["qalpha"])
