@@ -44,6 +44,11 @@ class GelNodefnRow(C.Structure):
     _fields_ = [("fn", C.c_int32), ("node", C.c_int32), ("p0", C.c_double), ("p1", C.c_double)]
 
 
+class GelCallbackIO(C.Structure):
+    _fields_ = [("res", _dp), ("vals_full", _dp), ("fill_constants", C.c_int32), ("rows_con", _dp), ("rows_jfn", _dp),
+                ("aero_con", _dp * 3), ("aero_jac", _dp * 3)]
+
+
 class GelDims(C.Structure):
     _fields_ = [
         ("S", C.c_int32), ("N", C.c_int32), ("M", C.c_int32), ("num_vars", C.c_int32),
@@ -96,6 +101,7 @@ SIGNATURES = {
     "gel_rows_dims": (C.c_int, [C.c_void_p, _ip, _ip]),
     "gel_rows_eval": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
     "gel_rows_eval_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gel_eval_callback": (C.c_int, [C.c_void_p, _dp, C.POINTER(GelCallbackIO)]),
     "gel_initial_guess": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp]),
     "gel_dynamics_velocity": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32,
                                          _dp, C.c_double, _dp]),

@@ -55,24 +55,16 @@ def _configure_all(pdict, unitdict, condition):
 
 
 def _evaluate(xdict, pdict, unitdict, condition, want_jac):
-    """The first of the three functions called for a new xdict evaluates ALL configured kinds in one launch (a state
-    node constrained by several kinds runs the air-velocity chain once); the others return their share of it."""
+    """The aero share of the callback's one device round trip (all configured kinds in one launch: a state node
+    constrained by several kinds runs the air-velocity chain once)."""
     st, nspec = _configure_all(pdict, unitdict, condition)
-    x = pack_x(xdict)
-    slot = "aero_jac_cache" if want_jac else "aero_con_cache"
-    cache = st.__dict__.get(slot)
-    key = tuple(sorted(st.__dict__.get("aero_spec", {}).items()))
-    if cache is None or cache[0] != key or not np.array_equal(cache[1], x):
-        con, jac, rc = st.engine.eval_aero_all(x, want_jac=want_jac, reuse=True)   # copies are handed out below
-        cache = (key, x, con, jac, rc)
-        st.__dict__[slot] = cache
-    st.status |= cache[4]                       # also when the cached result is handed out again
-    return st, nspec, cache[2], cache[3]
+    fr = st.frame(xdict, want_jac)
+    return st, nspec, fr["aero_con"], fr["aero_jac"]
 
 
 def _values(xdict, pdict, unitdict, condition, kind):
     st, nspec, con, _ = _evaluate(xdict, pdict, unitdict, condition, False)
-    return con[kind][0].copy() if nspec[kind] else None
+    return con[kind].copy() if nspec[kind] else None
 
 
 def _length(pdict, unitdict, condition, kind):
@@ -94,7 +86,7 @@ def _jacobian(xdict, pdict, unitdict, condition, kind):
     jac, off = {}, 0
     for v, var in enumerate(eng.AERO_VARS):
         r, c = pats[kind][v]
-        jac[var] = {"coo": [r, c, jv[kind][0, off:off + nnz[v]].copy()], "shape": shapes[v]}
+        jac[var] = {"coo": [r, c, jv[kind][off:off + nnz[v]].copy()], "shape": shapes[v]}
         off += nnz[v]
     return jac
 

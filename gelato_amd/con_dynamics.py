@@ -53,27 +53,31 @@ class _State:
         # D and tau are inputs of the path: whatever PSparams the caller put in pdict is used as is
         self.engine = Engine(prob, D=[ps.D(i) for i in range(S)], tau=[ps.tau(i) for i in range(S)],
                              barC20=float(pdict.get("barC20", 0.0)), device=int(pdict.get("device", 0)))
-        self.x_res = None
-        self.res = None
-        self.x_jac = None
-        self.vals = None
         self.status = 0
+        self._frame = None      # everything the device produced for the last xdict (one round trip)
+        self._frame_sig = None
+
+    def frame(self, xdict, need_jac):
+        """All device outputs for `xdict`: the first function of a callback that asks evaluates the four defect groups,
+        the knot / terminal / user row table and the aero path constraints -- whatever is configured on the handle -- in
+        ONE round trip (gel_eval_callback); the other functions of the callback read their share.  A derivative asked
+        for after a values-only frame of the same xdict re-evaluates with derivatives."""
+        x = pack_x(xdict)
+        eng = self.engine
+        sig = eng._cfg_gen      # a frame is only valid for the row table / aero specs it was evaluated with
+        fr = self._frame
+        if fr is None or self._frame_sig != sig or (need_jac and not fr["jac"]) or not np.array_equal(fr["x"], x):
+            fr = dict(eng.eval_callback(x, need_jac))
+            fr["x"], fr["jac"] = x, bool(need_jac)
+            self._frame, self._frame_sig = fr, sig
+        self.status |= fr["rc"]             # also when the cached frame is handed out again
+        return fr
 
     def residuals(self, xdict):
-        x = pack_x(xdict)
-        if self.x_res is None or not np.array_equal(x, self.x_res):
-            self.res, self.rc_res = self.engine.eval_residual(x)
-            self.x_res = x
-        self.status |= self.rc_res          # also when the cached result is handed out again
-        return self.engine.split_res(self.res)
+        return self.engine.split_res(self.frame(xdict, False)["res"])
 
     def jacobians(self, xdict):
-        x = pack_x(xdict)
-        if self.x_jac is None or not np.array_equal(x, self.x_jac):
-            self.vals, self.rc_jac = self.engine.eval_jacobian(x, out=self.vals)
-            self.x_jac = x
-        self.status |= self.rc_jac
-        return self.engine.jac_dicts(self.vals)
+        return self.engine.jac_dicts(self.frame(xdict, True)["vals"])
 
 
 def _state(pdict, unitdict):

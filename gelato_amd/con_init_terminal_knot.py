@@ -160,16 +160,11 @@ class _Rows:
         eng.rows_configure(lin, fn)
         self.engine = eng
         self.M = M
-        self.x = None
-        self.con = self.jfn = None
 
-    def evaluate(self, xdict, pdict):
-        x = pack_x(xdict)
-        if self.x is None or not np.array_equal(x, self.x):
-            con, jfn, rc = self.engine.rows_eval(x, want_jac=True)
-            self.con, self.jfn, self.x, self.rc = con[0], jfn[0], x, rc
-        con_dynamics.note_status(pdict, self.rc)     # also when the cached result is handed out again
-        return self.con, self.jfn
+    def evaluate(self, xdict, pdict, need_jac=False):
+        """(con [nlin + nfn], jfn [nfn, 6] | None) of this xdict, from the callback's one device round trip"""
+        fr = con_dynamics._state(pdict, None).frame(xdict, need_jac)
+        return fr["rows_con"], fr["rows_jfn"]
 
 
 def rows_of(pdict, unitdict, condition):
@@ -237,7 +232,7 @@ def equality_6DoF_LGR_terminal(xdict, pdict, unitdict, condition):
 def equality_jac_6DoF_LGR_terminal(xdict, pdict, unitdict, condition):
     """Jacobian of equality_terminal."""
     R = rows_of(pdict, unitdict, condition)
-    _, jfn = R.evaluate(xdict, pdict)
+    _, jfn = R.evaluate(xdict, pdict, need_jac=True)
     nT, M = R.n_terminal, R.M
     rows, cols = R.terminal_pattern
     J = jfn[:nT]                                           # [row][position xyz, velocity xyz]

@@ -59,17 +59,17 @@ def _device_rows(pdict):
     return eq, ineq
 
 
-def _device_eval(xdict, pdict, unitdict, condition, which):
+def _device_eval(xdict, pdict, unitdict, condition, which, need_jac=False):
     eq, ineq = _device_rows(pdict)
     mine = eq if which == 0 else ineq
     if not mine:
         return None, None, None
     R = _rows.rows_of(pdict, unitdict, condition)
-    con, jfn = R.evaluate(xdict, pdict)
+    con, jfn = R.evaluate(xdict, pdict, need_jac)
     first = R.nlin + R.n_terminal + (0 if which == 0 else len(eq))
     sl = slice(first, first + len(mine))
     nodes = R.user_nodes[(0 if which == 0 else len(eq)):][:len(mine)]
-    return con[sl], jfn[sl.start - R.nlin:sl.stop - R.nlin], nodes
+    return con[sl], (jfn[sl.start - R.nlin:sl.stop - R.nlin] if need_jac else None), nodes
 
 
 def _device_form(m, which):
@@ -95,7 +95,7 @@ def _jacobian(xdict, pdict, unitdict, condition, which, name):
     if rows is not None and not rows:
         return None
     if rows:
-        con, jfn, nodes = _device_eval(xdict, pdict, unitdict, condition, which)
+        con, jfn, nodes = _device_eval(xdict, pdict, unitdict, condition, which, need_jac=True)
         jac = {key: np.zeros((len(con), np.asarray(val).size)) for key, val in xdict.items()}   # lib/jac_fd.py:54-55
         for r, node in enumerate(nodes):
             jac["position"][r, 3 * node:3 * node + 3] = jfn[r, 0:3]

@@ -1393,6 +1393,61 @@ int gel_initial_guess(const gel_problem* p, int32_t nref, const double* t_ref, c
   return GEL_OK;
 }
 
+// ------------- one callback = one device round trip -------------
+int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io) {
+  if (!p || !x || !io) return fail(GEL_ERR_ARG, "null argument");
+  NEED_DEVICE(p);
+  HIPCHK(hipSetDevice(p->device));
+  int rc = ensure_capacity(p, 1);
+  if (rc) return rc;
+  const size_t nlin = p->lin_rows.size(), nfn = p->fn_rows.size(), R = nlin + nfn;
+  const bool rows = io->rows_con && R;
+  size_t off_c[3], off_j[3], atotal = 0;
+  bool aero = false;
+  for (int k = 0; k < 3; k++) {
+    const size_t n = p->aero_rows[k].size();
+    off_c[k] = atotal; atotal += (io->aero_con[k] && n) ? n : 0;
+    off_j[k] = atotal; atotal += (io->aero_con[k] && n && io->aero_jac[k]) ? aero_jac_len(p, k) : 0;
+    aero = aero || (io->aero_con[k] && n);
+  }
+  if (rows && (rc = grow(&p->h_rows, &p->h_rows_cap, R + 6 * nfn + 1, true))) return rc;
+  if (aero && (rc = grow(&p->h_aero, &p->h_aero_cap, atotal, true))) return rc;
+  std::memcpy(p->h_x, x, (size_t)p->dims.num_vars * 8);
+  // everything reads x from and writes to pinned host memory; launches go back to back on the handle's stream
+  gel::ProblemDev dv = p->dev;
+  dv.flag = p->h_flag;
+  const bool want_jac = io->vals_full != nullptr;
+  if (io->res || want_jac)
+    HIPCHK(gel::launch_eval(dv, 1, p->h_x, (io->res || want_jac) ? p->h_res : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
+  if (rows)
+    HIPCHK(gel::launch_rows(dv, (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, 1, p->h_x, p->h_rows,
+                            io->rows_jfn ? p->h_rows + R : nullptr, p->stream));
+  gel::AeroLaunchOut out;
+  if (aero) {
+    for (int k = 0; k < 3; k++) {
+      const size_t n = p->aero_rows[k].size();
+      out.nrows[k] = (int32_t)n;
+      out.con[k] = (io->aero_con[k] && n) ? p->h_aero + off_c[k] : nullptr;
+      out.jac[k] = (out.con[k] && io->aero_jac[k]) ? p->h_aero + off_j[k] : nullptr;
+    }
+    HIPCHK(gel::launch_aero(dv, (int)p->aero_nodes.size(), p->d_aero_nodes, 1, p->h_x, out, p->stream));
+  }
+  HIPCHK(hipStreamSynchronize(p->stream));   // the ONE synchronise of the callback
+  if (io->res) std::memcpy(io->res, p->h_res, (size_t)11 * p->dims.N * 8);
+  if (want_jac) scatter_full(p, p->h_jv, io->vals_full, io->fill_constants);
+  if (rows) {
+    std::memcpy(io->rows_con, p->h_rows, R * 8);
+    if (io->rows_jfn) std::memcpy(io->rows_jfn, p->h_rows + R, 6 * nfn * 8);
+  }
+  if (aero)
+    for (int k = 0; k < 3; k++) {
+      if (out.con[k]) std::memcpy(io->aero_con[k], out.con[k], p->aero_rows[k].size() * 8);
+      if (out.jac[k]) std::memcpy(io->aero_jac[k], out.jac[k], aero_jac_len(p, k) * 8);
+    }
+  if (*p->h_flag) { *p->h_flag = 0; return GEL_NONFINITE; }
+  return GEL_OK;
+}
+
 int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux, int32_t aux_rows, double* out) {
   static const int nin[9] = {1, 3, 3, 6, 7, 1, 1, 2, 2}, nout[9] = {5, 3, 3, 3, 3, 3, 1, 4, 6};
   if (kind < 0 || kind > 8 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");

@@ -28,6 +28,11 @@ def make_callbacks(pdict, unitdict, condition):
 
     # the init / time / knot / terminal rows (and user rows) take part when the problem description carries what they read
     rows = all(k in pdict for k in ("event_index", "RocketStage")) and "init" in condition
+    if rows:  # a cut-down event list (the synthetic bench meshes) may lack a stage's ignition / separation events, which
+        # equality_knot_LGR looks up by name (lib/con_init_terminal_knot.py:192-203): no knot rows can be formed then
+        ev = pdict["event_index"]
+        rows = all(st["separation_at"] is None or (st["separation_at"] in ev and st["ignition_at"] in ev)
+                   for st in pdict["RocketStage"].values())
 
     def objfunc(xdict):
         con_dynamics.reset_status(pdict)         # the status is sticky over ALL device evaluations of this callback

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import GelDims, GelLinearRow, GelNodefnRow, GelProblemDesc, check, lib
+from ._lib import GelCallbackIO, GelDims, GelLinearRow, GelNodefnRow, GelProblemDesc, check, lib
 
 GROUPS = ["mass", "pos", "vel", "quat"]
 # funcs / funcsSens keys of the reference callbacks (Trajectory_Optimization.py:199-210,250-261)
@@ -105,6 +105,7 @@ class Engine:
         self._var_idx = None
         self._src = None
         self._nlin = self._nfn = 0
+        self._cfg_gen = 0       # bumped by every (re)configuration of the row table or of an aero kind
 
     # ------------------------------------------------------------------
     def close(self):
@@ -286,6 +287,8 @@ class Engine:
                                        ra.ctypes.data_as(_ip), _d(lim)))
         self._aero_dims = {}
         self._aero_out = {}
+        self._cb_out = {}
+        self._cfg_gen = getattr(self, "_cfg_gen", 0) + 1
 
     def aero_dims(self, kind):
         d = self.__dict__.setdefault("_aero_dims", {})
@@ -350,6 +353,46 @@ class Engine:
         jp = (C.c_void_p * 3)(*[p or None for p in d_jac]) if d_jac is not None else None
         check(lib().gel_eval_aero_all_device(self._h, B, d_x, cp, jp, stream or None))
 
+    def eval_callback(self, x, want_jac):
+        """ONE device round trip for one decision vector: the four defect groups, the row table (if configured) and the aero
+        kinds (if configured), values only or values + derivatives.  -> dict of the engine's own output arrays (overwritten
+        by the next call): res, vals (full COO values) | None, rows_con, rows_jfn | None, aero_con {kind}, aero_jac {kind} |
+        None, rc."""
+        x = _f64(x)
+        assert x.size == self.nvars
+        key = bool(want_jac)
+        slot = self.__dict__.setdefault("_cb_out", {}).get(key)
+        if slot is None:
+            io = GelCallbackIO()
+            out = {"res": np.empty(self.nres), "vals": None, "rows_con": None, "rows_jfn": None, "aero_con": {}, "aero_jac": {}}
+            io.res = _d(out["res"])
+            if want_jac:
+                if self._vals is None:
+                    self._vals = self.const_values()          # constants once; x-dependent entries rewritten per call
+                out["vals"] = self._vals
+                io.vals_full, io.fill_constants = _d(self._vals), 0
+            if self._nlin + self._nfn:
+                out["rows_con"] = np.empty(self._nlin + self._nfn)
+                io.rows_con = _d(out["rows_con"])
+                if want_jac:
+                    out["rows_jfn"] = np.empty((max(self._nfn, 1), 6))
+                    io.rows_jfn = _d(out["rows_jfn"])
+            for i, kind in enumerate(self.AERO_KINDS):
+                nrow, nnz = self.aero_dims(kind)
+                if nrow:
+                    out["aero_con"][kind] = np.empty(nrow)
+                    io.aero_con[i] = _d(out["aero_con"][kind])
+                    if want_jac:
+                        out["aero_jac"][kind] = np.empty(sum(nnz))
+                        io.aero_jac[i] = _d(out["aero_jac"][kind])
+            slot = (io, out)
+            self._cb_out[key] = slot
+        io, out = slot
+        out["rc"] = check(lib().gel_eval_callback(self._h, _d(x), C.byref(io)))
+        if out["rows_jfn"] is not None:
+            out["rows_jfn"] = out["rows_jfn"][:self._nfn]
+        return out
+
     def initial_guess(self, t_ref, table, knot_times):
         """initialize.py:322-409 behind the C-ABI: reference trajectory (t_ref [n], table [n, 13] = mass | pos 3 | vel 3 |
         quat 4 | body rates y, z) interpolated at the mesh's node times -> packed decision vector"""
@@ -379,6 +422,8 @@ class Engine:
             fn[k] = GelNodefnRow(int(self.NODE_FUNCTIONS.get(f, f)), int(node), float(p0), float(p1))
         check(lib().gel_rows_configure(self._h, len(linear), lin, len(nodefn), fn))
         self._nlin, self._nfn = len(linear), len(nodefn)
+        self._cb_out = {}
+        self._cfg_gen = getattr(self, "_cfg_gen", 0) + 1
 
     def rows_eval(self, X, want_jac=True):
         """X [B, nvars] (or [nvars]) -> (con [B, nlin + nfn], jfn [B, nfn, 6] | None, status)"""

@@ -170,3 +170,57 @@ def test_callbacks_carry_every_row_group_and_a_sticky_status():
         assert con_dynamics.last_status(pdict) == 0
     finally:
         con_user.set_user_module(None)
+
+
+def test_one_round_trip_callback_equals_the_separate_calls():
+    """gel_eval_callback: defect groups + row table + aero kinds of one decision vector, launched back to back, one
+    synchronise -- every output bit for bit what the separate entry points return; configuring a kind or the row
+    table afterwards invalidates the shared frame of the Python mirrors."""
+    from gelato_amd import con_aero, con_dynamics, pack_x
+    from gelato_amd import con_init_terminal_knot as ck
+    pdict, unitdict, condition, xdict = example({"inclination": 51.6})
+    cond = dict(condition, AOA_max={"KICKTURN": {"value": 10.0, "range": "all"}}, dynamic_pressure_max={},
+                Q_alpha_max={"ZEROLIFT_START": {"value": 30000.0, "range": "all"}, "ZEROLIFT_END": {"value": 2.0e4, "range": "initial"}})
+    E = con_dynamics.engine_of(pdict, unitdict)
+    R = ck.rows_of(pdict, unitdict, cond)
+    for kind in ("alpha", "q", "qalpha"):
+        con_aero._configured(pdict, unitdict, cond, kind)
+    x = pack_x(xdict) * (1.0 + 1e-6)
+    for want_jac in (False, True):
+        fr = E.eval_callback(x, want_jac)
+        assert fr["rc"] == 0
+        res, vals, _ = E.eval(x)
+        assert np.array_equal(fr["res"], res)
+        rc_, rj_, _ = E.rows_eval(x, want_jac=True)
+        assert np.array_equal(fr["rows_con"], rc_[0])
+        ac, aj, _ = E.eval_aero_all(x, want_jac=True)
+        assert sorted(fr["aero_con"]) == ["alpha", "qalpha"]
+        for kind in fr["aero_con"]:
+            assert np.array_equal(fr["aero_con"][kind], ac[kind][0])
+        if want_jac:
+            assert np.array_equal(fr["vals"], vals) and np.array_equal(fr["rows_jfn"], rj_[0])
+            for kind in fr["aero_jac"]:
+                assert np.array_equal(fr["aero_jac"][kind], aj[kind][0])
+        else:
+            assert fr["vals"] is None and fr["rows_jfn"] is None and not fr["aero_jac"]
+    # through the reference-named functions: one frame per xdict, shared by the three modules
+    xd = {k: np.ascontiguousarray(v) for k, v in E.split_x(x).items()}
+    st = con_dynamics._state(pdict, unitdict)
+    a = con_dynamics.equality_dynamics_velocity(xd, pdict, unitdict, cond)
+    f1 = st._frame
+    b = ck.equality_knot_LGR(xd, pdict, unitdict, cond)
+    c = con_aero.inequality_max_qalpha(xd, pdict, unitdict, cond)
+    assert st._frame is f1 and not f1["jac"]                       # values: one evaluation for all three modules
+    assert np.array_equal(a, E.split_res(res)["vel"]) and np.array_equal(b, rc_[0][slice(*R.slices["knot"])])
+    assert np.array_equal(c, ac["qalpha"][0])
+    J = ck.equality_jac_6DoF_LGR_terminal(xd, pdict, unitdict, cond)
+    f2 = st._frame
+    assert f2 is not f1 and f2["jac"]                              # derivatives asked: one more evaluation, with them
+    con_dynamics.equality_jac_dynamics_quaternion(xd, pdict, unitdict, cond)
+    con_aero.inequality_jac_max_alpha(xd, pdict, unitdict, cond)
+    assert st._frame is f2 and J["position"]["coo"][2].shape == (9,)
+    # a reconfiguration invalidates the frame (same xdict, new limits)
+    cond2 = dict(cond, AOA_max={"KICKTURN": {"value": 5.0, "range": "all"}})
+    d = con_aero.inequality_max_alpha(xd, pdict, unitdict, cond2)
+    assert st._frame is not f2
+    assert np.allclose(1.0 - d, 2.0 * (1.0 - con_aero.inequality_max_alpha(xd, pdict, unitdict, cond)), rtol=1e-12)
