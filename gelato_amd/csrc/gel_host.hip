@@ -164,6 +164,12 @@ struct gel_problem {
   // re-used while x stays the same (the four groups are asked for one after the other)
   double *jfd_x = nullptr, *jfd_Xp = nullptr, *jfd_res = nullptr, *jfd_J = nullptr;
   size_t jfd_J_cap = 0;                                       // doubles
+  // every phase as its own one-phase problem (gel_jac_fd differences phase by phase)
+  gel::PhaseDev* d_subphases = nullptr;                       // [S] the phase records with ua = xa = 0
+  int4* d_subchunks = nullptr;                                // the phase-ordered work items with phase index 0
+  int32_t* d_colmap = nullptr;                                // per phase: local column -> global column
+  std::vector<int32_t> sub_chunk0, sub_nchunks, sub_col0;     // [S] first work item, work items, first colmap entry
+  std::vector<size_t> sub_res0;                               // [S] first double of the phase's residuals in jfd_res
   std::vector<double> jfd_last_x;                             // empty = nothing cached
   int jfd_status = GEL_OK;
   // knot / terminal / user rows (gel_rows_configure)
@@ -741,6 +747,34 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     gel_problem_destroy(p);
     return rc;
   }
+  {
+    // one-phase sub-problems for the phase-by-phase forward difference (gel_jac_fd)
+    std::vector<gel::PhaseDev> sub = dph;
+    std::vector<int4> subchunks = chunks;
+    std::vector<int32_t> colmap;
+    int c0 = 0;
+    for (int i = 0; i < S; i++) {
+      const HostPhase& h = p->ph[i];
+      sub[i].ua = 0; sub[i].xa = 0; sub[i].voff = 0;
+      p->sub_chunk0.push_back(c0);
+      int cnt = 0;
+      while (c0 + cnt < (int)chunks.size() && chunks[c0 + cnt].x == i) { subchunks[c0 + cnt].x = 0; cnt++; }
+      p->sub_nchunks.push_back(cnt);
+      c0 += cnt;
+      p->sub_col0.push_back((int32_t)colmap.size());
+      const int n = h.n;
+      for (int k = 0; k <= n; k++) colmap.push_back(h.xa + k);                                  // mass
+      for (int k = 0; k < 3 * (n + 1); k++) colmap.push_back(M + 3 * h.xa + k);                  // position
+      for (int k = 0; k < 3 * (n + 1); k++) colmap.push_back(4 * M + 3 * h.xa + k);              // velocity
+      for (int k = 0; k < 4 * (n + 1); k++) colmap.push_back(7 * M + 4 * h.xa + k);              // quaternion
+      for (int k = 0; k < 2 * n; k++) colmap.push_back(11 * M + 2 * h.ua + k);                   // u
+      colmap.push_back(11 * M + 2 * N + i); colmap.push_back(11 * M + 2 * N + i + 1);            // t0, tf
+    }
+    if ((rc = upload(&p->d_subphases, sub)) || (rc = upload(&p->d_subchunks, subchunks)) || (rc = upload(&p->d_colmap, colmap))) {
+      gel_problem_destroy(p);
+      return rc;
+    }
+  }
   if (hipMalloc((void**)&p->d_flag, 4) != hipSuccess || hipMemset(p->d_flag, 0, 4) != hipSuccess ||
       hipHostMalloc((void**)&p->h_flag, 4) != hipSuccess || hipStreamCreate(&p->stream) != hipSuccess) {
     gel_problem_destroy(p);
@@ -784,6 +818,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->h_rows) hipHostFree(p->h_rows);
   hipFree(p->d_lin_rows); hipFree(p->d_fn_rows); hipFree(p->d_rows_x); hipFree(p->d_rows_out);
   hipFree(p->jfd_x); hipFree(p->jfd_Xp); hipFree(p->jfd_res); hipFree(p->jfd_J);
+  hipFree(p->d_subphases); hipFree(p->d_subchunks); hipFree(p->d_colmap);
   delete p;
   return GEL_OK;
 }
@@ -989,12 +1024,25 @@ int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) {
   HIPCHK(hipSetDevice(p->device));
   int rc = ensure_slots(p);  // the two pinned staging slots also carry J back to the caller
   if (rc) return rc;
-  const size_t nv = (size_t)p->dims.num_vars, nres = (size_t)11 * p->dims.N, nrows = (size_t)p->dims.num_rows[group];
-  const int roff = (group == 0) ? 0 : (group == 1) ? p->dims.N : (group == 2) ? 4 * p->dims.N : 7 * p->dims.N;
+  const size_t nv = (size_t)p->dims.num_vars, nrows = (size_t)p->dims.num_rows[group];
+  const int S = p->dims.S;
+  // working set: x, the perturbed local vectors of the LARGEST phase (reused phase after phase), the residuals of every
+  // phase's perturbed vectors (kept while x stays the same: the four groups are asked for one after the other), dense J
   if (!p->jfd_x) {
-    HIPCHK(hipMalloc((void**)&p->jfd_x, nv * 8));
-    HIPCHK(hipMalloc((void**)&p->jfd_Xp, (nv + 1) * nv * 8));
-    HIPCHK(hipMalloc((void**)&p->jfd_res, (nv + 1) * nres * 8));
+    size_t xp_max = 0, res_tot = 0;
+    p->sub_res0.clear();
+    for (int i = 0; i < S; i++) {
+      const size_t n = p->ph[i].n, nloc = 13 * n + 13;
+      xp_max = std::max(xp_max, (nloc + 1) * nloc);
+      p->sub_res0.push_back(res_tot);
+      res_tot += (nloc + 1) * 11 * n;
+    }
+    if (hipMalloc((void**)&p->jfd_x, nv * 8) != hipSuccess || hipMalloc((void**)&p->jfd_Xp, xp_max * 8) != hipSuccess ||
+        hipMalloc((void**)&p->jfd_res, res_tot * 8) != hipSuccess) {
+      hipFree(p->jfd_x); hipFree(p->jfd_Xp); hipFree(p->jfd_res);
+      p->jfd_x = p->jfd_Xp = p->jfd_res = nullptr;   // all or nothing: a later call must not find a partial set
+      return fail(GEL_ERR_ALLOC, "gel_jac_fd: device allocation failed");
+    }
   }
   if (p->jfd_J_cap < nrows * nv) {
     hipFree(p->jfd_J);
@@ -1002,19 +1050,34 @@ int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) {
     HIPCHK(hipMalloc((void**)&p->jfd_J, nrows * nv * 8));
     p->jfd_J_cap = nrows * nv;
   }
-  // one residual evaluation per column, all columns in one launch -- unless the same x was just differenced
+  // one residual evaluation per (phase, local column) -- unless the same x was just differenced
   if (p->jfd_last_x.size() != nv || std::memcmp(p->jfd_last_x.data(), x, nv * 8) != 0) {
     p->jfd_last_x.clear();
     HIPCHK(hipMemcpyAsync(p->jfd_x, x, nv * 8, hipMemcpyHostToDevice, p->stream));
-    HIPCHK(gel::launch_perturb((int)nv, p->dx, p->jfd_x, p->jfd_Xp, p->stream));
-    HIPCHK(gel::launch_eval(p->dev, (int)nv + 1, p->jfd_Xp, p->jfd_res, nullptr, p->stream));
+    for (int i = 0; i < S; i++) {
+      const int n = p->ph[i].n, nloc = 13 * n + 13;
+      gel::ProblemDev dv = p->dev;   // the phase as a one-phase problem: same tables, D, tau; local index space
+      dv.S = 1; dv.N = n; dv.M = n + 1; dv.nvars = nloc; dv.V = 0;
+      dv.phases = p->d_subphases + i;
+      dv.chunks = p->d_subchunks + p->sub_chunk0[i]; dv.nchunks = p->sub_nchunks[i]; dv.chunk0 = 0;
+      HIPCHK(gel::launch_perturb_local(nloc, p->dx, p->jfd_x, p->d_colmap + p->sub_col0[i], p->jfd_Xp, p->stream));
+      HIPCHK(gel::launch_eval(dv, nloc + 1, p->jfd_Xp, p->jfd_res + p->sub_res0[i], nullptr, p->stream));
+    }
     HIPCHK(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     p->jfd_status = GEL_OK;
     if (*p->h_flag) { *p->h_flag = 0; HIPCHK(hipMemsetAsync(p->d_flag, 0, 4, p->stream)); p->jfd_status = GEL_NONFINITE; }
     p->jfd_last_x.assign(x, x + nv);
   }
-  HIPCHK(gel::launch_quotient((int)nv, (int)nres, roff, (int)nrows, p->dx, p->jfd_res, p->jfd_J, p->stream));
+  // dense J of the group: zeros, then every phase's block of quotients at its rows and (mapped) columns
+  HIPCHK(hipMemsetAsync(p->jfd_J, 0, nrows * nv * 8, p->stream));
+  const int w = (group == 0) ? 1 : (group == 3) ? 4 : 3;                 // rows per node of the group
+  for (int i = 0; i < S; i++) {
+    const int n = p->ph[i].n, nloc = 13 * n + 13;
+    const int roff_loc = (group == 0) ? 0 : (group == 1) ? n : (group == 2) ? 4 * n : 7 * n;
+    HIPCHK(gel::launch_quotient_local(nloc, 11 * n, roff_loc, w * n, p->dx, p->jfd_res + p->sub_res0[i], p->jfd_J,
+                                      (long long)nv, w * p->ph[i].ua, p->d_colmap + p->sub_col0[i], p->stream));
+  }
   HIPCHK(hipStreamSynchronize(p->stream));
   // J -> caller through the two pinned slots: D2H of piece i+1 overlaps the host copy of piece i
   const size_t total = nrows * nv, piece = (size_t)p->pipe_evals * (size_t)std::max<int64_t>(p->dims.num_var_entries, 1);

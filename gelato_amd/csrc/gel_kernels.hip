@@ -91,32 +91,39 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(long long nnz, long long
 }
 
 // ---------------------------------------------------------------------------
-// generic column-batched forward difference (lib/jac_fd.py:29-62)
+// generic column-batched forward difference (lib/jac_fd.py:29-62) of the four defect residuals, PHASE BY PHASE.
+// The residual rows of a phase depend only on the 13 n + 13 columns of that phase (its state and control nodes and its
+// two knot times; lib/con_dynamics.py:46,132,237,512 are loops over phases with no cross-phase data): every other
+// column gives bit-identical residual rows, i.e. an exact zero in the reference's dense Jacobian.  So each phase is
+// differenced as its own one-phase problem: its local decision vector [mass n+1 | pos 3(n+1) | vel 3(n+1) | quat 4(n+1)
+// | u 2n | t0 tf] is gathered from x (colmap: local column -> global column), the 13 n + 14 perturbed copies are
+// formed, one residual-only launch evaluates them, and the quotients go straight to their rows and columns of the
+// dense Jacobian.  No (num_vars + 1) x num_vars copy of x is ever built.
 // ---------------------------------------------------------------------------
-// Xp[0] = x; Xp[i+1] = x with element i += dx
-__global__ void perturb_kernel(int nvars, double dx, const double* __restrict__ x, double* __restrict__ Xp) {
+// Xp[0] = gathered local x; Xp[c + 1] = the same with local column c += dx
+__global__ void perturb_local_kernel(int nloc, double dx, const double* __restrict__ x, const int32_t* __restrict__ colmap,
+                                     double* __restrict__ Xp) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long tot = (long long)(nvars + 1) * nvars;
-  if (t >= tot) return;
-  const int row = (int)(t / nvars), col = (int)(t - (long long)row * nvars);
-  double v = x[col];
+  if (t >= (long long)(nloc + 1) * nloc) return;
+  const int row = (int)(t / nloc), col = (int)(t - (long long)row * nloc);
+  double v = x[colmap[col]];
   if (row == col + 1) v += dx;
   Xp[t] = v;
 }
 
-// J[r][i] = (res[i+1][roff + r] - res[0][roff + r]) / dx       (tiled transpose through LDS)
-__global__ void quotient_kernel(int nvars, int nres, int roff, int nrows, double dx, const double* __restrict__ res,
-                                double* __restrict__ J) {
+// J[(row0 + r) * ldJ + colmap[c]] = (res[c + 1][roff + r] - res[0][roff + r]) / dx     (tiled transpose through LDS)
+__global__ void quotient_local_kernel(int nloc, int nres, int roff, int nrows, double dx, const double* __restrict__ res,
+                                      double* __restrict__ J, long long ldJ, int row0, const int32_t* __restrict__ colmap) {
   __shared__ double tile[32][33];
-  const int i0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   for (int k = threadIdx.y; k < 32; k += blockDim.y) {  // read: r fast
-    const int i = i0 + k, r = r0 + threadIdx.x;
-    if (i < nvars && r < nrows) tile[k][threadIdx.x] = res[(size_t)(i + 1) * nres + roff + r];
+    const int c = c0 + k, r = r0 + threadIdx.x;
+    if (c < nloc && r < nrows) tile[k][threadIdx.x] = res[(size_t)(c + 1) * nres + roff + r];
   }
   __syncthreads();
-  for (int k = threadIdx.y; k < 32; k += blockDim.y) {  // write: i fast
-    const int r = r0 + k, i = i0 + threadIdx.x;
-    if (i < nvars && r < nrows) __builtin_nontemporal_store((tile[threadIdx.x][k] - res[roff + r]) / dx, &J[(size_t)r * nvars + i]);
+  for (int k = threadIdx.y; k < 32; k += blockDim.y) {  // write: column fast (local columns of one variable are contiguous globally)
+    const int r = r0 + k, c = c0 + threadIdx.x;
+    if (c < nloc && r < nrows) J[(size_t)(row0 + r) * ldJ + colmap[c]] = (tile[threadIdx.x][k] - res[roff + r]) / dx;
   }
 }
 
@@ -580,16 +587,16 @@ hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, 
   return hipGetLastError();
 }
 
-hipError_t launch_perturb(int nvars, double dx, const double* d_x, double* d_Xp, hipStream_t s) {
-  const long long tot = (long long)(nvars + 1) * nvars;
-  hipLaunchKernelGGL(perturb_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, nvars, dx, d_x, d_Xp);
+hipError_t launch_perturb_local(int nloc, double dx, const double* d_x, const int32_t* d_colmap, double* d_Xp, hipStream_t s) {
+  const long long tot = (long long)(nloc + 1) * nloc;
+  hipLaunchKernelGGL(perturb_local_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, nloc, dx, d_x, d_colmap, d_Xp);
   return hipGetLastError();
 }
 
-hipError_t launch_quotient(int nvars, int nres, int roff, int nrows, double dx, const double* d_res, double* d_J,
-                           hipStream_t s) {
-  dim3 grid((nvars + 31) / 32, (nrows + 31) / 32);
-  hipLaunchKernelGGL(quotient_kernel, grid, dim3(32, 8), 0, s, nvars, nres, roff, nrows, dx, d_res, d_J);
+hipError_t launch_quotient_local(int nloc, int nres, int roff, int nrows, double dx, const double* d_res, double* d_J,
+                                 long long ldJ, int row0, const int32_t* d_colmap, hipStream_t s) {
+  dim3 grid((nloc + 31) / 32, (nrows + 31) / 32);
+  hipLaunchKernelGGL(quotient_local_kernel, grid, dim3(32, 8), 0, s, nloc, nres, roff, nrows, dx, d_res, d_J, ldJ, row0, d_colmap);
   return hipGetLastError();
 }
 
