@@ -392,6 +392,8 @@ void par_copy(void* dst, const void* src, size_t bytes) {
   for (auto& t : th) t.join();
 }
 
+void free_slots(gel_problem* p);
+
 int ensure_slots(gel_problem* p) {
   NEED_DEVICE(p);
   if (p->pipe_evals) return GEL_OK;
@@ -400,16 +402,15 @@ int ensure_slots(gel_problem* p) {
   const int cap = (int)std::max<size_t>(1, kPipeBytes / per_eval);
   const size_t nx = (size_t)cap * p->dims.num_vars, nr = (size_t)cap * 11 * p->dims.N, nj = (size_t)cap * std::max<int64_t>(1, p->dims.num_var_entries);
   for (auto& sl : p->slot) {
-    HIPCHK(hipMalloc((void**)&sl.d_x, nx * 8));
-    HIPCHK(hipMalloc((void**)&sl.d_res, nr * 8));
-    HIPCHK(hipMalloc((void**)&sl.d_jv, nj * 8));
-    HIPCHK(hipMalloc((void**)&sl.d_flag, 4));
-    HIPCHK(hipMemset(sl.d_flag, 0, 4));
-    HIPCHK(hipHostMalloc((void**)&sl.h_x, nx * 8));
-    HIPCHK(hipHostMalloc((void**)&sl.h_res, nr * 8));
-    HIPCHK(hipHostMalloc((void**)&sl.h_jv, nj * 8));
-    HIPCHK(hipHostMalloc((void**)&sl.h_flag, 4));
-    HIPCHK(hipStreamCreate(&sl.stream));
+    const bool ok = hipMalloc((void**)&sl.d_x, nx * 8) == hipSuccess && hipMalloc((void**)&sl.d_res, nr * 8) == hipSuccess &&
+                    hipMalloc((void**)&sl.d_jv, nj * 8) == hipSuccess && hipMalloc((void**)&sl.d_flag, 4) == hipSuccess &&
+                    hipMemset(sl.d_flag, 0, 4) == hipSuccess && hipHostMalloc((void**)&sl.h_x, nx * 8) == hipSuccess &&
+                    hipHostMalloc((void**)&sl.h_res, nr * 8) == hipSuccess && hipHostMalloc((void**)&sl.h_jv, nj * 8) == hipSuccess &&
+                    hipHostMalloc((void**)&sl.h_flag, 4) == hipSuccess && hipStreamCreate(&sl.stream) == hipSuccess;
+    if (!ok) {
+      free_slots(p);   // nothing half-allocated survives: the next call starts from scratch instead of leaking
+      return fail(GEL_ERR_ALLOC, "staging slots: allocation failed");
+    }
     *sl.h_flag = 0;
     sl.count = 0;
   }

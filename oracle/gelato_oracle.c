@@ -16,6 +16,7 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+#endif
 
 /* Per-thread scratch for the dense sub-matrices of the velocity / quaternion Jacobians (300-530 KB at n = 64):
  * allocated once per thread and kept.  Fresh malloc()s of that size are mmap()ed and page-faulted on every
@@ -30,7 +31,6 @@ static double* tls_buf(int slot, size_t n) {
   }
   return buf[slot];
 }
-#endif
 
 /* ------------------------------------------------------------------ */
 /* constants: src/Earth.cpp:41-47                                      */

@@ -156,6 +156,99 @@ def test_rhs_functions_vs_golden_and_oracle():
     close(np.concatenate(rq), g["rhs_quat"], atol=1e-16, what="dynamics_quaternion vs golden")
 
 
+def test_parity_corners_underground_polar_and_air_at_rest():
+    """Corners the synthetic trajectories never visit, GPU against the oracle (which follows the C++ sources):
+    a node below the polar radius (the r < b clamp of src/gravity.cpp:45-47, a branch the Python twin lacks), a node
+    exactly on the polar axis (p = 0: the reference's atan2(0, 0) = 0 longitude, finite everywhere), and a vehicle at
+    rest in the air (air-relative speed exactly 0 -> Mach 0, the x == xp[0] corner of interp)."""
+    oracle = _setup()
+    from gelato_amd import dynamics
+    from gelato_amd.dynamics import point_eval
+    g = load_golden("g2_g5_pointwise.npz")
+    prob = problem_from_golden(g)
+    W, CA = prob["wind_table"], prob["ca_table"]
+    units = prob["units"][:3]
+    Rb = 6378137.0 * (1.0 - 1.0 / 298.257223563)
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((64, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    radii = np.concatenate([np.linspace(0.3, 0.999, 40), [1.0, 1.0 + 1e-12, 1.0001, 1.1] * 6]) * Rb
+    pos = d * radii[:, None]
+    got = point_eval(2, pos, aux=np.array([oracle.BARC20_CPP]))
+    ref = np.array([oracle.gravity(p, oracle.BARC20_CPP) for p in pos])
+    close(got, ref, what="gravity with nodes below the polar radius")
+    inside = radii < Rb
+    # under ground the magnitude no longer grows with 1/r^2: the clamp holds the radial scale at r = b
+    assert np.all(np.linalg.norm(got[inside], axis=1) < 1.02 * 3.986004418e14 / Rb ** 2)
+    # RHS at an underground node, on the polar axis (north and south), and at rest in the air (zero wind table, v = omega x r)
+    W0 = W.copy()
+    W0[:, 1:] = 0.0
+    omega = 7.2921151467e-5
+    r_rest = np.array([[4.2e6, 3.9e6, 2.9e6], [-5.0e6, 1.0e6, 4.0e6]]) * 1.02
+    v_rest = np.column_stack([-(omega * r_rest[:, 1]), omega * r_rest[:, 0], np.zeros(2)])
+    cases = {
+        "underground": (pos[:8] * 1.0, rng.standard_normal((8, 3)) * 300.0, W),
+        "polar": (np.array([[0.0, 0.0, 6.45e6], [0.0, 0.0, -6.5e6], [0.0, 0.0, 6.36e6]]), rng.standard_normal((3, 3)) * 500.0, W),
+        "at rest": (r_rest, v_rest, W0),
+    }
+    param = np.array([4.2e5, 140.0, 2.21, 0.0, 0.68])
+    for name, (r, v, wt) in cases.items():
+        n = len(r)
+        m = np.full(n, 0.7)
+        q = rng.standard_normal((n, 4))
+        q /= np.linalg.norm(q, axis=1)[:, None]
+        t = np.linspace(0.0, 0.9, n)
+        a_gpu = dynamics.dynamics_velocity(m, r / units[1], v / units[2], q, t, param, wt, CA, units)
+        a_ref = oracle.dynamics_velocity(m, r / units[1], v / units[2], q, t, param, wt, CA, units)
+        assert np.all(np.isfinite(a_gpu)), name
+        close(a_gpu, a_ref, rtol=1e-9, atol=1e-11, what="RHS corner: " + name)
+    # at rest in the air the aerodynamic force is exactly zero: the same acceleration as a phase without aerodynamics
+    n = len(r_rest)
+    m = np.full(n, 0.7)
+    q = np.tile([0.5, 0.5, -0.5, 0.5], (n, 1))
+    a_air = dynamics.dynamics_velocity(m, r_rest / units[1], v_rest / units[2], q, np.zeros(n), np.array([4.2e5, 140.0, 2.21, 0.0, 0.0]),
+                                       W0, CA, units)
+    a_no = dynamics.dynamics_velocity_NoAir(m, r_rest / units[1], q, np.array([4.2e5, 140.0, 0.0, 0.0, 0.0]), units)
+    close(a_air, a_no, rtol=1e-13, atol=1e-15, what="zero air-relative speed: no aerodynamic force")
+
+
+def test_engine_generated_lgr_on_the_device_vs_reference_golden():
+    """The engine's OWN nodes and differentiation matrices (gel_lgr_nodes / gel_lgr_diffmat, Newton + barycentric
+    weights on the host) on the device, against the reference's residuals and Jacobians of the example problem, whose
+    D came from the reference's lib/PSfunctions.py.  D differs by <= 1e-11 of a row maximum (G1), so the residuals carry
+    that times sum |X|; the x-dependent Jacobian entries do not see D at all except through D[j][j+1]."""
+    oracle = _setup()
+    from gelato_amd import Engine
+    g = load_golden("g6_example.npz")
+    prob = problem_from_golden(g)
+    Dg, taug = D_tau_from_golden(g, prob)
+    E = Engine(prob, barC20=TW)                        # no D / tau handed over: the engine generates them
+    for i, (Dr, tr) in enumerate(zip(Dg, taug)):
+        assert np.max(np.abs(E.D(i) - Dr)) <= 1e-11 * np.max(np.abs(Dr)) and np.max(np.abs(E.tau(i) - tr)) <= 1e-14
+    x = g["x"]
+    res, vals, rc = E.eval(x)
+    assert rc == 0
+    R, J = E.split_res(res), E.jac_dicts(vals)
+    X = E.split_x(x)
+    scale = {"mass": np.abs(X["mass"]).max(), "pos": np.abs(X["position"]).max(), "vel": np.abs(X["velocity"]).max(),
+             "quat": np.abs(X["quaternion"]).max()}
+    vm = E.var_mask()
+    b = 0
+    for grp in oracle.GROUPS:
+        n_max = int(max(prob["num_nodes"]))
+        tol = 1e-11 * max(np.max(np.abs(d)) for d in Dg) * (n_max + 1) * scale[grp]
+        assert np.all(np.abs(R[grp] - g["res_" + grp]) <= 1e-12 + 1e-10 * np.abs(g["res_" + grp]) + tol), grp
+        for var in oracle.BLOCK_VARS[grp]:
+            key = "jac_%s_%s" % (grp, var)
+            r, c, v = J[grp][var]["coo"]
+            assert np.array_equal(r, g[key + "_rows"]) and np.array_equal(c, g[key + "_cols"])
+            m = vm[E.block_off[b]:E.block_off[b + 1]]
+            ref = g[key + "_vals"]
+            assert np.all(np.abs(v[m] - ref[m]) <= 1e-5 + 1e-6 * np.abs(ref[m])), key
+            assert np.all(np.abs(v[~m] - ref[~m]) <= 1e-11 * (1.0 + np.max(np.abs(ref)))), key     # D entries, +-1, 0
+            b += 1
+
+
 def test_rhs_shape_errors_like_pybind():
     from gelato_amd import dynamics
     with pytest.raises(TypeError):
@@ -194,7 +287,7 @@ def check_against_oracle(E, P, x, what):
     return res, vals
 
 
-@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64", "dense6x64"])
+@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64", "dense6x64", "negarea"])
 def test_residuals_jacobians_vs_golden_and_oracle(name):
     oracle = _setup()
     g = load_golden("g6_%s.npz" % name)

@@ -147,7 +147,7 @@ def _variable_mask(P, prob, group, var, rows, cols):
     return np.ones(len(rows), dtype=bool)
 
 
-@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64", "dense6x64"])
+@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64", "dense6x64", "negarea"])
 @pytest.mark.parametrize("own_lgr", [False, True])
 def test_g6_residuals_and_jacobians(name, own_lgr):
     g = load_golden("g6_%s.npz" % name)

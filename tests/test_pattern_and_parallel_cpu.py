@@ -27,7 +27,7 @@ def host_engine(prob, D=None, tau=None):
     return Engine(prob, D=D, tau=tau, device=-1)
 
 
-@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64", "dense6x64"])
+@pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64", "dense6x64", "negarea"])
 def test_pattern_bit_exact_vs_reference_golden(name):
     g = load_golden("g6_%s.npz" % name)
     prob = problem_from_golden(g)
