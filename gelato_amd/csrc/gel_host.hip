@@ -789,12 +789,15 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks_sorted; dv.Dsw = p->d_Dsw; dv.Dst = p->d_Dst;
   dv.park_off = (int32_t)((tables.size() + 1) / 2 * 2);
   {
-    // D.X path: the matrix pipe runs beside the fp64 VALU pipe that bounds this kernel, so the MFMA form
-    // is the default; GEL_FLAG_DX_VALU forces the wavefront dot-product form (kept for n < 16 phases,
-    // where a 16-row tile is mostly padding, and for A/B measurements)
+    // D.X path.  fp64 MFMA and fp64 VALU instructions share the SIMD's fp64 datapath on this part (measured: their busy
+    // times add up), so the matrix pipe is not free throughput; what it buys is fewer issue slots and the
+    // cooperative form (four decision vectors side by side, 44 of 48 tile columns used, a quarter of the D traffic).  It
+    // wins from 32 nodes per phase on and loses below, where a 16-row tile is mostly padding (same-box A/B, evals/s at
+    // B = 32768, MFMA vs VALU: 3x8 51.8 M vs 53.0 M, 3x16 48.5 M vs 49.1 M, 3x32 41.6 M vs 40.1 M, 6x64 13.9 M vs 12.7 M;
+    // residual-only 3x32 97.7 M vs 91.3 M, 6x64 31.3 M vs 21.4 M; tools/dx_paths.sh).  GEL_FLAG_DX_VALU / _MFMA force a path.
     int nmax = 0;
     for (int i = 0; i < S; i++) nmax = std::max(nmax, p->ph[i].n);
-    dv.use_mfma = (d->flags & GEL_FLAG_DX_VALU) ? 0 : ((d->flags & GEL_FLAG_DX_MFMA) ? 1 : (nmax >= 16));
+    dv.use_mfma = (d->flags & GEL_FLAG_DX_VALU) ? 0 : ((d->flags & GEL_FLAG_DX_MFMA) ? 1 : (nmax >= 32));
   }
   dv.um = p->um; dv.up = p->up; dv.uv = p->uv; dv.uu = p->uu; dv.ut = p->ut; dv.dx = p->dx; dv.barC20 = p->barC20;
   *out = p;

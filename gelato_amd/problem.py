@@ -19,6 +19,9 @@ _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "exampl
 CONFIGS = {
     # config 2: 3 phases x 32
     "3x32": (["KICKTURN", "ZEROLIFT_START", "SEIG", "SIMEND"], [0.0, 20.0, 169.0, 597.0], [32] * 3),
+    # the same three phases with 16 / 8 nodes: where the 16-row matrix-pipe tile of D.X is mostly padding
+    "3x16": (["KICKTURN", "ZEROLIFT_START", "SEIG", "SIMEND"], [0.0, 20.0, 169.0, 597.0], [16] * 3),
+    "3x8": (["KICKTURN", "ZEROLIFT_START", "SEIG", "SIMEND"], [0.0, 20.0, 169.0, 597.0], [8] * 3),
     # config 3: the 6-phase multi-stage vehicle, 64 nodes per phase; exercises every branch
     "mixed-6x64": (["LIFTOFF", "KICKTURN", "ZEROLIFT_START", "ZEROLIFT_END", "MECO", "SEIG", "SIMEND"],
                    [0.0, 10.0, 20.0, 90.0, 169.0, 179.0, 597.0], [64] * 6),
