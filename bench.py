@@ -285,7 +285,12 @@ def main():
                            "kernel": kname, "kernel_ms": kern_ms,
                            "frac_cold": abytes / (kern_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_cold": kern_ms_cold,
                            "algorithmic_bytes_per_eval": a_min, "algorithmic_bytes_per_launch": abytes,
-                           "note": "fp64-VALU-bound, not HBM-bound (libm chains of the RHS sweeps); see DESIGN.md 3.1"}
+                           # what one eval actually writes (residual + the DISTINCT x-dependent values; the gather map
+                           # restores negated / shared / structurally constant entries) -- `achieved` uses SURVEY 8(d)'s
+                           # A_min as the contract prescribes, `traffic` shows the bytes that really moved
+                           "stored_bytes_per_eval": 8 * E.nres if a.residual_only else E.stored_bytes,
+                           "note": "bound by the fp64 pipe (VALU + MFMA share it) and by the clock the chip holds under the "
+                                   "store stream, not by HBM bandwidth; see DESIGN.md 3.1"}
     else:
         out["shard"] = {"step_ms": kern_ms, "step_ms_cold": kern_ms_cold,
                         "units_per_rank": [c for _, c in shards.ranges],

@@ -1,0 +1,8 @@
+#!/bin/bash
+# every BASELINE config on the record (bench line + rocprofv3 kernel stats + PMC traffic): tools/record_all.sh <tag>
+TAG=${1:-r02}
+cd $GRAFT_REPO_ROOT
+tools/gpu_record.sh $TAG/mixed
+tools/gpu_record.sh $TAG/dense --workload dense-6x64
+tools/gpu_record.sh $TAG/stress --workload stress-12x128 --batch 4096
+tools/gpu_record.sh $TAG/3x32res --workload 3x32 --residual-only --batch 65536
