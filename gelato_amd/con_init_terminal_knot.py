@@ -53,7 +53,8 @@ class _Rows:
         eng = con_dynamics.engine_of(pdict, unitdict)
         S, M = pdict["num_sections"], pdict["M"]
         ps, P, ev = pdict["ps_params"], pdict["params"], pdict["event_index"]
-        o = {k: eng.var_offset(k) for k in ("mass", "position", "velocity", "quaternion", "t")}
+        o = {k: eng.var_offset(k) for k in ("mass", "position", "velocity", "quaternion", "u", "t")}
+        N = pdict["N"]
         xa = [ps.index_start_x(i) for i in range(S)]
         lin = []            # (idx0, coef0, idx1, coef1, c0): (coef0 x[idx0] + coef1 x[idx1]) + c0
         self.slices = {}
@@ -138,6 +139,66 @@ class _Rows:
                 rows += [r, r]; cols += [i, i + 1]; vals += [-1.0, 1.0]
         self.slices["tineq"] = (k0, len(lin))
         self.jac["tineq"] = {"t": _coo(rows, cols, vals, (len(lin) - k0, S + 1))}
+
+        # ---- lib/con_trajectory.py, more rows of the same kind ----
+        # inequality_mass (con_trajectory.py:33-60): a stage cannot burn more than its propellant; Jacobian :63-103
+        k0 = len(lin)
+        rows, cols, vals = [], [], []
+        for stage in pdict["RocketStage"].values():
+            if stage.get("ignition_at") in ev and stage.get("cutoff_at") in ev:
+                ig, co = xa[ev[stage["ignition_at"]]], xa[ev[stage["cutoff_at"]]]
+                d_mass = stage["mass_propellant"] + sum(it["mass"] for it in (stage["dropMass"] or {}).values())
+                r = len(lin) - k0
+                lin.append((o["mass"] + ig, -1.0, o["mass"] + co, 1.0, d_mass / unitdict["mass"]))
+                rows += [r, r]; cols += [ig, co]; vals += [-1.0, 1.0]
+        self.slices["imass"] = (k0, len(lin))
+        self.jac["imass"] = {"mass": _coo(rows, cols, vals, (len(lin) - k0, M))}
+        # inequality_kickturn (:106-125): the pitch rate of a kick-turn section is not positive; Jacobian :128-160
+        k0 = len(lin)
+        rows, cols, vals = [], [], []
+        uu = unitdict["u"]
+        for i in range(S - 1):
+            if "kick" in P[i]["attitude"]:
+                ua_, n = ps.index_start_u(i), ps.nodes(i)
+                r = len(lin) - k0
+                for k in range(n):
+                    lin.append((o["u"] + 2 * (ua_ + k), -uu, -1, 0.0, 0.0))
+                rows += list(range(r, r + n)); cols += list(range(2 * ua_, 2 * (ua_ + n), 2)); vals += [-uu] * n
+        self.slices["kick"] = (k0, len(lin))
+        self.jac["kick"] = {"u": _coo(rows, cols, vals, (len(lin) - k0, 2 * N))}
+        # equality_6DoF_rate (:163-213): the body-rate pattern of every attitude option; Jacobian :255-347 (per block the
+        # -1 entries of the reference column first, then the +1 entries)
+        k0 = len(lin)
+        rows, cols, vals = [], [], []
+
+        def rate_block(plus_cols, minus_col):
+            r = len(lin) - k0
+            cnt = len(plus_cols)
+            for pc in plus_cols:
+                lin.append((o["u"] + pc, 1.0, -1 if minus_col is None else o["u"] + minus_col,
+                            0.0 if minus_col is None else -1.0, 0.0))
+            rr = list(range(r, r + cnt))
+            if minus_col is not None:
+                rows.extend(rr); cols.extend([minus_col] * cnt); vals.extend([-1.0] * cnt)
+            rows.extend(rr); cols.extend(plus_cols); vals.extend([1.0] * cnt)
+
+        for i in range(S):
+            a, n, att = ps.index_start_u(i), ps.nodes(i), P[i]["attitude"]
+            if att in ("hold", "vertical"):
+                rate_block(list(range(2 * a, 2 * (a + n))), None)
+            elif att in ("kick-turn", "pitch"):
+                rate_block(list(range(2 * (a + 1), 2 * (a + n), 2)), 2 * a)
+                rate_block(list(range(2 * a + 1, 2 * (a + n) + 1, 2)), None)
+            elif att == "pitch-yaw":
+                rate_block(list(range(2 * (a + 1), 2 * (a + n), 2)), 2 * a)
+                rate_block(list(range(2 * (a + 1) + 1, 2 * (a + n) + 1, 2)), 2 * a + 1)
+            elif att == "same-rate":
+                rate_block(list(range(2 * a, 2 * (a + n), 2)), 2 * a - 2)
+                rate_block(list(range(2 * a + 1, 2 * (a + n) + 1, 2)), 2 * a - 1)
+            elif att not in ("zero-lift-turn", "free"):
+                raise ValueError("unknown attitude option %r" % att)      # the reference prints and exits (:209-211)
+        self.slices["rate"] = (k0, len(lin))
+        self.jac["rate"] = {"u": _coo(rows, cols, vals, (len(lin) - k0, 2 * N))}
 
         # ---- equality_6DoF_LGR_terminal (:329-375): energy, angular momentum (and inclination) of the LAST state node
         fn = []

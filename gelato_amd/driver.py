@@ -9,7 +9,7 @@ timers the reference prints (:511-517).
 """
 import time
 
-from . import con_aero, con_dynamics, con_user
+from . import con_aero, con_dynamics, con_trajectory, con_user
 from . import con_init_terminal_knot as con_a
 from .cost_gradient import cost_6DoF, cost_jac
 
@@ -32,7 +32,7 @@ def make_callbacks(pdict, unitdict, condition):
         # equality_knot_LGR looks up by name (lib/con_init_terminal_knot.py:192-203): no knot rows can be formed then
         ev = pdict["event_index"]
         rows = all(st["separation_at"] is None or (st["separation_at"] in ev and st["ignition_at"] in ev)
-                   for st in pdict["RocketStage"].values())
+                   for st in pdict["RocketStage"].values()) and all("attitude" in q for q in pdict["params"])
 
     def objfunc(xdict):
         con_dynamics.reset_status(pdict)         # the status is sticky over ALL device evaluations of this callback
@@ -45,6 +45,9 @@ def make_callbacks(pdict, unitdict, condition):
             funcs["eqcon_user"] = con_user.equality_user(xdict, pdict, unitdict, condition)
             funcs["ineqcon_time"] = con_a.inequality_time(xdict, pdict, unitdict, condition)
             funcs["ineqcon_user"] = con_user.inequality_user(xdict, pdict, unitdict, condition)
+            funcs["eqcon_rate"] = con_trajectory.equality_6DoF_rate(xdict, pdict, unitdict, condition)          # :217
+            funcs["ineqcon_mass"] = con_trajectory.inequality_mass(xdict, pdict, unitdict, condition)           # :228
+            funcs["ineqcon_kick"] = con_trajectory.inequality_kickturn(xdict, pdict, unitdict, condition)       # :229-231
         funcs["eqcon_dyn_mass"] = con_dynamics.equality_dynamics_mass(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_pos"] = con_dynamics.equality_dynamics_position(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_vel"] = con_dynamics.equality_dynamics_velocity(xdict, pdict, unitdict, condition)
@@ -66,6 +69,9 @@ def make_callbacks(pdict, unitdict, condition):
             fs["eqcon_user"] = con_user.equality_jac_user(xdict, pdict, unitdict, condition)
             fs["ineqcon_time"] = con_a.inequality_jac_time(xdict, pdict, unitdict, condition)
             fs["ineqcon_user"] = con_user.inequality_jac_user(xdict, pdict, unitdict, condition)
+            fs["eqcon_rate"] = con_trajectory.equality_jac_6DoF_rate(xdict, pdict, unitdict, condition)
+            fs["ineqcon_mass"] = con_trajectory.inequality_jac_mass(xdict, pdict, unitdict, condition)
+            fs["ineqcon_kick"] = con_trajectory.inequality_jac_kickturn(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_mass"] = con_dynamics.equality_jac_dynamics_mass(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_pos"] = con_dynamics.equality_jac_dynamics_position(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_vel"] = con_dynamics.equality_jac_dynamics_velocity(xdict, pdict, unitdict, condition)

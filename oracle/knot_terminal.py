@@ -39,6 +39,12 @@ def make_spec(pdict, unitdict, condition):
         "time_ref": [ev[p["time_ref"]] if isinstance(p["time_ref"], str) and p["time_ref"] in ev else -1 for p in P],
         "mass_jettison": [p["mass_jettison"] for p in P],
         "stages": stages,
+        # lib/con_trajectory.py: ignition / cut-off sections and burnt mass of every stage; attitude option per section
+        "burns": [(ev[st["ignition_at"]], ev[st["cutoff_at"]],
+                   st["mass_propellant"] + sum(it["mass"] for it in (st["dropMass"] or {}).values()))
+                  for st in pdict["RocketStage"].values()],
+        "attitude": [p["attitude"] for p in P],
+        "ua": [ps.index_start_u(i) for i in range(S)],
         "units": {k: float(unitdict[k]) for k in ("mass", "position", "velocity", "u", "t")},
         "dx": float(pdict["dx"]),
         "payload_mode": condition["OptimizationMode"] == "Payload",
@@ -251,6 +257,90 @@ def inequality_jac_time(x, sp):
     for k, i in enumerate(_free_gaps(sp)):
         rows += [k, k]; cols += [i, i + 1]; vals += [-1.0, 1.0]
     return {"t": _coo(rows, cols, vals, (len(rows) // 2, sp["S"] + 1))}
+
+
+# ---------------------------------------------------------------- lib/con_trajectory.py (stage mass, kick turn, body rates)
+def inequality_mass(x, sp):                     # :33-60; Jacobian :63-103
+    m = split(x, sp["M"], sp["N"])[0]
+    return np.array([-m[sp["xa"][ig]] + m[sp["xa"][co]] + d / sp["units"]["mass"] for ig, co, d in sp["burns"]])
+
+
+def inequality_jac_mass(x, sp):
+    rows, cols, vals = [], [], []
+    for k, (ig, co, _) in enumerate(sp["burns"]):
+        rows += [k, k]; cols += [sp["xa"][ig], sp["xa"][co]]; vals += [-1.0, 1.0]
+    return {"mass": _coo(rows, cols, vals, (len(sp["burns"]), sp["M"]))}
+
+
+def _kick_sections(sp):
+    return [i for i in range(sp["S"] - 1) if "kick" in sp["attitude"][i]]
+
+
+def inequality_kickturn(x, sp):                 # :106-125; Jacobian :128-160
+    u = split(x, sp["M"], sp["N"])[4] * sp["units"]["u"]
+    parts = [-u[sp["ua"][i]:sp["ua"][i] + sp["nodes"][i], 0] for i in _kick_sections(sp)]
+    return np.concatenate(parts, axis=None) if parts else np.zeros(0)
+
+
+def inequality_jac_kickturn(x, sp):
+    rows, cols, vals = [], [], []
+    r = 0
+    for i in _kick_sections(sp):
+        a, n = sp["ua"][i], sp["nodes"][i]
+        rows += list(range(r, r + n)); cols += list(range(2 * a, 2 * (a + n), 2)); vals += [-sp["units"]["u"]] * n
+        r += n
+    return {"u": _coo(rows, cols, vals, (r, 2 * sp["N"]))}
+
+
+def _rate_rows(sp):
+    """(column of the +1 term, column of the -1 term or -1) of every row of equality_6DoF_rate, in its order (:163-213)"""
+    out = []
+    for i in range(sp["S"]):
+        a, n, att = sp["ua"][i], sp["nodes"][i], sp["attitude"][i]
+        if att in ("hold", "vertical"):                       # both rates zero, node by node
+            out += [(2 * a + k, -1) for k in range(2 * n)]
+        elif att in ("kick-turn", "pitch"):                   # pitch rate constant, yaw rate zero
+            out += [(2 * (a + k), 2 * a) for k in range(1, n)] + [(2 * (a + k) + 1, -1) for k in range(n)]
+        elif att == "pitch-yaw":                              # both rates constant
+            out += [(2 * (a + k), 2 * a) for k in range(1, n)] + [(2 * (a + k) + 1, 2 * a + 1) for k in range(1, n)]
+        elif att == "same-rate":                              # both rates as at the end of the previous section
+            out += [(2 * (a + k), 2 * a - 2) for k in range(n)] + [(2 * (a + k) + 1, 2 * a - 1) for k in range(n)]
+        elif att not in ("zero-lift-turn", "free"):
+            raise ValueError("unknown attitude option %r" % att)
+    return out
+
+
+def equality_rate(x, sp):
+    u = split(x, sp["M"], sp["N"])[4].ravel()
+    return np.array([u[p] - (u[q] if q >= 0 else 0.0) for p, q in _rate_rows(sp)])
+
+
+def equality_jac_rate(x, sp):                   # :255-347: per block the -1 column entries first, then the +1 entries
+    rows, cols, vals = [], [], []
+    r = 0
+    for i in range(sp["S"]):
+        a, n, att = sp["ua"][i], sp["nodes"][i], sp["attitude"][i]
+
+        def block(count, minus_col, plus_cols):
+            nonlocal r
+            rr = list(range(r, r + count))
+            if minus_col is not None:
+                rows.extend(rr); cols.extend([minus_col] * count); vals.extend([-1.0] * count)
+            rows.extend(rr); cols.extend(plus_cols); vals.extend([1.0] * count)
+            r += count
+
+        if att in ("hold", "vertical"):
+            block(2 * n, None, list(range(2 * a, 2 * (a + n))))
+        elif att in ("kick-turn", "pitch"):
+            block(n - 1, 2 * a, list(range(2 * (a + 1), 2 * (a + n), 2)))
+            block(n, None, list(range(2 * a + 1, 2 * (a + n) + 1, 2)))
+        elif att == "pitch-yaw":
+            block(n - 1, 2 * a, list(range(2 * (a + 1), 2 * (a + n), 2)))
+            block(n - 1, 2 * a + 1, list(range(2 * (a + 1) + 1, 2 * (a + n) + 1, 2)))
+        elif att == "same-rate":
+            block(n, 2 * a - 2, list(range(2 * a, 2 * (a + n), 2)))
+            block(n, 2 * a - 1, list(range(2 * a + 1, 2 * (a + n) + 1, 2)))
+    return {"u": _coo(rows, cols, vals, (r, 2 * sp["N"]))}
 
 
 # ---------------------------------------------------------------- the shipped user constraint and lib/jac_fd.py

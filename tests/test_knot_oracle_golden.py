@@ -14,7 +14,9 @@ CONDS = {"Payload": {}, "Other_incl": {"OptimizationMode": "Other", "inclination
 GROUPS = [("init", kt.equality_init, kt.equality_jac_init), ("time", kt.equality_time, kt.equality_jac_time),
           ("knot", kt.equality_knot_LGR, kt.equality_jac_knot_LGR),
           ("terminal", kt.equality_terminal, kt.equality_jac_terminal),
-          ("tineq", kt.inequality_time, kt.inequality_jac_time)]
+          ("tineq", kt.inequality_time, kt.inequality_jac_time),
+          ("rate", kt.equality_rate, kt.equality_jac_rate), ("imass", kt.inequality_mass, kt.inequality_jac_mass),
+          ("kick", kt.inequality_kickturn, kt.inequality_jac_kickturn)]
 
 
 def example(extra=None):
@@ -112,8 +114,10 @@ def test_product_row_tables_and_constant_jacobians_vs_golden(cname):
     g = load_golden("g11_knot_terminal.npz")
     pdict, unitdict, condition, xdict = example(CONDS[cname])
     R = ck.rows_of(pdict, unitdict, condition)
+    from gelato_amd import con_trajectory as ct
     jfs = {"init": ck.equality_jac_init, "time": ck.equality_jac_time, "knot": ck.equality_jac_knot_LGR,
-           "tineq": ck.inequality_jac_time}
+           "tineq": ck.inequality_jac_time, "rate": ct.equality_jac_6DoF_rate, "imass": ct.inequality_jac_mass,
+           "kick": ct.inequality_jac_kickturn}
     for xname in ("init", "moved"):
         x = g["x_" + xname]
         lin = np.array([(c0 * x[i0] + (c1 * x[i1] if i1 >= 0 else 0.0)) + cc if i1 >= 0 else c0 * x[i0] + cc
@@ -130,6 +134,7 @@ def test_product_row_tables_and_constant_jacobians_vs_golden(cname):
                 assert all(np.array_equal(blk["coo"][i], g[k + s]) for i, s in enumerate(("_rows", "_cols", "_vals"))), k
                 assert blk["coo"][0].dtype == np.int32 and blk["shape"] == tuple(g[k + "_shape"])
     # terminal rows: functions, node and scaling of the node-function rows
+    assert ct.equality_length_6DoF_rate(xdict, pdict, unitdict, condition) == len(g["init_%s_rate_con" % cname]) == 93
     nT = 3 if cname == "Other_incl" else 2
     assert R.n_terminal == nT and [f[0] for f in R.fn[:nT]] == ["orbit_energy", "angular_momentum", "inclination_rad"][:nT]
     assert all(f[1] == pdict["M"] - 1 for f in R.fn[:nT])

@@ -29,6 +29,7 @@ def xdict_of(E, x):
 def test_row_groups_vs_reference_golden_and_oracle(cname):
     from gelato_amd import con_dynamics
     from gelato_amd import con_init_terminal_knot as ck
+    from gelato_amd import con_trajectory as ct
     from oracle import knot_terminal as kt
     g = load_golden("g11_knot_terminal.npz")
     pdict, unitdict, condition, _ = example(CONDS[cname])
@@ -37,7 +38,9 @@ def test_row_groups_vs_reference_golden_and_oracle(cname):
     fns = {"init": (ck.equality_init, ck.equality_jac_init), "time": (ck.equality_time, ck.equality_jac_time),
            "knot": (ck.equality_knot_LGR, ck.equality_jac_knot_LGR),
            "terminal": (ck.equality_6DoF_LGR_terminal, ck.equality_jac_6DoF_LGR_terminal),
-           "tineq": (ck.inequality_time, ck.inequality_jac_time)}
+           "tineq": (ck.inequality_time, ck.inequality_jac_time),
+           "rate": (ct.equality_6DoF_rate, ct.equality_jac_6DoF_rate), "imass": (ct.inequality_mass, ct.inequality_jac_mass),
+           "kick": (ct.inequality_kickturn, ct.inequality_jac_kickturn)}
     for xname in ("init", "moved"):
         xd = xdict_of(E, g["x_" + xname])
         before = {k: v.copy() for k, v in xd.items()}
@@ -46,7 +49,7 @@ def test_row_groups_vs_reference_golden_and_oracle(cname):
             con, ref = f(xd, pdict, unitdict, condition), g[base + "_con"]
             J = jf(xd, pdict, unitdict, condition)
             if tag != "terminal":
-                assert np.array_equal(con, ref), base
+                assert np.array_equal(np.asarray(con), ref), base
             else:
                 assert np.all(np.abs(con - ref) <= 1e-13 + 1e-12 * np.abs(ref)), base
                 assert np.all(np.abs(con - kt.equality_terminal(g["x_" + xname], sp)) <= 1e-13 + 1e-12 * np.abs(ref))
