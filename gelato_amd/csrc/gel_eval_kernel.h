@@ -67,6 +67,10 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_DX_PF_RES 4
 #endif
 
+#ifndef GEL_COOP_XLDS
+#define GEL_COOP_XLDS 1  // cooperative D.X: state rows staged in LDS (1) or fetched per k-step from global memory (0)
+#endif
+
 #ifndef GEL_STORE_AUX
 #define GEL_STORE_AUX 2  // cache policy of the Jacobian stores: 2 = nt (A/B: 0 plain, 1 sc0, 16 sc1, 18 sc1+nt)
 #endif
@@ -184,12 +188,23 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 #define FDQ(fp, fc) (((fc) - (fp)) * fds)
 
   // ======================= phase A: every global load =======================
-  const double me = xm[xj];
-  const double re[3] = {xr[3 * xj], xr[3 * xj + 1], xr[3 * xj + 2]};
+  // XLDS (cooperative form, phases whose n + 1 state rows fit one 68-row slab): the four decision vectors' state rows are
+  // staged in LDS once per workgroup and serve both as the B operand of D.X and as the node's own state -- no strided
+  // 8-byte global loads in the matrix loop.  Measured against fetching B per k-step from global memory (same box,
+  // B = 16384 / 65536): fused launch -2 % at 6x64, residual-only -9 % at 3x32; with two slabs (n = 128) the extra
+  // workgroup barriers cost what the loads save (residual-only +10 %), so longer phases keep the global form.
+  const bool XLDS = COOP && (GEL_COOP_XLDS != 0) && n < 68;   // wave-uniform
+  double me = 0.0, re[3] = {0.0, 0.0, 0.0};
+  if (!XLDS) { me = xm[xj]; re[0] = xr[3 * xj]; re[1] = xr[3 * xj + 1]; re[2] = xr[3 * xj + 2]; }
   const double tau = P.tau[ph.toff + jc];
   {
-    const double q[4] = {xq[4 * xj], xq[4 * xj + 1], xq[4 * xj + 2], xq[4 * xj + 3]};
-    const double ve[3] = {xv[3 * xj], xv[3 * xj + 1], xv[3 * xj + 2]};
+    double q[4] = {0.0, 0.0, 0.0, 0.0}, ve[3] = {0.0, 0.0, 0.0};
+    if (!XLDS) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) q[c] = xq[4 * xj + c];
+#pragma unroll
+      for (int c = 0; c < 3; c++) ve[c] = xv[3 * xj + c];
+    }
     double u0 = 0.0, u1 = 0.0;
     if (!ph.hold) { u0 = xu[2 * (ph.ua + jc)]; u1 = xu[2 * (ph.ua + jc) + 1]; }
     const double djj = JAC ? P.Dt[ph.doff + (size_t)(jc + 1) * n + jc] : 0.0;  // D[j][j+1]
@@ -197,7 +212,99 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     // D.X rows (lib/con_dynamics.py:54,146,256,524)
     double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
     if (rb) {
-      if (COOP) {
+      if (XLDS) {
+        // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP, operands as in the branch below, but B comes from LDS: in slabs of 68
+        // state rows (17 k-steps) every wavefront stages ITS OWN vector's rows -- lane = row, the eleven interleaved
+        // columns (mass | pos xyz | vel xyz | quat wxyz) side by side, [row][11] at the start of its park region --
+        // and all four read the 44 packed columns from there.  Eleven strided global loads per wavefront and slab instead
+        // of three per k-step, and the node's own state row is read back from the same image.
+        const int c16 = lane & 15, kq = lane >> 4;
+        constexpr int kSlabK = 17, kSlabRows = 4 * kSlabK;
+        static_assert(kSlabRows * 11 <= kWaveLds, "a slab of state rows must fit the wave's park region");
+        lds_double* regions = (lds_double*)lds + P.park_off;
+        int xoff[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) {
+          const int c = 16 * ct + c16;            // packed column: vector c / 11, state column c % 11
+          const int vb = min(c / 11, 3);          // columns 44..47 are padding: computed on vector 3, never read
+          xoff[ct] = vb * kWaveLds + ((c < 44) ? c - 11 * vb : 0) + kq * 11;
+        }
+        gel_double4 acc[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
+        const double* ap = P.Dst + (size_t)dsw * 4 + wv * 64 + lane;
+        const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4)
+        const int own = jc + 1;            // this lane's state row inside the phase
+        for (int s0 = 0; s0 < ksteps; s0 += kSlabK) {
+          const int kbase = 4 * s0;
+          if (s0) __syncthreads();         // every wavefront is done multiplying the previous slab
+#pragma unroll
+          for (int it = 0; it < 2; it++) {
+            const int rr = lane + 64 * it;
+            if (rr < kSlabRows) {
+              const int k = kbase + rr;
+              lds_double* dst = wave_lds + rr * 11;
+              if (k <= n) {
+                const int xk = ph.xa + k;
+                dst[0] = xm[xk];
+#pragma unroll
+                for (int c = 0; c < 3; c++) { dst[1 + c] = xr[3 * xk + c]; dst[4 + c] = xv[3 * xk + c]; }
+#pragma unroll
+                for (int c = 0; c < 4; c++) dst[7 + c] = xq[4 * xk + c];
+              } else {  // rows past the phase meet zero columns of D: any finite value
+#pragma unroll
+                for (int c = 0; c < 11; c++) dst[c] = 0.0;
+              }
+            }
+          }
+          __syncthreads();
+          {
+            const int ol = own - kbase;     // the node's own state row, if it lies in this slab
+            if (ol >= 0 && ol < kSlabRows) {
+              lds_double* src = wave_lds + ol * 11;
+              me = src[0];
+#pragma unroll
+              for (int c = 0; c < 3; c++) { re[c] = src[1 + c]; ve[c] = src[4 + c]; }
+#pragma unroll
+              for (int c = 0; c < 4; c++) q[c] = src[7 + c];
+            }
+          }
+          const int kcount = min(kSlabK, ksteps - s0);
+          double a = ap[s0 * 256];
+#ifdef GEL_ABL_NODX
+          for (int ks = 0; ks < 0; ks++) {
+#else
+          for (int ks = 0; ks < kcount; ks++) {
+#endif
+            const double a_next = ap[min(s0 + ks + 1, ksteps - 1) * 256];   // the next k-step's A slab is on its way
+            const int ro = ks * 44;                                          // 4 rows of 11 columns per k-step
+            const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl2, acc[2], 0, 0, 0);
+            a = a_next;
+          }
+        }
+        __syncthreads();                   // the hand-over area overlaps the state-row image: everyone is done reading it
+        lds_double* wg_lds = regions + kCoopStageOff;
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) {
+          const int c = 16 * ct + c16;
+          const int vb = c / 11, col = c - 11 * vb;
+          if (c < 44) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) wg_lds[vb * kWaveLds + (16 * wv + kq + 4 * i) * 11 + col] = acc[ct][i];
+          }
+        }
+        __syncthreads();
+        if (ghost) return;
+        lds_double* row = wave_lds + kCoopStageOff + lane * 11;
+        lm = row[0];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
+#pragma unroll
+        for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
+      } else if (COOP) {
         // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP: A = the work item's rows of D, shared by all four wavefronts;
         // B = the 11 state columns of the workgroup's four decision vectors side by side (44 of 48 columns used,
         // against 11 of 16 when every wavefront multiplies alone).  Wavefront w forms row tile w (16 nodes) for all
