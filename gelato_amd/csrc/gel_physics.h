@@ -137,16 +137,30 @@ GEL_DEV double frsqrt(double x) {
 // (3.0 % vs 3.1 % of results differ from glibc's on 2.6 M arguments), 84 ns.  Larger arguments: the library's.
 // -DGEL_STD_MATH restores log() / sincos() everywhere.
 // ---------------------------------------------------------------------------
+// One Horner step p * w + c with the coefficient as a SCALAR operand.  hipcc compiles __builtin_fma(p, w, literal) to
+// v_fmac_f64 with the literal first moved into the destination VGPR pair -- two v_mov_b32 per term, which on a
+// kernel bound by vector issue doubles the cost of every polynomial.  With the coefficient in an SGPR pair (two s_mov_b32
+// on the scalar unit) the step is the one v_fma_f64.  Same operation, same bits.  -DGEL_HORNER_VGPR restores the plain form.
+#ifndef GEL_HORNER_VGPR
+GEL_DEV double horner(double p, double w, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(w), "s"(c));
+  return r;
+}
+#else
+GEL_DEV double horner(double p, double w, double c) { return __builtin_fma(p, w, c); }
+#endif
+
 GEL_DEV double flog_ratio(double x) {
 #ifndef GEL_STD_MATH
   if (x > 0.5 && x < 2.0) {
     const double z = fdiv(x - 1.0, x + 1.0), w = z * z;
     double p = 1.0 / 33.0;
-    p = __builtin_fma(p, w, 1.0 / 31.0); p = __builtin_fma(p, w, 1.0 / 29.0); p = __builtin_fma(p, w, 1.0 / 27.0);
-    p = __builtin_fma(p, w, 1.0 / 25.0); p = __builtin_fma(p, w, 1.0 / 23.0); p = __builtin_fma(p, w, 1.0 / 21.0);
-    p = __builtin_fma(p, w, 1.0 / 19.0); p = __builtin_fma(p, w, 1.0 / 17.0); p = __builtin_fma(p, w, 1.0 / 15.0);
-    p = __builtin_fma(p, w, 1.0 / 13.0); p = __builtin_fma(p, w, 1.0 / 11.0); p = __builtin_fma(p, w, 1.0 / 9.0);
-    p = __builtin_fma(p, w, 1.0 / 7.0); p = __builtin_fma(p, w, 1.0 / 5.0); p = __builtin_fma(p, w, 1.0 / 3.0);
+    p = horner(p, w, 1.0 / 31.0); p = horner(p, w, 1.0 / 29.0); p = horner(p, w, 1.0 / 27.0);
+    p = horner(p, w, 1.0 / 25.0); p = horner(p, w, 1.0 / 23.0); p = horner(p, w, 1.0 / 21.0);
+    p = horner(p, w, 1.0 / 19.0); p = horner(p, w, 1.0 / 17.0); p = horner(p, w, 1.0 / 15.0);
+    p = horner(p, w, 1.0 / 13.0); p = horner(p, w, 1.0 / 11.0); p = horner(p, w, 1.0 / 9.0);
+    p = horner(p, w, 1.0 / 7.0); p = horner(p, w, 1.0 / 5.0); p = horner(p, w, 1.0 / 3.0);
     return __builtin_fma(2.0 * z * w, p, 2.0 * z);
   }
 #endif
@@ -168,11 +182,11 @@ GEL_DEV void fsincos(double x, double* sn, double* cs) {
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
   const double v = z * r;
-  const double ps = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double ps = horner(horner(horner(horner(S6, z, S5), z, S4), z, S3), z, S2);
   const double ks = r - ((z * (0.5 * y - v * ps) - y) - v * S1);
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  const double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double pc = z * horner(horner(horner(horner(horner(C6, z, C5), z, C4), z, C3), z, C2), z, C1);
   const double hz = 0.5 * z, w = 1.0 - hz;
   const double kc = w + (((1.0 - w) - hz) + (z * pc - r * y));
   const bool q = n != 0.0;        // |x| = n pi/2 + (r + y):  n = 0 -> (ks, kc);  n = 1 -> (kc, -ks); sin is odd in x
