@@ -41,7 +41,7 @@ class GelLinearRow(C.Structure):
 
 
 class GelNodefnRow(C.Structure):
-    _fields_ = [("fn", C.c_int32), ("node", C.c_int32), ("p0", C.c_double), ("p1", C.c_double)]
+    _fields_ = [("fn", C.c_int32), ("node", C.c_int32), ("tcol", C.c_int32), ("mode", C.c_int32), ("p", C.c_double * 8)]
 
 
 class GelCallbackIO(C.Structure):

@@ -11,9 +11,11 @@ Drop-in for the reference's lib/con_init_terminal_knot.py: the same ten function
 All five groups are rows of ONE device table on the handle of the defect path (gel_rows_configure): four of them are
 differences of single decision variables plus a constant ("linear rows", constant Jacobians laid out here in the
 reference's emission order); the terminal group is three functions of the last state node with a six-column forward
-difference formed in the kernel ("node-function rows").  The first call for a new xdict evaluates every row in one
+difference formed in the kernel ("node-function rows"; the user rows of con_user.py and the waypoint rows of
+con_waypoint.py are more of them in the same table).  The first call for a new xdict evaluates every row in one
 launch; the other calls return slices of it.  xdict is never mutated.
 """
+import json
 import math
 
 import numpy as np
@@ -215,15 +217,24 @@ class _Rows:
         self.user_rows = list(user_rows)
         for (f, section, p0, p1) in self.user_rows:
             fn.append((f, xa[ev[section]], p0, p1))
+        self.user_nodes = [xa[ev[section]] for (_, section, _, _) in self.user_rows]
+        # ---- waypoint / impact-point / antenna rows (con_waypoint.py): functions of a knot state and its knot time
+        from . import con_waypoint
+        self.waypoint_base = len(fn)
+        self.waypoint_rows = con_waypoint.build_rows(pdict, condition, xa)
+        self.waypoint_slices = {}
+        for g in con_waypoint._GROUPS:
+            idx = [k for k, r in enumerate(self.waypoint_rows) if r[0] == g]
+            self.waypoint_slices[g] = (idx[0], idx[-1] + 1) if idx else (0, 0)
+        fn += [r[3] for r in self.waypoint_rows]
         self.nlin, self.nfn = len(lin), len(fn)
         self.lin, self.fn = lin, fn
-        self.user_nodes = [xa[ev[section]] for (_, section, _, _) in self.user_rows]
         eng.rows_configure(lin, fn)
         self.engine = eng
         self.M = M
 
     def evaluate(self, xdict, pdict, need_jac=False):
-        """(con [nlin + nfn], jfn [nfn, 6] | None) of this xdict, from the callback's one device round trip"""
+        """(con [nlin + nfn], jfn [nfn, 7] | None) of this xdict, from the callback's one device round trip"""
         fr = con_dynamics._state(pdict, None).frame(xdict, need_jac)
         return fr["rows_con"], fr["rows_jfn"]
 
@@ -234,7 +245,8 @@ def rows_of(pdict, unitdict, condition):
     user = tuple(tuple(r) for r in (pdict.get("gelato_amd_user_rows") or ()))
     key = (id(condition), condition["OptimizationMode"], tuple(condition.get(k) for k in (
         "altitude_perigee", "altitude_apogee", "inclination", "radius", "vel_tangential_geocentric",
-        "flightpath_vel_inertial_geocentric")), user)
+        "flightpath_vel_inertial_geocentric")), user,
+        json.dumps([condition.get("waypoint"), condition.get("antenna")], sort_keys=True))
     cached = st.__dict__.get("rows")
     if cached is None or cached[0] != key:
         st.rows = (key, _Rows(pdict, unitdict, condition, user))
@@ -296,7 +308,7 @@ def equality_jac_6DoF_LGR_terminal(xdict, pdict, unitdict, condition):
     _, jfn = R.evaluate(xdict, pdict, need_jac=True)
     nT, M = R.n_terminal, R.M
     rows, cols = R.terminal_pattern
-    J = jfn[:nT]                                           # [row][position xyz, velocity xyz]
+    J = jfn[:nT]                                           # [row][position xyz, velocity xyz, knot time]
     return {"position": {"coo": [rows, cols, J[:, 0:3].T.ravel().copy()], "shape": (nT, 3 * M)},
             "velocity": {"coo": [rows, cols, J[:, 3:6].T.ravel().copy()], "shape": (nT, 3 * M)}}
 

@@ -58,7 +58,10 @@ struct AeroNodeDev {
 
 // knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py): see gel_kernels.hip rows_kernel
 struct LinRowDev { int32_t idx0, idx1; double coef0, coef1, c0; };  // (coef0 x[idx0] + coef1 x[idx1]) + c0; idx1 < 0: one term
-struct FnRowDev { int32_t fn, node; double p0, p1; };               // f(position, velocity of state node) / p0 - p1
+// f(position, velocity of state node `node`[, knot time x_t[tcol]]) mapped by `mode` (gel_kernels.hip rows_kernel):
+// value: mode & 3 == 0: f / p[0] - p[1];  == 1: (f - p[1]) / p[0];  bit 3: negated
+// difference: bit 2 clear: (value(x + dx e_c) - value(x)) / dx;  set: ((f(x + dx e_c) - f(x)) / dx) / p[0], negated with bit 3
+struct FnRowDev { int32_t fn, node, tcol, mode; double p[8]; };
 
 struct ProblemDev {
   int32_t S, N, M, nvars;

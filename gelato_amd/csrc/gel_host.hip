@@ -1349,12 +1349,17 @@ int gel_rows_configure(gel_problem* p, int32_t nlin, const gel_linear_row* lin, 
     if (lin[i].idx0 < 0 || lin[i].idx0 >= p->dims.num_vars || lin[i].idx1 >= p->dims.num_vars)
       return fail(GEL_ERR_ARG, "linear row: variable index out of range");
   for (int i = 0; i < nfn; i++)
-    if (fn[i].fn < 0 || fn[i].fn > 8 || fn[i].node < 0 || fn[i].node >= p->dims.M || !(fn[i].p0 != 0.0))
-      return fail(GEL_ERR_ARG, "node-function row: unknown function, node out of range, or zero scale");
+    if (fn[i].fn < 0 || fn[i].fn > 14 || fn[i].node < 0 || fn[i].node >= p->dims.M || !(fn[i].p[0] != 0.0) ||
+        fn[i].tcol < -1 || fn[i].tcol > p->dims.S || (fn[i].fn >= 9 && fn[i].tcol < 0) || (fn[i].mode & ~15) || (fn[i].mode & 3) > 1)
+      return fail(GEL_ERR_ARG, "node-function row: unknown function or mode, node / time column out of range, or zero scale");
   p->lin_rows.resize(nlin);
   p->fn_rows.resize(nfn);
   for (int i = 0; i < nlin; i++) p->lin_rows[i] = gel::LinRowDev{lin[i].idx0, lin[i].idx1 < 0 ? -1 : lin[i].idx1, lin[i].coef0, lin[i].coef1, lin[i].c0};
-  for (int i = 0; i < nfn; i++) p->fn_rows[i] = gel::FnRowDev{fn[i].fn, fn[i].node, fn[i].p0, fn[i].p1};
+  for (int i = 0; i < nfn; i++) {
+    gel::FnRowDev& d = p->fn_rows[i];
+    d.fn = fn[i].fn; d.node = fn[i].node; d.tcol = fn[i].tcol; d.mode = fn[i].mode;
+    for (int k = 0; k < 8; k++) d.p[k] = fn[i].p[k];
+  }
   if (p->device == GEL_DEVICE_NONE) return GEL_OK;
   HIPCHK(hipSetDevice(p->device));
   HIPCHK(hipStreamSynchronize(p->stream));
@@ -1387,7 +1392,7 @@ int gel_rows_eval(gel_problem* p, int32_t B, const double* x, double* con, doubl
   const size_t R = p->lin_rows.size() + p->fn_rows.size(), nf = p->fn_rows.size();
   if (R == 0) return GEL_OK;
   HIPCHK(hipSetDevice(p->device));
-  const size_t nx = (size_t)B * p->dims.num_vars, nc = (size_t)B * R, nj = jfn ? (size_t)B * nf * 6 : 0;
+  const size_t nx = (size_t)B * p->dims.num_vars, nc = (size_t)B * R, nj = jfn ? (size_t)B * nf * 7 : 0;
   int rc;
   if ((nx + nc + nj) * 8 <= kZeroCopyBytes) {
     // the optimiser's callback: the kernel reads x from and writes to pinned host memory, one launch + one synchronise
@@ -1477,7 +1482,7 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
     off_j[k] = atotal; atotal += (io->aero_con[k] && n && io->aero_jac[k]) ? aero_jac_len(p, k) : 0;
     aero = aero || (io->aero_con[k] && n);
   }
-  if (rows && (rc = grow(&p->h_rows, &p->h_rows_cap, R + 6 * nfn + 1, true))) return rc;
+  if (rows && (rc = grow(&p->h_rows, &p->h_rows_cap, R + 7 * nfn + 1, true))) return rc;
   if (aero && (rc = grow(&p->h_aero, &p->h_aero_cap, atotal, true))) return rc;
   std::memcpy(p->h_x, x, (size_t)p->dims.num_vars * 8);
   // everything reads x from and writes to pinned host memory; launches go back to back on the handle's stream
@@ -1504,7 +1509,7 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
   if (want_jac) scatter_full(p, p->h_jv, io->vals_full, io->fill_constants);
   if (rows) {
     std::memcpy(io->rows_con, p->h_rows, R * 8);
-    if (io->rows_jfn) std::memcpy(io->rows_jfn, p->h_rows + R, 6 * nfn * 8);
+    if (io->rows_jfn) std::memcpy(io->rows_jfn, p->h_rows + R, 7 * nfn * 8);
   }
   if (aero)
     for (int k = 0; k < 3; k++) {

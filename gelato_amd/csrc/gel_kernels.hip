@@ -449,13 +449,80 @@ hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes
 // Node-function rows: g = f(r, v) / p0 - p1 at ONE state node, r = position * unit, v = velocity * unit, and the forward
 // difference (g(x + dx e_c) - g(x)) / dx over exactly the six columns the row can see (lib/con_init_terminal_knot.py:
 // 378-405 perturbs the last node's six columns; lib/jac_fd.py:29-62 perturbs every column of x, and every column but
-// these six returns an exact zero).  Eight lanes per row: lane 0 the centre, lanes 1..6 one perturbed column each,
-// formed in the kernel -- no perturbed copies of x exist anywhere.
-//   fn 0 orbit energy (src/wrapper_coordinate.hpp:246-250)   1 |angular momentum| (:222-228)   2 inclination [rad] (:229-236)
-//   fn 3 a   4 e   5 a (1 - e)   6 a (1 + e)   (src/Coordinate.cpp:197-245: p = c.c/mu, e = |f|/mu, a = p/(1 - e^2))
-//   fn 7 |r|   8 |v|
+// these six returns an exact zero).  Eight lanes per row: lane 0 the centre, lanes 1..6 one perturbed state column each,
+// lane 7 the knot time of rows that read it (the waypoint rows of lib/con_waypoint.py), formed in the kernel -- no
+// perturbed copies of x exist anywhere.  Functions: see node_fn().
 // ---------------------------------------------------------------------------
-GEL_DEV double node_fn(int fn, const double r[3], const double v[3]) {
+// Instantaneous impact point, FAA algorithm (lib/IIP.py:30-135 posLLH_IIP_FAA, fill_na = True, n_iter = 5): geodetic
+// latitude and East longitude [deg] of the vacuum impact of (posECEF, velECEF); (0, 0) where the algorithm has no solution.
+GEL_DEV void iip_faa(const double pe[3], const double ve[3], double& lat_deg, double& lon_deg) {
+  const double a = 6378137.0, f = 1.0 / 298.257223563, b = a * (1.0 - f), e2 = 2.0 * f - f * f;
+  lat_deg = 0.0; lon_deg = 0.0;
+  double r_k1 = b;
+  const double r0 = sqrt(pe[0] * pe[0] + pe[1] * pe[1] + pe[2] * pe[2]);
+  if (r0 < r_k1) return;                                          // below the surface
+  const double vi[3] = {ve[0] - kOmega * pe[1], ve[1] + kOmega * pe[0], ve[2]};   // + omega x r
+  const double v0 = sqrt(vi[0] * vi[0] + vi[1] * vi[1] + vi[2] * vi[2]);
+  const double eps_cos = (r0 * (v0 * v0) / kMu) - 1.0;
+  if (eps_cos >= 1.0) return;                                     // not elliptical
+  const double a_t = r0 / (1.0 - eps_cos);
+  const double eps_sin = (pe[0] * vi[0] + pe[1] * vi[1] + pe[2] * vi[2]) / sqrt(kMu * a_t);
+  const double eps2 = eps_cos * eps_cos + eps_sin * eps_sin;
+  if (sqrt(eps2) <= 1.0 && a_t * (1.0 - sqrt(eps2)) - a >= 0.0) return;   // positive perigee height
+  double Ek = 0.0, Fk = 0.0, Gk = 0.0, r_k2 = 0.0, r_prev = 0.0, eps_k_sin = 0.0, dcos = 0.0, dsin = 0.0;
+  const double root = sqrt((a_t * a_t * a_t) / kMu);
+  for (int it = 0; it < 5; it++) {
+    const double eps_k_cos = (a_t - r_k1) / a_t;
+    if (eps2 - eps_k_cos * eps_k_cos < 0.0) return;              // no intersection with the surface
+    eps_k_sin = -sqrt(eps2 - eps_k_cos * eps_k_cos);
+    dcos = (eps_k_cos * eps_cos + eps_k_sin * eps_sin) / eps2;
+    dsin = (eps_k_sin * eps_cos - eps_k_cos * eps_sin) / eps2;
+    const double fs = (dcos - eps_cos) / (1.0 - eps_cos);
+    const double gs = (dsin + eps_sin - eps_k_sin) * root;
+    Ek = fs * pe[0] + gs * vi[0]; Fk = fs * pe[1] + gs * vi[1]; Gk = fs * pe[2] + gs * vi[2];
+    const double q = Gk / r_k1;
+    r_k2 = a / sqrt((e2 / (1.0 - e2)) * (q * q) + 1.0);
+    r_prev = r_k1;
+    r_k1 = r_k2;
+  }
+  if (fabs(r_prev - r_k2) > 1.0) return;                          // not converged
+  const double delta = atan2(dsin, dcos);
+  const double time_sec = (delta + eps_sin - eps_k_sin) * root;
+  const double phi = atan2(tan(asin(Gk / r_k2)), 1.0 - e2);
+  const double lam = atan2(Fk, Ek) - kOmega * time_sec;
+  lat_deg = phi * 180.0 / kPi;
+  lon_deg = lam * 180.0 / kPi;
+}
+
+// functions of ONE knot state (r, v in SI units, t in seconds, row parameters p):
+//   0 orbit energy (src/wrapper_coordinate.hpp:246-250)   1 |angular momentum| (:222-228)   2 inclination [rad] (:229-236)
+//   3 a   4 e   5 a (1 - e)   6 a (1 + e)   (src/Coordinate.cpp:197-245)   7 |r|   8 |v|
+//   9 / 10 / 11 geodetic latitude [deg] / longitude [deg] / altitude [m] of the ECEF position at time t
+//       (eci2geodetic, lib/coordinate.py; lib/con_waypoint.py:507-560)
+//   12 / 13 latitude / longitude [deg] of the instantaneous impact point (lib/con_waypoint.py:164-207, lib/IIP.py)
+//   14 sine of the elevation above an antenna's horizon, p[2..4] = antenna ECEF, p[5..7] = its local vertical
+//       (lib/con_waypoint.py:45-51)
+GEL_DEV double node_fn(int fn, const double r[3], const double v[3], double t, const double* p) {
+  if (fn >= 9) {
+    double sn, cs;
+    sincos(kOmega * t, &sn, &cs);
+    const double pe[3] = {r[0] * cs + r[1] * sn, -r[0] * sn + r[1] * cs, r[2]};      // eci2ecef (src/Coordinate.cpp:51-59)
+    if (fn <= 11) {
+      double lat, lon, alt;
+      geodetic_full(pe[0], pe[1], pe[2], lat, lon, alt);
+      return (fn == 9) ? lat * (180.0 / kPi) : (fn == 10) ? lon * (180.0 / kPi) : alt;   // math.degrees
+    }
+    if (fn <= 13) {
+      const double d0 = v[0] + kOmega * r[1], d1 = v[1] - kOmega * r[0];             // vel_eci2ecef (:69-73)
+      const double ve[3] = {d0 * cs + d1 * sn, -d0 * sn + d1 * cs, v[2]};
+      double la, lo;
+      iip_faa(pe, ve, la, lo);
+      return (fn == 12) ? la : lo;
+    }
+    const double d[3] = {pe[0] - p[2], pe[1] - p[3], pe[2] - p[4]};
+    const double dn = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    return (d[0] / dn) * p[5] + (d[1] / dn) * p[6] + (d[2] / dn) * p[7];
+  }
   const double rn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
   const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   if (fn == 0) return 0.5 * vn * vn - kMu / rn;
@@ -492,7 +559,7 @@ __global__ void rows_kernel(ProblemDev P, int nlin, const LinRowDev* __restrict_
   } else {
     const long long t = (long long)(blockIdx.x - lin_blocks) * blockDim.x + threadIdx.x;
     const long long grp = t >> 3;
-    const int sw = (int)(t & 7);                       // 0 centre, 1..3 position xyz + dx, 4..6 velocity xyz + dx, 7 idle
+    const int sw = (int)(t & 7);                       // 0 centre, 1..3 position xyz + dx, 4..6 velocity xyz + dx, 7 knot time + dx
     const bool live = grp < (long long)B * nfn;
     const long long g2 = live ? grp : 0;
     const int b = (int)(g2 / nfn), row = (int)(g2 - (long long)b * nfn);
@@ -501,16 +568,30 @@ __global__ void rows_kernel(ProblemDev P, int nlin, const LinRowDev* __restrict_
     double r[3], v[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      // xdict[key][j] += dx, then * unit (con_init_terminal_knot.py:340-341,392-394)
+      // xdict[key][j] += dx, then * unit (con_init_terminal_knot.py:340-341,392-394; con_waypoint.py:219-232,565-577)
       const double pe = xb[P.M + 3 * F.node + c], ve = xb[4 * P.M + 3 * F.node + c];
       r[c] = ((sw == 1 + c) ? pe + P.dx : pe) * P.up;
       v[c] = ((sw == 4 + c) ? ve + P.dx : ve) * P.uv;
     }
-    const double g = node_fn(F.fn, r, v) / F.p0 - F.p1;
-    const double gc = __shfl(g, (int)(threadIdx.x & 63 & ~7), 64);  // the centre value of this row's lane group
-    if (!live || sw == 7) return;
+    double tk = 0.0;
+    if (F.tcol >= 0) {
+      const double te = xb[11 * P.M + 2 * P.N + F.tcol];
+      tk = ((sw == 7) ? te + P.dx : te) * P.ut;
+    }
+    const double f = node_fn(F.fn, r, v, tk, F.p);
+    const int vm = F.mode & 3;
+    double g = (vm == 0) ? f / F.p[0] - F.p[1] : (f - F.p[1]) / F.p[0];
+    if (F.mode & 8) g = -g;
+    const int lane0 = (int)(threadIdx.x & 63 & ~7);
+    const double gc = __shfl(g, lane0, 64), fc = __shfl(f, lane0, 64);   // the centre values of this row's lane group
+    if (!live) return;
     if (sw == 0) chk = con[(size_t)b * R + nlin + row] = g;
-    else if (jfn) chk = jfn[((size_t)b * nfn + row) * 6 + (sw - 1)] = (g - gc) / P.dx;
+    else if (jfn) {
+      double d;
+      if (F.mode & 4) { d = ((f - fc) / P.dx) / F.p[0]; if (F.mode & 8) d = -d; }   // the reference scales the raw difference
+      else d = (g - gc) / P.dx;                                                       // difference of the row's own value
+      chk = jfn[((size_t)b * nfn + row) * 7 + (sw - 1)] = d;
+    }
   }
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }

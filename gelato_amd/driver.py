@@ -9,7 +9,7 @@ timers the reference prints (:511-517).
 """
 import time
 
-from . import con_aero, con_dynamics, con_trajectory, con_user
+from . import con_aero, con_dynamics, con_trajectory, con_user, con_waypoint
 from . import con_init_terminal_knot as con_a
 from .cost_gradient import cost_6DoF, cost_jac
 
@@ -48,6 +48,11 @@ def make_callbacks(pdict, unitdict, condition):
             funcs["eqcon_rate"] = con_trajectory.equality_6DoF_rate(xdict, pdict, unitdict, condition)          # :217
             funcs["ineqcon_mass"] = con_trajectory.inequality_mass(xdict, pdict, unitdict, condition)           # :228
             funcs["ineqcon_kick"] = con_trajectory.inequality_kickturn(xdict, pdict, unitdict, condition)       # :229-231
+            funcs["eqcon_pos"] = con_waypoint.equality_posLLH(xdict, pdict, unitdict, condition)                # :217-218
+            funcs["eqcon_iip"] = con_waypoint.equality_IIP(xdict, pdict, unitdict, condition)
+            funcs["ineqcon_pos"] = con_waypoint.inequality_posLLH(xdict, pdict, unitdict, condition)            # :233-237
+            funcs["ineqcon_iip"] = con_waypoint.inequality_IIP(xdict, pdict, unitdict, condition)
+            funcs["ineqcon_antenna"] = con_waypoint.inequality_antenna(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_mass"] = con_dynamics.equality_dynamics_mass(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_pos"] = con_dynamics.equality_dynamics_position(xdict, pdict, unitdict, condition)
         funcs["eqcon_dyn_vel"] = con_dynamics.equality_dynamics_velocity(xdict, pdict, unitdict, condition)
@@ -72,6 +77,11 @@ def make_callbacks(pdict, unitdict, condition):
             fs["eqcon_rate"] = con_trajectory.equality_jac_6DoF_rate(xdict, pdict, unitdict, condition)
             fs["ineqcon_mass"] = con_trajectory.inequality_jac_mass(xdict, pdict, unitdict, condition)
             fs["ineqcon_kick"] = con_trajectory.inequality_jac_kickturn(xdict, pdict, unitdict, condition)
+            fs["eqcon_pos"] = con_waypoint.equality_jac_posLLH(xdict, pdict, unitdict, condition)               # :272-275
+            fs["eqcon_iip"] = con_waypoint.equality_jac_IIP(xdict, pdict, unitdict, condition)
+            fs["ineqcon_pos"] = con_waypoint.inequality_jac_posLLH(xdict, pdict, unitdict, condition)           # :298-306
+            fs["ineqcon_iip"] = con_waypoint.inequality_jac_IIP(xdict, pdict, unitdict, condition)
+            fs["ineqcon_antenna"] = con_waypoint.inequality_jac_antenna(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_mass"] = con_dynamics.equality_jac_dynamics_mass(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_pos"] = con_dynamics.equality_jac_dynamics_position(xdict, pdict, unitdict, condition)
         fs["eqcon_dyn_vel"] = con_dynamics.equality_jac_dynamics_velocity(xdict, pdict, unitdict, condition)

@@ -375,7 +375,7 @@ class Engine:
                 out["rows_con"] = np.empty(self._nlin + self._nfn)
                 io.rows_con = _d(out["rows_con"])
                 if want_jac:
-                    out["rows_jfn"] = np.empty((max(self._nfn, 1), 6))
+                    out["rows_jfn"] = np.empty((max(self._nfn, 1), 7))
                     io.rows_jfn = _d(out["rows_jfn"])
             for i, kind in enumerate(self.AERO_KINDS):
                 nrow, nnz = self.aero_dims(kind)
@@ -404,7 +404,11 @@ class Engine:
 
     # ---- knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py) ----
     NODE_FUNCTIONS = {"orbit_energy": 0, "angular_momentum": 1, "inclination_rad": 2, "semi_major_axis": 3,
-                      "eccentricity": 4, "periapsis_radius": 5, "apoapsis_radius": 6, "radius": 7, "speed": 8}
+                      "eccentricity": 4, "periapsis_radius": 5, "apoapsis_radius": 6, "radius": 7, "speed": 8,
+                      "latitude_deg": 9, "longitude_deg": 10, "altitude": 11, "lat_IIP_deg": 12, "lon_IIP_deg": 13,
+                      "sin_elevation": 14}
+    # row modes (include/gelato_amd.h): value f / p0 - p1 | (f - p1) / p0; difference of the value | scaled raw difference
+    MODE_SHIFTED, MODE_RAW_DIFFERENCE, MODE_NEGATED = 1, 4, 8
 
     def var_offset(self, key):
         """first index of xdict[key] inside the packed decision vector"""
@@ -413,24 +417,32 @@ class Engine:
 
     def rows_configure(self, linear, nodefn):
         """linear: rows (idx0, coef0, idx1 | -1, coef1, c0) -> (coef0 x[idx0] + coef1 x[idx1]) + c0;
-        nodefn: rows (fn, node, p0, p1) -> f(r, v at state node) / p0 - p1 with its six-column forward difference."""
+        nodefn: rows (fn, node, p0, p1) -> f(r, v at state node) / p0 - p1 with its forward difference, or the long form
+        (fn, node, tcol, mode, [p0 .. p7]) of include/gelato_amd.h (functions of the knot time, other value / difference forms)."""
         lin = (GelLinearRow * max(1, len(linear)))()
         for k, (i0, c0_, i1, c1_, cc) in enumerate(linear):
             lin[k] = GelLinearRow(int(i0), int(i1), float(c0_), float(c1_), float(cc))
         fn = (GelNodefnRow * max(1, len(nodefn)))()
-        for k, (f, node, p0, p1) in enumerate(nodefn):
-            fn[k] = GelNodefnRow(int(self.NODE_FUNCTIONS.get(f, f)), int(node), float(p0), float(p1))
+        for k, row in enumerate(nodefn):
+            if len(row) == 4:
+                f, node, p0, p1 = row
+                tcol, mode, pp = -1, 0, [p0, p1]
+            else:
+                f, node, tcol, mode, pp = row
+            pp = [float(v) for v in pp] + [0.0] * (8 - len(pp))
+            fn[k] = GelNodefnRow(int(self.NODE_FUNCTIONS.get(f, f)), int(node), int(tcol), int(mode), (C.c_double * 8)(*pp))
         check(lib().gel_rows_configure(self._h, len(linear), lin, len(nodefn), fn))
         self._nlin, self._nfn = len(linear), len(nodefn)
         self._cb_out = {}
         self._cfg_gen = getattr(self, "_cfg_gen", 0) + 1
 
     def rows_eval(self, X, want_jac=True):
-        """X [B, nvars] (or [nvars]) -> (con [B, nlin + nfn], jfn [B, nfn, 6] | None, status)"""
+        """X [B, nvars] (or [nvars]) -> (con [B, nlin + nfn], jfn [B, nfn, 7] | None, status); the seven difference columns
+        are position xyz, velocity xyz of the row's node, then its knot time"""
         X = _f64(X).reshape(-1, self.nvars)
         B = X.shape[0]
         con = np.empty((B, self._nlin + self._nfn))
-        jfn = np.empty((B, self._nfn, 6)) if want_jac else None
+        jfn = np.empty((B, self._nfn, 7)) if want_jac else None
         rc = check(lib().gel_rows_eval(self._h, B, _d(X), _d(con), _d(jfn) if want_jac else None))
         return con, jfn, rc
 

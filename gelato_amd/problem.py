@@ -98,6 +98,7 @@ def build_pdict(vehicle, rows, knots, nodes, ps_params=None):
     # velocity of the ground there and the launcher's attitude: plain numbers in the vehicle file)
     condition = {"OptimizationMode": vehicle["OptimizationMode"]}
     condition.update(vehicle.get("TerminalCondition", {}))
+    condition.update(vehicle.get("FlightConstraint", {}))     # :169 (aero limits, waypoints, antennas)
     if "init" in vehicle:
         condition["init"] = {"mass": m_init, "position": np.array(vehicle["init"]["position"]),
                              "velocity": np.array(vehicle["init"]["velocity"]),

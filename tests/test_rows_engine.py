@@ -118,14 +118,14 @@ def test_rows_batch_device_api_and_nonfinite_status():
     B = 37
     X = problem.synthetic_batch(x0, E.M, B, seed=5)
     con, jfn, rc = E.rows_eval(X)
-    assert rc == 0 and con.shape == (B, R.nlin + R.nfn) and jfn.shape == (B, R.nfn, 6)
+    assert rc == 0 and con.shape == (B, R.nlin + R.nfn) and jfn.shape == (B, R.nfn, 7)
     for b in (0, 11, B - 1):                                 # element b of a batch == the single-vector call, bit for bit
         c1, j1, _ = E.rows_eval(X[b])
         assert np.array_equal(c1[0], con[b]) and np.array_equal(j1[0], jfn[b])
     dev = torch.device("cuda:0")
     dX = torch.from_numpy(X).to(dev)
     dcon = torch.empty((B, R.nlin + R.nfn), dtype=torch.float64, device=dev)
-    djfn = torch.empty((B, R.nfn, 6), dtype=torch.float64, device=dev)
+    djfn = torch.empty((B, R.nfn, 7), dtype=torch.float64, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     E.rows_eval_device(B, dX.data_ptr(), dcon.data_ptr(), djfn.data_ptr(), s)
     assert E.sync(s) == 0
@@ -137,7 +137,9 @@ def test_rows_batch_device_api_and_nonfinite_status():
     # the speed row: |v| / 1000 of SEIG's first node; its position columns are exact zeros
     node = pdict["ps_params"].index_start_x(pdict["event_index"]["SEIG"])
     v = X[0, 4 * E.M + 3 * node:4 * E.M + 3 * node + 3] * unitdict["velocity"]
-    assert abs(con[0, -1] - np.linalg.norm(v) / 1000.0) <= 1e-12 and np.all(jfn[0, -1, 0:3] == 0.0)
+    k = R.waypoint_base - 1                                   # the last user row (the waypoint rows follow them)
+    assert abs(con[0, R.nlin + k] - np.linalg.norm(v) / 1000.0) <= 1e-12 and np.all(jfn[0, k, 0:3] == 0.0)
+    assert np.all(jfn[0, k, 6] == 0.0)                        # and it does not read the knot time
     # non-finite input -> status 1, reported through the sticky status of the callbacks
     xb = x0.copy()
     xb[E.M + 3 * (E.M - 1)] = np.nan
