@@ -257,7 +257,7 @@ def main():
         except Exception:
             traffic = None
     info = E.launch_info(B, True, not a.residual_only)   # which instantiation the launcher picked
-    kname = "gel::eval_kernel<%s, %s, %s>" % tuple("true" if v else "false" for v in info[:3])
+    kname = "gel::eval_kernel<%s, %s, %s, %s>" % tuple("true" if v else "false" for v in (info[0], info[1], info[2], info[4]))
     out = {
         "metric": "residual+Jacobian evals/sec (and ms/eval), 6-phase x 64-node LGR mesh",
         "value": evals / T, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -68,7 +68,10 @@ struct ProblemDev {
   int32_t Kw, Kc;
   int32_t nchunks;           // sum over phases of ceil(n/64): wavefront work items per eval
   int32_t use_mfma;          // D.X on v_mfma_f64_16x16x4_f64 instead of VALU FMAs
+  int32_t pack;              // every phase has at most 32 nodes: the cooperative form carries two decision vectors per wavefront
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
+  int32_t nair;              // the first nair of the launch's nchunks work items belong to aerodynamic phases and the rest
+                             // to NoAir phases (whole launches: the list is sorted that way); -1: not known
   int32_t unit0, nunits;     // split form only: first unit and number of units (unit = 4 * work item + part)
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)
   const int4* chunks;        // [nchunks] {phase, first node of the chunk, offset of its MFMA-ordered D in Dsw / 4, 0}:

@@ -40,6 +40,17 @@ static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wav
 // wavefronts of its workgroup still write their tiles.
 constexpr int kCoopStageOff = PK_LV0 * 64;
 static_assert(kWaveLds - kCoopStageOff >= 64 * 11, "the cooperative hand-over area must fit behind the early park slots");
+// Residual-only instantiations park PK_Q0 .. PK_LV2 only: their region is the D.X operand image (cooperative LDS-staged
+// form: a 68-row slab, or two 36-row vectors when two decision vectors share a wavefront), the hand-over area over it and
+// then, once the wavefront has taken its rows, the park over that -- 6 KB instead of 9.5 KB per wavefront.
+constexpr int kSlabRowsMax = 68, kPackRows = 36, kParkRes = (PK_LV2 + 1) * 64;
+// The NoAir-only instantiations (also with the Jacobian) park the same slots: the same small region.
+constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack, bool noair = false) {
+  return (jac && !noair) ? kWaveLds : (!mfma ? kParkRes : (pack ? 2 * kPackRows * 11 : kSlabRowsMax * 11));
+}
+static_assert(wave_lds_doubles(false, true, true) >= 64 * 11 && wave_lds_doubles(false, true, false) >= 64 * 11, "hand-over area");
+static_assert(wave_lds_doubles(false, true, true) >= kParkRes && wave_lds_doubles(false, true, false) >= kParkRes, "residual-only park");
+static_assert(PK_DJJ < PK_LV2, "the small park holds quaternion, velocity, D[j][j+1] and the D.X row of the velocity defect");
 
 // Compact Jacobian slots of a node (gel_host.hip walk_pattern() maps them to the reference's COO entries).  Only
 // DISTINCT x-dependent values are stored: a tf column that is the exact negative of its t0 column, the node-uniform
@@ -54,6 +65,12 @@ constexpr int kSlotPT = 0, kSlotVM = 3, kSlotVP = 6;
 #ifndef GEL_MIN_WAVES_PER_SIMD
 #define GEL_MIN_WAVES_PER_SIMD 4  // 112 VGPRs, no scratch: 4 waves/SIMD (16 per CU, matching the LDS budget); 5 spills
 #endif
+#ifndef GEL_MIN_WAVES_PER_SIMD_NOAIR
+#define GEL_MIN_WAVES_PER_SIMD_NOAIR 5  // NoAir-only instantiations: 87 VGPRs, 24 KB of LDS per workgroup
+#endif
+#ifndef GEL_MIN_WAVES_PER_SIMD_RES
+#define GEL_MIN_WAVES_PER_SIMD_RES 5  // residual-only, two vectors per wavefront: 94 VGPRs, 25 KB of LDS per workgroup
+#endif
 
 typedef double gel_double4 __attribute__((ext_vector_type(4)));
 
@@ -65,6 +82,9 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef GEL_DX_PF_RES
 #define GEL_DX_PF_RES 4
+#endif
+#ifndef GEL_DX_PF_NOAIR
+#define GEL_DX_PF_NOAIR 1  // NoAir-only instantiation
 #endif
 
 #ifndef GEL_COOP_XLDS
@@ -80,24 +100,42 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 // becomes four wavefronts -- part 0 does everything except the three position sweeps, parts 1..3 do the
 // centre evaluation plus ONE position sweep each -- so the serial chain of a wavefront is about two trips of
 // the atmosphere/geodesy chain instead of four plus the light sweeps.  Same expressions, same bits.
-template <bool JAC, bool MFMA, bool SPLIT = false>
-__global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
+// PACK (cooperative form, every phase of the problem at most 32 nodes): a wavefront carries TWO decision vectors, one
+// per 32-lane half, and a workgroup eight -- otherwise half of the lanes (and two of the four D.X row tiles) idle.
+// NOAIR (cooperative form): the launch holds work items of NoAir phases only.  Their wavefronts do a quarter of the
+// arithmetic of an aerodynamic one and spend their life waiting -- on the operands of D.X and on the store stream; without
+// the aerodynamic chain the instantiation needs neither the tables nor the sweep park in LDS and half of the registers,
+// so more wavefronts share a SIMD.
+template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, bool NOAIR = false>
+__global__ __launch_bounds__(kBlock, NOAIR ? GEL_MIN_WAVES_PER_SIMD_NOAIR : ((!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : GEL_MIN_WAVES_PER_SIMD)) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   extern __shared__ double lds[];
-  const Tables tb = stage_tables(P, lds);
+  static_assert(!NOAIR || (MFMA && !SPLIT), "the NoAir-only instantiations exist in the cooperative form only");
+  const int park_off = NOAIR ? 0 : P.park_off;              // NOAIR: no tables in LDS
+  const Tables tb = NOAIR ? Tables{} : stage_tables(P, lds);
   const int lane = threadIdx.x & 63;
   // explicit LDS address space: ds_read/ds_write (lgkmcnt), never flat_* (which also ticks vmcnt)
   typedef __attribute__((address_space(3))) double lds_double;
-  lds_double* wave_lds = (lds_double*)lds + P.park_off + (threadIdx.x >> 6) * kWaveLds;
+  constexpr int kWL = wave_lds_doubles(JAC, MFMA, PACK, NOAIR);   // this instantiation's region per wavefront
+  constexpr int kHO = (JAC && !NOAIR) ? kCoopStageOff : 0;        // where the cooperative hand-over area starts in it
+  static_assert(!(MFMA && !SPLIT) || kWL - kHO >= 64 * 11, "the cooperative hand-over area must fit the region");
+  lds_double* wave_lds = (lds_double*)lds + park_off + (threadIdx.x >> 6) * kWL;
   lds_double* park = wave_lds + lane;
-#define PARK(slot) park[(slot) * 64]
+  // Residual-only instantiations have a smaller region (the D.X operand image / hand-over area only, see
+  // wave_lds_doubles()): once a wavefront has read its D.X rows from the hand-over area the region is private, and the
+  // few slots such a launch parks (PK_Q0 .. PK_LV2) overlay it.
+#define PARK_GET(slot) park[(slot) * 64]
+#define PARK_SET(slot, val) park[(slot) * 64] = (val)
 
   // COOP: the throughput form with D.X on the matrix pipe.  A workgroup = ONE work item x FOUR decision vectors;
   // its wavefronts share the A operand (D) and form the product together (see phase A).
   constexpr bool COOP = MFMA && !SPLIT;
   static_assert(!COOP || kBlock == 256, "the cooperative D.X form is written for four wavefronts per workgroup");
+  static_assert(!PACK || (COOP && GEL_COOP_XLDS != 0), "two vectors per wavefront exist in the cooperative LDS-staged form only");
+  constexpr int kVecWg = PACK ? 8 : 4;   // decision vectors per workgroup
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int nb4 = (B + 3) >> 2;  // COOP: workgroups per work item
+  const int half = PACK ? (lane >> 5) : 0;
+  const int nb4 = (B + kVecWg - 1) / kVecWg;  // COOP: workgroups per work item
   const long long item = COOP ? 0 : __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
   if (!COOP && item >= (long long)B * (SPLIT ? P.nunits : P.nchunks)) return;
   // work-item major: all B vectors of one (phase, chunk) are neighbours, so the four wavefronts of a
@@ -107,18 +145,19 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   // SPLIT: the list is walked in units = (work item, part), unit id = 4 * item + part, again with all B vectors
   // of a unit next to each other; P.unit0 / P.nunits select a range of units (unit-sharded launches)
   const int q = COOP ? (int)(blockIdx.x / (unsigned)nb4) : (int)(item / B);
-  const int b0 = COOP ? (int)(blockIdx.x - (unsigned)q * (unsigned)nb4) * 4 : 0;  // first vector of the workgroup
-  // COOP: a wavefront past the end of the batch (B not a multiple of 4) still computes its row tile for the
-  // others; it reads vector B - 1 and leaves after the hand-over without writing anything
-  const bool ghost = COOP && b0 + wv >= B;
-  const int b = COOP ? min(b0 + wv, B - 1) : (int)(item - (long long)q * B);
+  const int b0 = COOP ? (int)(blockIdx.x - (unsigned)q * (unsigned)nb4) * kVecWg : 0;  // first vector of the workgroup
+  // COOP: a wavefront (PACK: a half) past the end of the batch (B not a multiple of 4 / 8) still computes its tiles for
+  // the others; it reads vector B - 1 and leaves after the hand-over without writing anything
+  const int bw = PACK ? b0 + 2 * wv + half : b0 + wv;
+  const bool ghost = COOP && bw >= B;
+  const int b = COOP ? min(bw, B - 1) : (int)(item - (long long)q * B);
   const int ci = SPLIT ? ((P.unit0 + q) >> 2) : q;
   const int part = SPLIT ? ((P.unit0 + q) & 3) : 0;  // wave-uniform
   const int4 ck = P.chunks[(SPLIT ? 0 : P.chunk0) + ci];
   const int sec = __builtin_amdgcn_readfirstlane(ck.x);
   const int j0 = __builtin_amdgcn_readfirstlane(ck.y);
   const int dsw = __builtin_amdgcn_readfirstlane(ck.z);  // first gel_double4 of this work item in Dsw
-  const int j = j0 + lane;  // node inside the phase
+  const int j = PACK ? (lane & 31) : j0 + lane;  // node inside the phase (PACK: one chunk per phase, j0 = 0)
   const PhaseDev ph = load_phase(P.phases + sec);  // by value, in SGPRs, before any store
   if (SPLIT && part && !ph.air) return;  // only aerodynamic phases have the long position sweeps
   const bool lead = !(SPLIT && part);     // the wavefront that owns everything but the split-off sweeps
@@ -145,11 +184,12 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 
   double* rb = (res && lead) ? res + (size_t)b * 11 * N : nullptr;
 #ifdef GEL_ABL_NOSTORE  // ablation (tools/variant.sh): everything computed, (almost) nothing stored
-  double* jb = JAC ? jvar + (size_t)b * P.V + ph.voff + j : nullptr;
-#define EMIT(slot, val)                                   \
+  double* jb = JAC ? jvar + (size_t)b * P.V + ph.voff + (size_t)j0 * ph.K + (j - j0) : nullptr;
+  const int cw8 = min(64, n - j0) * 8;
+#define EMIT_AT(byteoff, val)                             \
   do {                                                    \
     const double _v = (val);                              \
-    if (_v == 1.2345e300) jb[(size_t)(slot) * n] = _v;    \
+    if (_v == 1.2345e300) jb[(byteoff) / 8] = _v;         \
     chk += _v;                                            \
   } while (0)
 #else
@@ -162,18 +202,22 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 #ifdef GEL_ABL_SAMEADDR  // ablation: every vector writes over vector 0's values (same instructions, L2-resident target)
       __builtin_amdgcn_make_buffer_rsrc(JAC ? (void*)(jvar + ph.voff + j0) : (void*)nullptr, 0, -1, 0x00020000);
 #else
-      __builtin_amdgcn_make_buffer_rsrc(JAC ? (void*)(jvar + (size_t)b * P.V + ph.voff + j0) : (void*)nullptr, 0, -1, 0x00020000);
+      // a phase's node values are laid out [64-node chunk][slot][node of the chunk]: this wavefront's block starts at j0 * K
+      __builtin_amdgcn_make_buffer_rsrc(JAC ? (void*)(jvar + (size_t)(PACK ? min(b0 + 2 * wv, B - 1) : b) * P.V + ph.voff + (size_t)j0 * ph.K) : (void*)nullptr,
+                                        0, -1, 0x00020000);
 #endif
-  const int jvo = lane * 8;
-#define EMIT(slot, val)                                                                 \
+  const int jvo = PACK ? (half * (int)P.V + j) * 8 : lane * 8;
+  const int cw8 = min(64, n - j0) * 8;   // bytes between two slots of this wavefront's block
+#define EMIT_AT(byteoff, val)                                                           \
   do {                                                                                  \
     const double _v = (val);                                                            \
     gel_u2 _d;                                                                          \
     __builtin_memcpy(&_d, &_v, 8);                                                      \
-    __builtin_amdgcn_raw_buffer_store_b64(_d, jrs, jvo, (int)(slot) * n * 8, GEL_STORE_AUX); \
+    __builtin_amdgcn_raw_buffer_store_b64(_d, jrs, jvo, (byteoff), GEL_STORE_AUX);      \
     chk += _v;                                                                          \
   } while (0)
 #endif
+#define EMIT(slot, val) EMIT_AT((int)(slot) * cw8, val)
 #ifdef GEL_ABL_NORES  // ablation: residual rows computed, not stored
 #define RSTORE(idx, val) do { if ((val) == 1.2345e300) rb[idx] = (val); } while (0)
 #else
@@ -193,7 +237,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
   // 8-byte global loads in the matrix loop.  Measured against fetching B per k-step from global memory (same box,
   // B = 16384 / 65536): fused launch -2 % at 6x64, residual-only -9 % at 3x32; with two slabs (n = 128) the extra
   // workgroup barriers cost what the loads save (residual-only +10 %), so longer phases keep the global form.
-  const bool XLDS = COOP && (GEL_COOP_XLDS != 0) && n < 68;   // wave-uniform
+  const bool XLDS = PACK || (COOP && (GEL_COOP_XLDS != 0) && n < 68);   // wave-uniform
   double me = 0.0, re[3] = {0.0, 0.0, 0.0};
   if (!XLDS) { me = xm[xj]; re[0] = xr[3 * xj]; re[1] = xr[3 * xj + 1]; re[2] = xr[3 * xj + 2]; }
   const double tau = P.tau[ph.toff + jc];
@@ -213,70 +257,63 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
     if (rb) {
       if (XLDS) {
-        // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP, operands as in the branch below, but B comes from LDS: in slabs of 68
-        // state rows (17 k-steps) every wavefront stages ITS OWN vector's rows -- lane = row, the eleven interleaved
-        // columns (mass | pos xyz | vel xyz | quat wxyz) side by side, [row][11] at the start of its park region --
-        // and all four read the 44 packed columns from there.  Eleven strided global loads per wavefront and slab instead
-        // of three per k-step, and the node's own state row is read back from the same image.
+        // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP, operands as in the branch below, but B comes from LDS: every wavefront
+        // stages ITS OWN vector's n + 1 <= 68 state rows (17 k-steps) -- lane = row, the eleven interleaved columns (mass |
+        // pos xyz | vel xyz | quat wxyz) side by side, [row][11] at the start of its region -- and all four read the 44
+        // packed columns from there.  Eleven strided global loads per wavefront instead of three per k-step, and the node's
+        // own state row is read back from the same image.
         const int c16 = lane & 15, kq = lane >> 4;
         constexpr int kSlabK = 17, kSlabRows = 4 * kSlabK;
-        static_assert(kSlabRows * 11 <= kWaveLds, "a slab of state rows must fit the wave's park region");
-        lds_double* regions = (lds_double*)lds + P.park_off;
+        static_assert(kSlabRows == kSlabRowsMax, "slab size");
+        static_assert(!COOP || kSlabRows * 11 <= kWL, "a slab of state rows must fit the wave's park region");
+        lds_double* regions = (lds_double*)lds + park_off;
+        // PACK: [32 x (n+1)] . [(n+1) x 88]: row tiles 0 and 1 only, six column tiles; wavefront w forms row tile w & 1 for
+        // column tiles 3 (w >> 1) .. + 2; vector v's image lies in wavefront v >> 1's region, half v & 1.
+        constexpr int kCols = 11 * kVecWg;
+        const int ct0 = PACK ? 3 * (wv >> 1) : 0;
         int xoff[3];
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
-          const int c = 16 * ct + c16;            // packed column: vector c / 11, state column c % 11
-          const int vb = min(c / 11, 3);          // columns 44..47 are padding: computed on vector 3, never read
-          xoff[ct] = vb * kWaveLds + ((c < 44) ? c - 11 * vb : 0) + kq * 11;
+          const int c = 16 * (ct0 + ct) + c16;    // packed column: vector c / 11, state column c % 11
+          const int vb = min(c / 11, kVecWg - 1); // the last columns are padding: computed on the last vector, never read
+          const int col = (c < kCols) ? c - 11 * vb : 0;
+          xoff[ct] = PACK ? (vb >> 1) * kWL + (vb & 1) * kPackRows * 11 + col + kq * 11 : vb * kWL + col + kq * 11;
         }
         gel_double4 acc[3];
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
-        const double* ap = P.Dst + (size_t)dsw * 4 + wv * 64 + lane;
-        const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4)
-        const int own = jc + 1;            // this lane's state row inside the phase
-        for (int s0 = 0; s0 < ksteps; s0 += kSlabK) {
-          const int kbase = 4 * s0;
-          if (s0) __syncthreads();         // every wavefront is done multiplying the previous slab
+        const double* ap = P.Dst + (size_t)dsw * 4 + (PACK ? (wv & 1) : wv) * 64 + lane;
+        const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4) <= kSlabK: the phase is one slab
 #pragma unroll
-          for (int it = 0; it < 2; it++) {
-            const int rr = lane + 64 * it;
-            if (rr < kSlabRows) {
-              const int k = kbase + rr;
-              lds_double* dst = wave_lds + rr * 11;
-              if (k <= n) {
-                const int xk = ph.xa + k;
-                dst[0] = xm[xk];
+        for (int it = 0; it < 2; it++) {
+          const int rr = lane + 64 * it;
+          if (rr < (PACK ? 2 * kPackRows : kSlabRows)) {
+            const int hv = PACK ? rr / kPackRows : 0;          // PACK: which of the wavefront's two vectors
+            const int k = PACK ? rr - kPackRows * hv : rr;
+            const double* xs = PACK ? x + (size_t)min(b0 + 2 * wv + hv, B - 1) * P.nvars : xb;
+            lds_double* dst = wave_lds + rr * 11;
+            if (k <= n) {
+              const int xk = ph.xa + k;
+              dst[0] = xs[xk];
 #pragma unroll
-                for (int c = 0; c < 3; c++) { dst[1 + c] = xr[3 * xk + c]; dst[4 + c] = xv[3 * xk + c]; }
+              for (int c = 0; c < 3; c++) { dst[1 + c] = xs[M + 3 * xk + c]; dst[4 + c] = xs[4 * M + 3 * xk + c]; }
 #pragma unroll
-                for (int c = 0; c < 4; c++) dst[7 + c] = xq[4 * xk + c];
-              } else {  // rows past the phase meet zero columns of D: any finite value
+              for (int c = 0; c < 4; c++) dst[7 + c] = xs[7 * M + 4 * xk + c];
+            } else {  // rows past the phase meet zero columns of D: any finite value
 #pragma unroll
-                for (int c = 0; c < 11; c++) dst[c] = 0.0;
-              }
+              for (int c = 0; c < 11; c++) dst[c] = 0.0;
             }
           }
-          __syncthreads();
-          {
-            const int ol = own - kbase;     // the node's own state row, if it lies in this slab
-            if (ol >= 0 && ol < kSlabRows) {
-              lds_double* src = wave_lds + ol * 11;
-              me = src[0];
-#pragma unroll
-              for (int c = 0; c < 3; c++) { re[c] = src[1 + c]; ve[c] = src[4 + c]; }
-#pragma unroll
-              for (int c = 0; c < 4; c++) q[c] = src[7 + c];
-            }
-          }
-          const int kcount = min(kSlabK, ksteps - s0);
-          double a = ap[s0 * 256];
+        }
+        __syncthreads();
+        {
+          double a = ap[0];
 #ifdef GEL_ABL_NODX
           for (int ks = 0; ks < 0; ks++) {
 #else
-          for (int ks = 0; ks < kcount; ks++) {
+          for (int ks = 0; ks < ksteps; ks++) {
 #endif
-            const double a_next = ap[min(s0 + ks + 1, ksteps - 1) * 256];   // the next k-step's A slab is on its way
+            const double a_next = ap[min(ks + 1, ksteps - 1) * 256];       // the next k-step's A slab is on its way
             const int ro = ks * 44;                                          // 4 rows of 11 columns per k-step
             const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl0, acc[0], 0, 0, 0);
@@ -285,26 +322,40 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
             a = a_next;
           }
         }
+        {
+          // the node's own state row comes from the same image (after the product: nothing of it is live across the loop)
+          lds_double* src = wave_lds + (half * kPackRows + jc + 1) * 11;
+          me = src[0];
+#pragma unroll
+          for (int c = 0; c < 3; c++) { re[c] = src[1 + c]; ve[c] = src[4 + c]; }
+#pragma unroll
+          for (int c = 0; c < 4; c++) q[c] = src[7 + c];
+        }
         __syncthreads();                   // the hand-over area overlaps the state-row image: everyone is done reading it
-        lds_double* wg_lds = regions + kCoopStageOff;
+        lds_double* wg_lds = regions + kHO;
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
-          const int c = 16 * ct + c16;
+          const int c = 16 * (ct0 + ct) + c16;
           const int vb = c / 11, col = c - 11 * vb;
-          if (c < 44) {
+          if (c < kCols) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) wg_lds[vb * kWaveLds + (16 * wv + kq + 4 * i) * 11 + col] = acc[ct][i];
+            for (int i = 0; i < 4; i++) {
+              if (PACK)   // node 16 (w & 1) + .. of vector vb -> lane 32 (vb & 1) + node of wavefront vb >> 1
+                wg_lds[(vb >> 1) * kWL + (32 * (vb & 1) + 16 * (wv & 1) + kq + 4 * i) * 11 + col] = acc[ct][i];
+              else
+                wg_lds[vb * kWL + (16 * wv + kq + 4 * i) * 11 + col] = acc[ct][i];
+            }
           }
         }
         __syncthreads();
         if (ghost) return;
-        lds_double* row = wave_lds + kCoopStageOff + lane * 11;
+        lds_double* row = wave_lds + kHO + lane * 11;
         lm = row[0];
 #pragma unroll
         for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
 #pragma unroll
         for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
-      } else if (COOP) {
+      } else if (COOP && !PACK) {
         // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP: A = the work item's rows of D, shared by all four wavefronts;
         // B = the 11 state columns of the workgroup's four decision vectors side by side (44 of 48 columns used,
         // against 11 of 16 when every wavefront multiplies alone).  Wavefront w forms row tile w (16 nodes) for all
@@ -337,7 +388,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         // Software pipeline: the operands of k-step ks + kPF are requested while k-step ks multiplies.  Without
         // it every k-step waits a full memory latency (x comes from HBM on first touch) before its three MFMAs.
         // Requests past the last k-step repeat it (valid addresses, results unused).
-        constexpr int kPF = JAC ? GEL_DX_PF_JAC : GEL_DX_PF_RES;
+        constexpr int kPF = NOAIR ? GEL_DX_PF_NOAIR : (JAC ? GEL_DX_PF_JAC : GEL_DX_PF_RES);
         double ra[kPF], rb0[kPF], rb1[kPF], rb2[kPF];
 #define GEL_DX_LOAD(slot, kstep)                                  \
   do {                                                            \
@@ -367,19 +418,19 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         }
 #undef GEL_DX_LOAD
         // hand-over: the rows of vector vb go to wavefront vb's own region ([node][11] behind its early park slots)
-        lds_double* wg_lds = (lds_double*)lds + P.park_off + kCoopStageOff;
+        lds_double* wg_lds = (lds_double*)lds + park_off + kHO;
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
           const int c = 16 * ct + c16;
           const int vb = c / 11, col = c - 11 * vb;
           if (c < 44) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) wg_lds[vb * kWaveLds + (16 * wv + kq + 4 * i) * 11 + col] = acc[ct][i];
+            for (int i = 0; i < 4; i++) wg_lds[vb * kWL + (16 * wv + kq + 4 * i) * 11 + col] = acc[ct][i];
           }
         }
         __syncthreads();
         if (ghost) return;
-        lds_double* row = wave_lds + kCoopStageOff + lane * 11;
+        lds_double* row = wave_lds + kHO + lane * 11;
         lm = row[0];
 #pragma unroll
         for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
@@ -446,10 +497,10 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     if (MFMA && !active) return;  // ragged tail: nothing to write
     // the staging tile has been consumed: the region now becomes the park of what the velocity group
     // needs late (its sweeps re-read quaternion, velocity and D[j][j+1]; its defect needs the D.X row)
-    PARK(PK_Q0) = q[0]; PARK(PK_Q1) = q[1]; PARK(PK_Q2) = q[2]; PARK(PK_Q3) = q[3];
-    PARK(PK_V0) = ve[0]; PARK(PK_V1) = ve[1]; PARK(PK_V2) = ve[2];
-    if (JAC) PARK(PK_DJJ) = djj;
-    if (rb) { PARK(PK_LV0) = lv[0]; PARK(PK_LV1) = lv[1]; PARK(PK_LV2) = lv[2]; }
+    PARK_SET(PK_Q0, q[0]); PARK_SET(PK_Q1, q[1]); PARK_SET(PK_Q2, q[2]); PARK_SET(PK_Q3, q[3]);
+    PARK_SET(PK_V0, ve[0]); PARK_SET(PK_V1, ve[1]); PARK_SET(PK_V2, ve[2]);
+    if (JAC) PARK_SET(PK_DJJ, djj);
+    if (rb) { PARK_SET(PK_LV0, lv[0]); PARK_SET(PK_LV1, lv[1]); PARK_SET(PK_LV2, lv[2]); }
     // last global loads: the reference rows of engine-off / hold phases
     const double m0 = (rb && !ph.engine_on) ? xm[ph.xa] : 0.0;
     double q0[4] = {0, 0, 0, 0};
@@ -462,7 +513,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     //      position Jacobian entries, the whole quaternion group (:155-213, :499-632) ----
     if (JAC && lead) {
       // pos/velocity diagonal (:190-196): the same value for every node and component -> one scalar per phase
-      if (j == 0) EMIT(ph.K, -P.uv * (tf - to) * ut / 2.0 / P.up);
+      if (j == 0) EMIT_AT(ph.K * n * 8, -P.uv * (tf - to) * ut / 2.0 / P.up);   // behind all chunks' blocks of the phase
 #pragma unroll
       for (int c = 0; c < 3; c++) EMIT(kSlotPT + c, ve[c] * P.uv * ut / 2.0 / P.up);  // t0 column; tf = its negative
     }
@@ -541,7 +592,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
     const double tn = tau * (tf - to) / 2 + (tf + to) / 2;  // PSparams.time_nodes, SectionParameters.py:77-81
     const double inv_m = frcp(me * P.um);
 
-    if (ph.air) {
+    if (!NOAIR && ph.air) {
       const EarthAngle ea = earth_angle(tn);  // position sweeps do not change it
       // Trips k = 0,1,2: position sweeps (pos_k + dx); trip k = 3: centre, leaves by break.  Nothing but
       // the node position, the Earth angle and 1/m stays in registers across a trip: velocity and thrust
@@ -560,11 +611,11 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         pp = pos_part(r, tb, P.barC20);
         wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
 #pragma unroll
-        for (int c = 0; c < 3; c++) v[c] = PARK(PK_V0 + c) * P.uv;
+        for (int c = 0; c < 3; c++) v[c] = PARK_GET(PK_V0 + c) * P.uv;
         aero_force(r, v, pp.rho, pp.inv_a, ea, w, ph.area, tb, F);
         T = ph.thrust - ph.nozzle * pp.P;
         {
-          const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
+          const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
           thrust_dir(q, dir);
         }
         const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
@@ -573,10 +624,10 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         // park the sweep result (9 values: 8 LDS slots + one register)
         if (k < 2) {
 #pragma unroll
-          for (int c = 0; c < 3; c++) PARK(PK_FP0 + 3 * k + c) = fc[c];
+          for (int c = 0; c < 3; c++) PARK_SET(PK_FP0 + 3 * k + c, fc[c]);
         } else {
-          PARK(PK_FP6) = fc[0];
-          PARK(PK_FP7) = fc[1];
+          PARK_SET(PK_FP6, fc[0]);
+          PARK_SET(PK_FP7, fc[1]);
           fp8 = fc[2];
         }
       }
@@ -587,20 +638,20 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           const int i = 3 * k + c;
-          EMIT(kSlotVP + i, FDQ((i < 8) ? PARK(PK_FP0 + i) : fp8, fc[c]));
+          EMIT(kSlotVP + i, FDQ((i < 8) ? PARK_GET(PK_FP0 + i) : fp8, fc[c]));
         }
       }
       if (JAC && lead) {
         if (!SPLIT) {
 #pragma unroll
-          for (int i = 0; i < 8; i++) EMIT(kSlotVP + i, FDQ(PARK(PK_FP0 + i), fc[i % 3]));
+          for (int i = 0; i < 8; i++) EMIT(kSlotVP + i, FDQ(PARK_GET(PK_FP0 + i), fc[i % 3]));
           EMIT(kSlotVP + 8, FDQ(fp8, fc[2]));
         }
 
         // The position-sweep slots are free now.  Values that only LATER blocks need leave the registers:
         // the t0/tf sweeps' inputs (half-latitude pair, 1/p, wind) and the centre aero force.
-        PARK(PK_FP0) = pp.shp; PARK(PK_FP1) = pp.chp; PARK(PK_FP2) = pp.inv_p; PARK(PK_FP3) = pp.wn; PARK(PK_FP4) = pp.we;
-        PARK(PK_FP5) = F[0]; PARK(PK_FP6) = F[1]; PARK(PK_FP7) = F[2];
+        PARK_SET(PK_FP0, pp.shp); PARK_SET(PK_FP1, pp.chp); PARK_SET(PK_FP2, pp.inv_p); PARK_SET(PK_FP3, pp.wn); PARK_SET(PK_FP4, pp.we);
+        PARK_SET(PK_FP5, F[0]); PARK_SET(PK_FP6, F[1]); PARK_SET(PK_FP7, F[2]);
         asm volatile("" ::: "memory");
 
         const double r[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
@@ -608,12 +659,12 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
         double f[3];
         // velocity sweeps: only the aerodynamic force changes
         if (ph.air_fd) {
-          const double djj = PARK(PK_DJJ);
+          const double djj = PARK_GET(PK_DJJ);
 #pragma unroll 1
           for (int k = 0; k < 3; k++) {
             double vp[3], Fp[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) vp[c] = ((k == c) ? (PARK(PK_V0 + c) + dx) : PARK(PK_V0 + c)) * P.uv;
+            for (int c = 0; c < 3; c++) vp[c] = ((k == c) ? (PARK_GET(PK_V0 + c) + dx) : PARK_GET(PK_V0 + c)) * P.uv;
             aero_force(r, vp, pp.rho, pp.inv_a, ea, w, ph.area, tb, Fp);
             accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
             // submat_vel[3j+c, 3(j+1)+k] = D[j][j+1]*(c==k) + rh_vel   (con_dynamics.py:341-343,415-416)
@@ -621,10 +672,10 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
             for (int c = 0; c < 3; c++) EMIT(ph.s_vv + 3 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fc[c]));
           }
         }
-        const double Fc[3] = {PARK(PK_FP5), PARK(PK_FP6), PARK(PK_FP7)};
+        const double Fc[3] = {PARK_GET(PK_FP5), PARK_GET(PK_FP6), PARK_GET(PK_FP7)};
         // quaternion sweeps: only the thrust direction changes
         {
-          const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
+          const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
 #pragma unroll 1
           for (int k = 0; k < 4; k++) {
             double qp[4];
@@ -647,8 +698,8 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
           // quaternion, D[j][j+1] and force slots are free now: the rest of what these two sweeps need is
           // parked there, so that only the node position lives in registers across the sincos chains of
           // earth_angle()
-          PARK(PK_Q0) = pp.rho; PARK(PK_Q1) = pp.inv_a; PARK(PK_Q2) = Tdc[0]; PARK(PK_Q3) = Tdc[1]; PARK(PK_DJJ) = Tdc[2];
-          PARK(PK_FP5) = pp.g[0]; PARK(PK_FP6) = pp.g[1]; PARK(PK_FP7) = pp.g[2];
+          PARK_SET(PK_Q0, pp.rho); PARK_SET(PK_Q1, pp.inv_a); PARK_SET(PK_Q2, Tdc[0]); PARK_SET(PK_Q3, Tdc[1]); PARK_SET(PK_DJJ, Tdc[2]);
+          PARK_SET(PK_FP5, pp.g[0]); PARK_SET(PK_FP6, pp.g[1]); PARK_SET(PK_FP7, pp.g[2]);
 #pragma unroll 1
           for (int k = 0; k < 2; k++) {
             asm volatile("" ::: "memory");  // re-read the park inside every trip
@@ -658,11 +709,11 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
             const EarthAngle eq = earth_angle(tnp);
             double wq[3], Fp[3];
             const double rq[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
-            wind_eci(rq, eq, PARK(PK_FP0), PARK(PK_FP1), PARK(PK_FP2), PARK(PK_FP3), PARK(PK_FP4), wq);
-            const double vq[3] = {PARK(PK_V0) * P.uv, PARK(PK_V1) * P.uv, PARK(PK_V2) * P.uv};
-            aero_force(rq, vq, PARK(PK_Q0), PARK(PK_Q1), eq, wq, ph.area, tb, Fp);
-            const double Tq[3] = {PARK(PK_Q2), PARK(PK_Q3), PARK(PK_DJJ)};
-            const double gq[3] = {PARK(PK_FP5), PARK(PK_FP6), PARK(PK_FP7)};
+            wind_eci(rq, eq, PARK_GET(PK_FP0), PARK_GET(PK_FP1), PARK_GET(PK_FP2), PARK_GET(PK_FP3), PARK_GET(PK_FP4), wq);
+            const double vq[3] = {PARK_GET(PK_V0) * P.uv, PARK_GET(PK_V1) * P.uv, PARK_GET(PK_V2) * P.uv};
+            aero_force(rq, vq, PARK_GET(PK_Q0), PARK_GET(PK_Q1), eq, wq, ph.area, tb, Fp);
+            const double Tq[3] = {PARK_GET(PK_Q2), PARK_GET(PK_Q3), PARK_GET(PK_DJJ)};
+            const double gq[3] = {PARK_GET(PK_FP5), PARK_GET(PK_FP6), PARK_GET(PK_FP7)};
             accel(Tq, Fp, inv_m, gq, inv_uv, f);
             // -(f_p*(tf_p - to_p) - f_c*(tf - to))/dx*unit_t/2   (con_dynamics.py:463-477)
 #pragma unroll
@@ -679,7 +730,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
       const double T = ph.thrust;
       double dir[3];
       {
-        const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
+        const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
         thrust_dir(q, dir);
       }
       const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
@@ -704,7 +755,7 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 #pragma unroll
           for (int c = 0; c < 3; c++) EMIT(kSlotVP + 3 * k + c, FDQ(f[c], fc[c]));
         }
-        const double q[4] = {PARK(PK_Q0), PARK(PK_Q1), PARK(PK_Q2), PARK(PK_Q3)};
+        const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
           double qp[4];
@@ -726,16 +777,18 @@ __global__ __launch_bounds__(kBlock, GEL_MIN_WAVES_PER_SIMD) void eval_kernel(Pr
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       const double rh = fc[c] * (tf - to) * ut / 2.0;
-      const double cv = PARK(PK_LV0 + c) - rh;
+      const double cv = PARK_GET(PK_LV0 + c) - rh;
       RSTORE(4 * N + 3 * g + c, cv);
       chk += cv;
     }
   }
 
 #undef EMIT
+#undef EMIT_AT
 #undef RSTORE
 #undef FDQ
-#undef PARK
+#undef PARK_GET
+#undef PARK_SET
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 

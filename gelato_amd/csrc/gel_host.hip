@@ -206,11 +206,18 @@ using Visitor = std::function<void(int block, int64_t k, int32_t row, int32_t co
 
 // Walks all 13 blocks in the reference's emission order (lib/con_dynamics.py:66-113,
 // 155-213,292-496,536-632).  k is the index inside the block.
-// Compact slots: see gel_eval_kernel.h (kSlotPT ...); the per-phase scalar sits at voff + K * n.
+// Compact slots: see gel_eval_kernel.h (kSlotPT ...).  Layout of a phase's K * n node values: 64-node chunk major,
+// [chunk][slot][node of the chunk] -- everything one wavefront writes is one contiguous block (a [slot][n] layout makes a
+// wavefront of a phase above 64 nodes write 512 bytes out of every n * 8: measured 8 % slower on 12 x 128).  The per-phase
+// scalar sits behind them at voff + K * n.
+static inline int64_t compact_index(const HostPhase& h, int slot, int j) {
+  const int j0 = j & ~63, w = std::min(64, h.n - j0);
+  return h.voff + (int64_t)j0 * h.K + (int64_t)slot * w + (j - j0);
+}
 void walk_pattern(const gel_problem& P, const Visitor& vis) {
   const int S = (int)P.ph.size();
   int64_t k[GEL_NUM_BLOCKS] = {0};
-  auto cs = [&](const HostPhase& h, int slot, int j) { return h.voff + (int64_t)slot * h.n + j; };
+  auto cs = [&](const HostPhase& h, int slot, int j) { return compact_index(h, slot, j); };
   for (int i = 0; i < S; i++) {
     const HostPhase& h = P.ph[i];
     const int n = h.n, ua = h.ua, xa = h.xa;
@@ -787,17 +794,24 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   dv.phases = p->d_phases; dv.node_phase = p->d_node_phase; dv.Dt = p->d_Dt; dv.tau = p->d_tau; dv.tables = p->d_tables;
   dv.flag = p->d_flag;
   dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks_sorted; dv.Dsw = p->d_Dsw; dv.Dst = p->d_Dst;
+  dv.nair = 0;
+  for (const int4& c : sorted_chunks) dv.nair += p->ph[c.x].air ? 1 : 0;   // sorted: aerodynamic work items first
+  if (d->flags & GEL_FLAG_ONE_KERNEL) dv.nair = -1;
   dv.park_off = (int32_t)((tables.size() + 1) / 2 * 2);
   {
     // D.X path.  fp64 MFMA and fp64 VALU instructions share the SIMD's fp64 datapath on this part (measured: their busy
     // times add up), so the matrix pipe is not free throughput; what it buys is fewer issue slots and the
-    // cooperative form (four decision vectors side by side, 44 of 48 tile columns used, a quarter of the D traffic).  It
-    // wins from 32 nodes per phase on and loses below, where a 16-row tile is mostly padding (same-box A/B, evals/s at
-    // B = 32768, MFMA vs VALU: 3x8 51.8 M vs 53.0 M, 3x16 48.5 M vs 49.1 M, 3x32 41.6 M vs 40.1 M, 6x64 13.9 M vs 12.7 M;
-    // residual-only 3x32 97.7 M vs 91.3 M, 6x64 31.3 M vs 21.4 M; tools/dx_paths.sh).  GEL_FLAG_DX_VALU / _MFMA force a path.
+    // cooperative form: four decision vectors side by side (44 of 48 tile columns used, a quarter of the D traffic), and --
+    // when every phase fits 32 lanes -- two decision vectors per wavefront, which no wavefront dot-product form offers.
+    // Same-box A/B, evals/s at B = 32768, matrix pipe vs VALU (tools/dx_paths.sh): 3x8 97.2 M vs 53.3 M, 3x16 77.7 M vs
+    // 49.1 M, 3x32 55.2 M vs 40.1 M, 6x64 13.9 M vs 12.7 M; residual-only 3x8 265 M vs 163 M, 3x16 217 M vs 129 M, 3x32
+    // 161 M vs 91 M, 6x64 31.3 M vs 21.4 M.  Between 33 and 63 nodes per phase the matrix pipe wins as well (one vector per
+    // wavefront).  Only a mesh that mixes phases above 32 nodes with many tiny ones would prefer the dot-products; none
+    // of the reference's configurations does.  GEL_FLAG_DX_VALU / _MFMA force a path.
     int nmax = 0;
     for (int i = 0; i < S; i++) nmax = std::max(nmax, p->ph[i].n);
-    dv.use_mfma = (d->flags & GEL_FLAG_DX_VALU) ? 0 : ((d->flags & GEL_FLAG_DX_MFMA) ? 1 : (nmax >= 32));
+    dv.use_mfma = (d->flags & GEL_FLAG_DX_VALU) ? 0 : 1;
+    dv.pack = (nmax <= 32) && !(d->flags & GEL_FLAG_NO_PACK);
   }
   dv.um = p->um; dv.up = p->up; dv.uv = p->uv; dv.uu = p->uu; dv.ut = p->ut; dv.dx = p->dx; dv.barC20 = p->barC20;
   *out = p;
@@ -929,6 +943,7 @@ int gel_eval_shard_device(gel_problem* p, int32_t B, const double* d_x, double* 
   if (chunk_count == 0) return GEL_OK;
   gel::ProblemDev dv = p->dev;
   dv.chunks = p->d_chunks;  // shard ranges index the phase-ordered list
+  dv.nair = -1;
   dv.chunk0 = chunk_begin;
   dv.nchunks = chunk_count;
   HIPCHK(gel::launch_eval(dv, B, d_x, d_res, d_jvar, stream ? (hipStream_t)stream : p->stream));
@@ -945,6 +960,7 @@ int gel_eval_shard_units_device(gel_problem* p, int32_t B, const double* d_x, do
   if (unit_count == 0) return GEL_OK;
   gel::ProblemDev dv = p->dev;
   dv.chunks = p->d_chunks;  // unit ids refer to the phase-ordered list
+  dv.nair = -1;
   dv.chunk0 = 0;
   dv.unit0 = unit_begin;
   dv.nunits = unit_count;
@@ -969,6 +985,7 @@ int gel_launch_info(const gel_problem* p, int32_t B, int32_t want_res, int32_t w
   NEED_DEVICE(p);
   const gel::EvalForm f = gel::eval_form(p->dev, B, want_res != 0, want_jac != 0);
   info[0] = f.jac; info[1] = f.mfma; info[2] = f.split; info[3] = (int32_t)std::min<long long>(f.waves, INT32_MAX);
+  info[4] = f.pack; info[5] = f.two_kernels;
   return GEL_OK;
 }
 
@@ -990,7 +1007,7 @@ int gel_unit_owner(const gel_problem* p, int32_t* res_owner, int32_t* jvar_owner
         for (int c = 0; c < 4; c++) res_owner[7 * N + 4 * g + c] = 4 * item;
         for (int s = 0; s < h.K; s++) {
           const int part = (h.air && s >= 6 && s < 15) ? 1 + (s - 6) / 3 : 0;
-          jvar_owner[h.voff + (int64_t)s * h.n + j] = 4 * item + part;
+          jvar_owner[compact_index(h, s, j)] = 4 * item + part;
         }
       }
       if (j0 == 0) jvar_owner[h.voff + (int64_t)h.K * h.n] = 4 * item;
@@ -1063,7 +1080,7 @@ int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) {
       gel::ProblemDev dv = p->dev;   // the phase as a one-phase problem: same tables, D, tau; local index space
       dv.S = 1; dv.N = n; dv.M = n + 1; dv.nvars = nloc; dv.V = 0;
       dv.phases = p->d_subphases + i;
-      dv.chunks = p->d_subchunks + p->sub_chunk0[i]; dv.nchunks = p->sub_nchunks[i]; dv.chunk0 = 0;
+      dv.chunks = p->d_subchunks + p->sub_chunk0[i]; dv.nchunks = p->sub_nchunks[i]; dv.chunk0 = 0; dv.nair = -1;
       HIPCHK(gel::launch_perturb_local(nloc, p->dx, p->jfd_x, p->d_colmap + p->sub_col0[i], p->jfd_Xp, p->stream));
       HIPCHK(gel::launch_eval(dv, nloc + 1, p->jfd_Xp, p->jfd_res + p->sub_res0[i], nullptr, p->stream));
     }

@@ -612,6 +612,10 @@ constexpr long long kSplitMaxWaves = 1024;
 
 static size_t table_lds_bytes(int Kw, int Kc) { return sizeof(double) * staged_table_doubles(Kw, Kc); }
 
+// NoAir work items get their own launch (NoAir-only instantiation) from this many of their wavefronts on: below it the
+// second launch's fixed cost and its own tail outweigh the gain
+constexpr long long kTwoKernelMinWaves = 4096;
+
 // which instantiation a launch takes (also reported through gel_launch_info)
 EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
   EvalForm f;
@@ -622,17 +626,52 @@ EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
   // a handful of vectors cannot fill 1024 SIMDs: trade recomputation of the centre for a shorter serial chain;
   // P.nunits > 0: the caller asked for a range of units (unit-sharded launch)
   f.split = want_jac && (P.nunits > 0 || waves * 4 <= kSplitMaxWaves);
-  f.waves = f.split ? (long long)B * (P.nunits > 0 ? P.nunits : 4 * P.nchunks) : waves;
+  // two decision vectors per wavefront: cooperative form (matrix pipe, not split) of a problem whose phases all fit 32 lanes
+  f.pack = f.mfma && !f.split && P.pack;
+  const int vw = f.pack ? 8 : 4;   // decision vectors per workgroup of the cooperative form
+  f.waves = f.split ? (long long)B * (P.nunits > 0 ? P.nunits : 4 * P.nchunks)
+                    : (f.mfma ? 4LL * P.nchunks * ((B + vw - 1) / vw) : waves);
+  // cooperative form with the Jacobian, both phase types present, enough NoAir wavefronts to fill the chip: the NoAir
+  // work items run in the NoAir-only instantiation (more wavefronts per SIMD), as a launch of their own
+  f.two_kernels = f.jac && f.mfma && !f.split && P.nair > 0 && P.nair < P.nchunks &&
+                  4LL * (P.nchunks - P.nair) * ((B + vw - 1) / vw) >= kTwoKernelMinWaves;
   return f;
+}
+
+template <bool JAC, bool PACK, bool NOAIR>
+static void launch_coop(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
+  const unsigned grid = (unsigned)P.nchunks * (unsigned)((B + (PACK ? 7 : 3)) / (PACK ? 8 : 4));
+  const size_t lds = sizeof(double) * ((NOAIR ? (size_t)0 : (size_t)P.park_off) + (size_t)wave_lds_doubles(JAC, true, PACK, NOAIR) * (kBlock / 64));
+  hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK, NOAIR>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
 }
 
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
   if (B <= 0) return hipSuccess;
   const EvalForm f = eval_form(P, B, d_res != nullptr, d_jvar != nullptr);
-  // cooperative D.X form (matrix pipe, not split): one workgroup = one work item x four decision vectors
-  const unsigned grid = (f.mfma && !f.split) ? (unsigned)P.nchunks * (unsigned)((B + 3) / 4)
-                                             : (unsigned)((f.waves * 64 + kBlock - 1) / kBlock);
-  const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)PK_COUNT * kBlock);  // tables | per-lane park
+  if (f.mfma && !f.split) {
+    // cooperative D.X form (matrix pipe, not split): one workgroup = one work item x four (PACK: eight) decision vectors
+    if (f.two_kernels) {
+      // NoAir items first: their wavefronts are short, so the launch drains quickly before the long ones start
+      ProblemDev Q = P;
+      Q.chunk0 = P.chunk0 + P.nair; Q.nchunks = P.nchunks - P.nair; Q.nair = 0;
+      if (f.pack) launch_coop<true, true, true>(Q, B, d_x, d_res, d_jvar, s);
+      else launch_coop<true, false, true>(Q, B, d_x, d_res, d_jvar, s);
+      Q = P;
+      Q.nchunks = P.nair;
+      if (f.pack) launch_coop<true, true, false>(Q, B, d_x, d_res, d_jvar, s);
+      else launch_coop<true, false, false>(Q, B, d_x, d_res, d_jvar, s);
+    } else if (f.jac) {
+      if (f.pack) launch_coop<true, true, false>(P, B, d_x, d_res, d_jvar, s);
+      else launch_coop<true, false, false>(P, B, d_x, d_res, d_jvar, s);
+    } else {
+      if (f.pack) launch_coop<false, true, false>(P, B, d_x, d_res, d_jvar, s);
+      else launch_coop<false, false, false>(P, B, d_x, d_res, d_jvar, s);
+    }
+    return hipGetLastError();
+  }
+  const unsigned grid = (unsigned)((f.waves * 64 + kBlock - 1) / kBlock);
+  // tables | one region per wavefront (the park, or only what a residual-only launch parks)
+  const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(f.jac, f.mfma, false) * (kBlock / 64));
   if (f.split) {
     ProblemDev Q = P;
     if (Q.nunits <= 0) { Q.unit0 = 4 * P.chunk0; Q.nunits = 4 * P.nchunks; }  // the whole list, split
@@ -642,12 +681,8 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
       hipLaunchKernelGGL((eval_kernel<true, false, true>), dim3(grid), dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
     return hipGetLastError();
   }
-  if (f.jac && f.mfma)
-    hipLaunchKernelGGL((eval_kernel<true, true>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
-  else if (f.jac)
+  if (f.jac)
     hipLaunchKernelGGL((eval_kernel<true, false>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
-  else if (f.mfma)
-    hipLaunchKernelGGL((eval_kernel<false, true>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
   else
     hipLaunchKernelGGL((eval_kernel<false, false>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
   return hipGetLastError();

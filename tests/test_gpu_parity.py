@@ -417,6 +417,54 @@ def test_cooperative_dx_form_equals_single_vector_calls(name, Bs):
     assert E.launch_info(Bmax, True, False)[2] == 0 and E.launch_info(1)[2] == 1
 
 
+@pytest.mark.parametrize("name", ["3x32", "example", "3x16"])
+def test_two_vectors_per_wavefront_equal_one_vector_per_wavefront(name):
+    """Problems whose phases all have <= 32 nodes carry two decision vectors per wavefront (eight per workgroup) in the
+    cooperative matrix-pipe form.  Same product, same order of accumulation: every batch size around the multiples of
+    eight gives the bits of the one-vector-per-wavefront form (GEL_FLAG_NO_PACK), nothing is written behind the batch."""
+    import torch
+    from gelato_amd import Engine, problem
+    prob, x0, _ = named_problem(name)
+    Ep = Engine(prob, flags=1)        # matrix pipe; packed because every phase fits 32 lanes
+    E1 = Engine(prob, flags=1 | 4)    # GEL_FLAG_NO_PACK
+    assert Ep.launch_info(1024)[4] == 1 and E1.launch_info(1024)[4] == 0 and Ep.launch_info(64, True, False)[4] == 1
+    assert Ep.launch_info(1024)[3] * 2 == E1.launch_info(1024)[3]
+    assert Ep.launch_info(1)[2] == 1 and Ep.launch_info(1)[4] == 0            # the split latency form never packs
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    Bs = (7, 8, 9, 15, 16, 17, 100, 1001, 1003)
+    X = problem.synthetic_batch(x0, Ep.M, max(Bs), seed=21)
+    compared_jac = 0
+    for B in Bs:
+        dX = torch.from_numpy(X[:B].copy()).to(dev)
+        split = bool(Ep.launch_info(B)[2])                                     # small batches: the fused launch splits instead
+        out = []
+        for E in (Ep, E1):
+            dres = torch.full((B + 1, E.nres), -7.0, dtype=torch.float64, device=dev)
+            djv = torch.full((B + 1, E.V), -7.0, dtype=torch.float64, device=dev)
+            dres2 = torch.full((B + 1, E.nres), -7.0, dtype=torch.float64, device=dev)
+            E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), s)
+            E.eval_batch_device(B, dX.data_ptr(), dres2.data_ptr(), 0, s)      # residual-only launches never split
+            assert E.sync(s) == 0
+            out.append((dres.cpu().numpy(), djv.cpu().numpy(), dres2.cpu().numpy()))
+        for o in out:
+            assert np.all(o[0][B] == -7.0) and np.all(o[1][B] == -7.0) and np.all(o[2][B] == -7.0), (B, "wrote behind the batch")
+            assert np.array_equal(o[0], o[2])
+        assert np.array_equal(out[0][2], out[1][2]), B
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), B
+        compared_jac += not split
+    assert compared_jac >= 2
+    # a non-finite value in the second vector of a wavefront is seen
+    Xb = X[:16].copy()
+    Xb[5, Ep.M + 4] = np.nan
+    dX = torch.from_numpy(Xb).to(dev)
+    dres = torch.empty((16, Ep.nres), dtype=torch.float64, device=dev)
+    Ep.eval_batch_device(16, dX.data_ptr(), dres.data_ptr(), 0, s)
+    assert Ep.sync(s) == 1
+    r = dres.cpu().numpy()
+    assert np.isnan(r[5]).any() and np.isfinite(np.delete(r, 5, axis=0)).all()
+
+
 def test_device_pointer_api_and_full_expansion():
     import torch
     prob, x0, _ = named_problem("mixed-6x64")
