@@ -70,11 +70,10 @@ struct ProblemDev {
   int32_t use_mfma;          // D.X on v_mfma_f64_16x16x4_f64 instead of VALU FMAs
   int32_t pack;              // every phase has at most 32 nodes: the cooperative form carries two decision vectors per wavefront
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
-  int32_t nair;              // the first nair of the launch's nchunks work items belong to aerodynamic phases and the rest
-                             // to NoAir phases (whole launches: the list is sorted that way); -1: not known
   int32_t unit0, nunits;     // split form only: first unit and number of units (unit = 4 * work item + part)
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)
-  const int4* chunks;        // [nchunks] {phase, first node of the chunk, offset of its MFMA-ordered D in Dsw / 4, 0}:
+  const int4* chunks;        // [nchunks] {phase, first node of the chunk, offset of its MFMA-ordered D in Dsw / 4,
+                             //  (position in the run of this phase's chunks) << 16 | chunks of the phase in the list}:
                              // dearest phase type first for a whole launch, the natural (phase) order for a
                              // phase-sharded one
   const double* Dsw;         // D in matrix-pipe feed order: [chunk][k-step][lane][row tile 0..3] (see gel_host.hip):

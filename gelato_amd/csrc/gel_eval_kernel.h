@@ -44,13 +44,11 @@ static_assert(kWaveLds - kCoopStageOff >= 64 * 11, "the cooperative hand-over ar
 // form: a 68-row slab, or two 36-row vectors when two decision vectors share a wavefront), the hand-over area over it and
 // then, once the wavefront has taken its rows, the park over that -- 6 KB instead of 9.5 KB per wavefront.
 constexpr int kSlabRowsMax = 68, kPackRows = 36, kParkRes = (PK_LV2 + 1) * 64;
-// The NoAir-only instantiations (also with the Jacobian) park the same slots: the same small region.
-constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack, bool noair = false) {
-  return (jac && !noair) ? kWaveLds : (!mfma ? kParkRes : (pack ? 2 * kPackRows * 11 : kSlabRowsMax * 11));
+constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack) {
+  return jac ? kWaveLds : (!mfma ? kParkRes : (pack ? 2 * kPackRows * 11 : kSlabRowsMax * 11));
 }
 static_assert(wave_lds_doubles(false, true, true) >= 64 * 11 && wave_lds_doubles(false, true, false) >= 64 * 11, "hand-over area");
 static_assert(wave_lds_doubles(false, true, true) >= kParkRes && wave_lds_doubles(false, true, false) >= kParkRes, "residual-only park");
-static_assert(PK_DJJ < PK_LV2, "the small park holds quaternion, velocity, D[j][j+1] and the D.X row of the velocity defect");
 
 // Compact Jacobian slots of a node (gel_host.hip walk_pattern() maps them to the reference's COO entries).  Only
 // DISTINCT x-dependent values are stored: a tf column that is the exact negative of its t0 column, the node-uniform
@@ -64,9 +62,6 @@ constexpr int kSlotPT = 0, kSlotVM = 3, kSlotVP = 6;
 
 #ifndef GEL_MIN_WAVES_PER_SIMD
 #define GEL_MIN_WAVES_PER_SIMD 4  // 112 VGPRs, no scratch: 4 waves/SIMD (16 per CU, matching the LDS budget); 5 spills
-#endif
-#ifndef GEL_MIN_WAVES_PER_SIMD_NOAIR
-#define GEL_MIN_WAVES_PER_SIMD_NOAIR 5  // NoAir-only instantiations: 87 VGPRs, 24 KB of LDS per workgroup
 #endif
 #ifndef GEL_MIN_WAVES_PER_SIMD_RES
 #define GEL_MIN_WAVES_PER_SIMD_RES 5  // residual-only, two vectors per wavefront: 94 VGPRs, 25 KB of LDS per workgroup
@@ -82,9 +77,6 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef GEL_DX_PF_RES
 #define GEL_DX_PF_RES 4
-#endif
-#ifndef GEL_DX_PF_NOAIR
-#define GEL_DX_PF_NOAIR 1  // NoAir-only instantiation
 #endif
 
 #ifndef GEL_COOP_XLDS
@@ -102,22 +94,17 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 // the atmosphere/geodesy chain instead of four plus the light sweeps.  Same expressions, same bits.
 // PACK (cooperative form, every phase of the problem at most 32 nodes): a wavefront carries TWO decision vectors, one
 // per 32-lane half, and a workgroup eight -- otherwise half of the lanes (and two of the four D.X row tiles) idle.
-// NOAIR (cooperative form): the launch holds work items of NoAir phases only.  Their wavefronts do a quarter of the
-// arithmetic of an aerodynamic one and spend their life waiting -- on the operands of D.X and on the store stream; without
-// the aerodynamic chain the instantiation needs neither the tables nor the sweep park in LDS and half of the registers,
-// so more wavefronts share a SIMD.
-template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, bool NOAIR = false>
-__global__ __launch_bounds__(kBlock, NOAIR ? GEL_MIN_WAVES_PER_SIMD_NOAIR : ((!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : GEL_MIN_WAVES_PER_SIMD)) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
+template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false>
+__global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : GEL_MIN_WAVES_PER_SIMD) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   extern __shared__ double lds[];
-  static_assert(!NOAIR || (MFMA && !SPLIT), "the NoAir-only instantiations exist in the cooperative form only");
-  const int park_off = NOAIR ? 0 : P.park_off;              // NOAIR: no tables in LDS
-  const Tables tb = NOAIR ? Tables{} : stage_tables(P, lds);
+  const int park_off = P.park_off;
+  const Tables tb = stage_tables(P, lds);
   const int lane = threadIdx.x & 63;
   // explicit LDS address space: ds_read/ds_write (lgkmcnt), never flat_* (which also ticks vmcnt)
   typedef __attribute__((address_space(3))) double lds_double;
-  constexpr int kWL = wave_lds_doubles(JAC, MFMA, PACK, NOAIR);   // this instantiation's region per wavefront
-  constexpr int kHO = (JAC && !NOAIR) ? kCoopStageOff : 0;        // where the cooperative hand-over area starts in it
+  constexpr int kWL = wave_lds_doubles(JAC, MFMA, PACK);   // this instantiation's region per wavefront
+  constexpr int kHO = JAC ? kCoopStageOff : 0;             // where the cooperative hand-over area starts in it
   static_assert(!(MFMA && !SPLIT) || kWL - kHO >= 64 * 11, "the cooperative hand-over area must fit the region");
   lds_double* wave_lds = (lds_double*)lds + park_off + (threadIdx.x >> 6) * kWL;
   lds_double* park = wave_lds + lane;
@@ -144,8 +131,32 @@ __global__ __launch_bounds__(kBlock, NOAIR ? GEL_MIN_WAVES_PER_SIMD_NOAIR : ((!J
   // the mixed vehicle at B = 4096, -6..9 % at B = 2048)
   // SPLIT: the list is walked in units = (work item, part), unit id = 4 * item + part, again with all B vectors
   // of a unit next to each other; P.unit0 / P.nunits select a range of units (unit-sharded launches)
-  const int q = COOP ? (int)(blockIdx.x / (unsigned)nb4) : (int)(item / B);
-  const int b0 = COOP ? (int)(blockIdx.x - (unsigned)q * (unsigned)nb4) * kVecWg : 0;  // first vector of the workgroup
+  // COOP launch order: work-item major (all B vectors of one (phase, chunk) are neighbours, dearest phase type first), but
+  // the chunks of ONE phase and ONE group of vectors are dispatched together and onto the same XCD (workgroup p goes to XCD
+  // p % 8): every chunk of a phase reads all n + 1 state rows of its vectors and writes a block next to the other chunks'
+  // blocks, so what the first one fetched is still in that XCD's L2 when the others ask, and the values of one vector
+  // reach their DRAM pages together.  Measured on 12 x 128 (two chunks per phase), same box: +4.6 % with the chunks merely
+  // adjacent in dispatch order; phases of at most 64 nodes have one chunk and keep plain work-item major order.
+  int q, b0;
+  if (COOP) {
+    const unsigned p = blockIdx.x, nb = (unsigned)nb4;
+    const unsigned it = p / nb, r = p - it * nb;
+    const int cw = __builtin_amdgcn_readfirstlane(P.chunks[P.chunk0 + it].w);   // (position in the phase's run of chunks) << 16 | chunks
+    const unsigned pos = (unsigned)cw >> 16, nc = (unsigned)cw & 0xffffu;
+    unsigned c = pos, bg = r;
+    if (nc > 1) {
+      const unsigned l = pos * nb + r;                 // index inside the phase's nc * nb workgroups
+      const unsigned blk = l / (8 * nc), rem = l - blk * 8 * nc;
+      const unsigned m = min(8u, nb - blk * 8);        // vector groups in this block of eight (the last one may be short)
+      c = rem / m;
+      bg = blk * 8 + (rem - c * m);
+    }
+    q = (int)(it - pos + c);
+    b0 = (int)bg * kVecWg;                             // first vector of the workgroup
+  } else {
+    q = (int)(item / B);
+    b0 = 0;
+  }
   // COOP: a wavefront (PACK: a half) past the end of the batch (B not a multiple of 4 / 8) still computes its tiles for
   // the others; it reads vector B - 1 and leaves after the hand-over without writing anything
   const int bw = PACK ? b0 + 2 * wv + half : b0 + wv;
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(kBlock, NOAIR ? GEL_MIN_WAVES_PER_SIMD_NOAIR : ((!J
         // Software pipeline: the operands of k-step ks + kPF are requested while k-step ks multiplies.  Without
         // it every k-step waits a full memory latency (x comes from HBM on first touch) before its three MFMAs.
         // Requests past the last k-step repeat it (valid addresses, results unused).
-        constexpr int kPF = NOAIR ? GEL_DX_PF_NOAIR : (JAC ? GEL_DX_PF_JAC : GEL_DX_PF_RES);
+        constexpr int kPF = JAC ? GEL_DX_PF_JAC : GEL_DX_PF_RES;
         double ra[kPF], rb0[kPF], rb1[kPF], rb2[kPF];
 #define GEL_DX_LOAD(slot, kstep)                                  \
   do {                                                            \
@@ -592,7 +603,7 @@ __global__ __launch_bounds__(kBlock, NOAIR ? GEL_MIN_WAVES_PER_SIMD_NOAIR : ((!J
     const double tn = tau * (tf - to) / 2 + (tf + to) / 2;  // PSparams.time_nodes, SectionParameters.py:77-81
     const double inv_m = frcp(me * P.um);
 
-    if (!NOAIR && ph.air) {
+    if (ph.air) {
       const EarthAngle ea = earth_angle(tn);  // position sweeps do not change it
       // Trips k = 0,1,2: position sweeps (pos_k + dx); trip k = 3: centre, leaves by break.  Nothing but
       // the node position, the Earth angle and 1/m stays in registers across a trip: velocity and thrust

@@ -725,7 +725,9 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     const HostPhase& h = p->ph[i];
     const int n = h.n, ksteps = (n + 4) >> 2;
     for (int j0 = 0; j0 < n; j0 += 64) {
-      chunks.push_back(make_int4(i, j0, (int)(Dsw.size() / 4), 0));
+      // .w: where the chunk stands in its phase's run and how long the run is (the cooperative launch order keeps the chunks
+      // of a phase and a group of vectors together, gel_eval_kernel.h)
+      chunks.push_back(make_int4(i, j0, (int)(Dsw.size() / 4), ((j0 / 64) << 16) | ((h.n + 63) / 64)));
       for (int ks = 0; ks < ksteps; ks++)
         for (int l = 0; l < 64; l++)
           for (int t = 0; t < 4; t++) {
@@ -748,8 +750,11 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   auto weight = [&](const int4& c) { return (p->ph[c.x].air ? 10.0 : 1.5) + (p->ph[c.x].hold ? 0.0 : 0.5); };
   std::stable_sort(sorted_chunks.begin(), sorted_chunks.end(), [&](const int4& a, const int4& b) { return weight(a) > weight(b); });
 
+  // the phase-ordered list serves shard launches over ARBITRARY work-item ranges: no runs there
+  std::vector<int4> shard_chunks = chunks;
+  for (int4& c : shard_chunks) c.w = 1;
   int rc = GEL_OK;
-  if ((rc = upload(&p->d_chunks, chunks)) || (rc = upload(&p->d_chunks_sorted, sorted_chunks)) || (rc = upload(&p->d_Dsw, Dsw)) || (rc = upload(&p->d_Dst, Dst)) || (rc = upload(&p->d_phases, dph)) || (rc = upload(&p->d_node_phase, node_phase)) || (rc = upload(&p->d_Dt, Dt)) ||
+  if ((rc = upload(&p->d_chunks, shard_chunks)) || (rc = upload(&p->d_chunks_sorted, sorted_chunks)) || (rc = upload(&p->d_Dsw, Dsw)) || (rc = upload(&p->d_Dst, Dst)) || (rc = upload(&p->d_phases, dph)) || (rc = upload(&p->d_node_phase, node_phase)) || (rc = upload(&p->d_Dt, Dt)) ||
       (rc = upload(&p->d_tau, tau)) || (rc = upload(&p->d_tables, tables)) || (rc = upload(&p->d_cval, p->cval)) ||
       (rc = upload(&p->d_src, p->src))) {
     gel_problem_destroy(p);
@@ -794,9 +799,6 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   dv.phases = p->d_phases; dv.node_phase = p->d_node_phase; dv.Dt = p->d_Dt; dv.tau = p->d_tau; dv.tables = p->d_tables;
   dv.flag = p->d_flag;
   dv.nchunks = (int32_t)chunks.size(); dv.chunks = p->d_chunks_sorted; dv.Dsw = p->d_Dsw; dv.Dst = p->d_Dst;
-  dv.nair = 0;
-  for (const int4& c : sorted_chunks) dv.nair += p->ph[c.x].air ? 1 : 0;   // sorted: aerodynamic work items first
-  if (d->flags & GEL_FLAG_ONE_KERNEL) dv.nair = -1;
   dv.park_off = (int32_t)((tables.size() + 1) / 2 * 2);
   {
     // D.X path.  fp64 MFMA and fp64 VALU instructions share the SIMD's fp64 datapath on this part (measured: their busy
@@ -943,7 +945,6 @@ int gel_eval_shard_device(gel_problem* p, int32_t B, const double* d_x, double* 
   if (chunk_count == 0) return GEL_OK;
   gel::ProblemDev dv = p->dev;
   dv.chunks = p->d_chunks;  // shard ranges index the phase-ordered list
-  dv.nair = -1;
   dv.chunk0 = chunk_begin;
   dv.nchunks = chunk_count;
   HIPCHK(gel::launch_eval(dv, B, d_x, d_res, d_jvar, stream ? (hipStream_t)stream : p->stream));
@@ -960,7 +961,6 @@ int gel_eval_shard_units_device(gel_problem* p, int32_t B, const double* d_x, do
   if (unit_count == 0) return GEL_OK;
   gel::ProblemDev dv = p->dev;
   dv.chunks = p->d_chunks;  // unit ids refer to the phase-ordered list
-  dv.nair = -1;
   dv.chunk0 = 0;
   dv.unit0 = unit_begin;
   dv.nunits = unit_count;
@@ -985,7 +985,7 @@ int gel_launch_info(const gel_problem* p, int32_t B, int32_t want_res, int32_t w
   NEED_DEVICE(p);
   const gel::EvalForm f = gel::eval_form(p->dev, B, want_res != 0, want_jac != 0);
   info[0] = f.jac; info[1] = f.mfma; info[2] = f.split; info[3] = (int32_t)std::min<long long>(f.waves, INT32_MAX);
-  info[4] = f.pack; info[5] = f.two_kernels;
+  info[4] = f.pack;
   return GEL_OK;
 }
 
@@ -1080,7 +1080,7 @@ int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) {
       gel::ProblemDev dv = p->dev;   // the phase as a one-phase problem: same tables, D, tau; local index space
       dv.S = 1; dv.N = n; dv.M = n + 1; dv.nvars = nloc; dv.V = 0;
       dv.phases = p->d_subphases + i;
-      dv.chunks = p->d_subchunks + p->sub_chunk0[i]; dv.nchunks = p->sub_nchunks[i]; dv.chunk0 = 0; dv.nair = -1;
+      dv.chunks = p->d_subchunks + p->sub_chunk0[i]; dv.nchunks = p->sub_nchunks[i]; dv.chunk0 = 0;
       HIPCHK(gel::launch_perturb_local(nloc, p->dx, p->jfd_x, p->d_colmap + p->sub_col0[i], p->jfd_Xp, p->stream));
       HIPCHK(gel::launch_eval(dv, nloc + 1, p->jfd_Xp, p->jfd_res + p->sub_res0[i], nullptr, p->stream));
     }

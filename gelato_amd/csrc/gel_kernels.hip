@@ -612,10 +612,6 @@ constexpr long long kSplitMaxWaves = 1024;
 
 static size_t table_lds_bytes(int Kw, int Kc) { return sizeof(double) * staged_table_doubles(Kw, Kc); }
 
-// NoAir work items get their own launch (NoAir-only instantiation) from this many of their wavefronts on: below it the
-// second launch's fixed cost and its own tail outweigh the gain
-constexpr long long kTwoKernelMinWaves = 4096;
-
 // which instantiation a launch takes (also reported through gel_launch_info)
 EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
   EvalForm f;
@@ -631,18 +627,14 @@ EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
   const int vw = f.pack ? 8 : 4;   // decision vectors per workgroup of the cooperative form
   f.waves = f.split ? (long long)B * (P.nunits > 0 ? P.nunits : 4 * P.nchunks)
                     : (f.mfma ? 4LL * P.nchunks * ((B + vw - 1) / vw) : waves);
-  // cooperative form with the Jacobian, both phase types present, enough NoAir wavefronts to fill the chip: the NoAir
-  // work items run in the NoAir-only instantiation (more wavefronts per SIMD), as a launch of their own
-  f.two_kernels = f.jac && f.mfma && !f.split && P.nair > 0 && P.nair < P.nchunks &&
-                  4LL * (P.nchunks - P.nair) * ((B + vw - 1) / vw) >= kTwoKernelMinWaves;
   return f;
 }
 
-template <bool JAC, bool PACK, bool NOAIR>
+template <bool JAC, bool PACK>
 static void launch_coop(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
   const unsigned grid = (unsigned)P.nchunks * (unsigned)((B + (PACK ? 7 : 3)) / (PACK ? 8 : 4));
-  const size_t lds = sizeof(double) * ((NOAIR ? (size_t)0 : (size_t)P.park_off) + (size_t)wave_lds_doubles(JAC, true, PACK, NOAIR) * (kBlock / 64));
-  hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK, NOAIR>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+  const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(JAC, true, PACK) * (kBlock / 64));
+  hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
 }
 
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
@@ -650,23 +642,10 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
   const EvalForm f = eval_form(P, B, d_res != nullptr, d_jvar != nullptr);
   if (f.mfma && !f.split) {
     // cooperative D.X form (matrix pipe, not split): one workgroup = one work item x four (PACK: eight) decision vectors
-    if (f.two_kernels) {
-      // NoAir items first: their wavefronts are short, so the launch drains quickly before the long ones start
-      ProblemDev Q = P;
-      Q.chunk0 = P.chunk0 + P.nair; Q.nchunks = P.nchunks - P.nair; Q.nair = 0;
-      if (f.pack) launch_coop<true, true, true>(Q, B, d_x, d_res, d_jvar, s);
-      else launch_coop<true, false, true>(Q, B, d_x, d_res, d_jvar, s);
-      Q = P;
-      Q.nchunks = P.nair;
-      if (f.pack) launch_coop<true, true, false>(Q, B, d_x, d_res, d_jvar, s);
-      else launch_coop<true, false, false>(Q, B, d_x, d_res, d_jvar, s);
-    } else if (f.jac) {
-      if (f.pack) launch_coop<true, true, false>(P, B, d_x, d_res, d_jvar, s);
-      else launch_coop<true, false, false>(P, B, d_x, d_res, d_jvar, s);
-    } else {
-      if (f.pack) launch_coop<false, true, false>(P, B, d_x, d_res, d_jvar, s);
-      else launch_coop<false, false, false>(P, B, d_x, d_res, d_jvar, s);
-    }
+    if (f.jac && f.pack) launch_coop<true, true>(P, B, d_x, d_res, d_jvar, s);
+    else if (f.jac) launch_coop<true, false>(P, B, d_x, d_res, d_jvar, s);
+    else if (f.pack) launch_coop<false, true>(P, B, d_x, d_res, d_jvar, s);
+    else launch_coop<false, false>(P, B, d_x, d_res, d_jvar, s);
     return hipGetLastError();
   }
   const unsigned grid = (unsigned)((f.waves * 64 + kBlock - 1) / kBlock);

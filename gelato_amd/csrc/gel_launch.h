@@ -9,9 +9,8 @@
 
 namespace gel {
 
-// the form of the fused kernel a launch takes: <JAC, MFMA, SPLIT, PACK> and its wavefront count; two_kernels: the NoAir work
-// items go to the NoAir-only instantiation in a launch of their own (nair work items in the first, the rest in the second)
-struct EvalForm { bool jac, mfma, split, pack, two_kernels; long long waves; };
+// the form of the fused kernel a launch takes: <JAC, MFMA, SPLIT, PACK> and its wavefront count
+struct EvalForm { bool jac, mfma, split, pack; long long waves; };
 EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac);
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s);
 hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, const int32_t* src,

@@ -82,7 +82,7 @@ class Engine:
         else:
             d.D, d.tau = None, None
         d.device = device
-        d.flags = int(flags)  # 0, or GEL_FLAG_DX_MFMA (1) / GEL_FLAG_DX_VALU (2) to force the D.X path, GEL_FLAG_NO_PACK (4), GEL_FLAG_ONE_KERNEL (8)
+        d.flags = int(flags)  # 0, or GEL_FLAG_DX_MFMA (1) / GEL_FLAG_DX_VALU (2) to force the D.X path, GEL_FLAG_NO_PACK (4)
         h = C.c_void_p()
         check(L.gel_problem_create(C.byref(d), C.byref(h)))
         self._h = h
@@ -231,8 +231,8 @@ class Engine:
         check(lib().gel_expand_full_device(self._h, B, d_jvar, d_jfull, stream or None))
 
     def launch_info(self, B, want_res=True, want_jac=True):
-        """-> [jacobian, mfma, split, wavefronts, pack, two_kernels] of the kernel form a launch of B vectors takes"""
-        info = (C.c_int32 * 6)()
+        """-> [jacobian, mfma, split, wavefronts, pack] of the kernel form a launch of B vectors takes"""
+        info = (C.c_int32 * 5)()
         check(lib().gel_launch_info(self._h, int(B), int(bool(want_res)), int(bool(want_jac)), info))
         return [int(v) for v in info]
 
