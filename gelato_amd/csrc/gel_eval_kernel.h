@@ -79,6 +79,16 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_DX_PF_RES 4
 #endif
 
+#ifndef GEL_XLDS_A_PF_JAC
+#define GEL_XLDS_A_PF_JAC 1  // LDS-staged cooperative D.X, one vector per wavefront: A slabs in flight, fused launch
+#endif
+#ifndef GEL_XLDS_A_PF_RES
+#define GEL_XLDS_A_PF_RES 4  // ... residual-only launch (6x64: +11 % over 1; the fused launch does not care: +-1 % for 1..8)
+#endif
+#ifndef GEL_PACK_A_PRELOAD
+#define GEL_PACK_A_PRELOAD 1  // two vectors per wavefront: all (<= 9) A slabs of D.X requested before the operand barrier
+#endif
+
 #ifndef GEL_COOP_XLDS
 #define GEL_COOP_XLDS 1  // cooperative D.X: state rows staged in LDS (1) or fetched per k-step from global memory (0)
 #endif
@@ -99,7 +109,8 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   extern __shared__ double lds[];
   const int park_off = P.park_off;
-  const Tables tb = stage_tables(P, lds);
+  // the cooperative forms meet at a barrier (operand image / hand-over) before any table lookup: no barrier of its own
+  const Tables tb = stage_tables(P, lds, !(MFMA && !SPLIT));
   const int lane = threadIdx.x & 63;
   // explicit LDS address space: ds_read/ds_write (lgkmcnt), never flat_* (which also ticks vmcnt)
   typedef __attribute__((address_space(3))) double lds_double;
@@ -316,21 +327,56 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
             }
           }
         }
-        __syncthreads();
-        {
-          double a = ap[0];
-#ifdef GEL_ABL_NODX
-          for (int ks = 0; ks < 0; ks++) {
-#else
-          for (int ks = 0; ks < ksteps; ks++) {
+        double a_ring[JAC ? GEL_XLDS_A_PF_JAC : GEL_XLDS_A_PF_RES];
+        if (!(PACK && GEL_PACK_A_PRELOAD)) {
+#pragma unroll
+          for (int i = 0; i < (JAC ? GEL_XLDS_A_PF_JAC : GEL_XLDS_A_PF_RES); i++) a_ring[i] = ap[min(i, ksteps - 1) * 256];
+        }
+#if GEL_PACK_A_PRELOAD
+        // PACK: at most nine k-steps -- all A slabs are requested before the barrier, so their latency runs under the state
+        // rows' (they do not depend on x)
+        double a_all[9];
+        if (PACK) {
+#pragma unroll
+          for (int ks = 0; ks < 9; ks++) a_all[ks] = ap[min(ks, ksteps - 1) * 256];
+        }
 #endif
-            const double a_next = ap[min(ks + 1, ksteps - 1) * 256];       // the next k-step's A slab is on its way
-            const int ro = ks * 44;                                          // 4 rows of 11 columns per k-step
-            const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl2, acc[2], 0, 0, 0);
-            a = a_next;
+        __syncthreads();
+#if GEL_PACK_A_PRELOAD
+        if (PACK) {
+#pragma unroll
+          for (int ks = 0; ks < 9; ks++) {
+            if (ks < ksteps) {   // wave-uniform
+              const int ro = ks * 44;
+              const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
+              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl0, acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl1, acc[1], 0, 0, 0);
+              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl2, acc[2], 0, 0, 0);
+            }
+          }
+        } else
+#endif
+        {
+          // k-steps of A slabs in flight ahead of the matrix pipe (an L2 round trip each; requested before the barrier)
+          constexpr int kAPF = JAC ? GEL_XLDS_A_PF_JAC : GEL_XLDS_A_PF_RES;
+          const int kfirst = 0;
+#ifdef GEL_ABL_NODX
+          const int klast = 0;
+#else
+          const int klast = ksteps;
+#endif
+          for (int ks = kfirst; ks < klast; ks += kAPF) {
+#pragma unroll
+            for (int i = 0; i < kAPF; i++) {
+              if (ks + i < klast) {   // wave-uniform
+                const int ro = (ks + i) * 44;                                // 4 rows of 11 columns per k-step
+                const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ring[i], bl0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ring[i], bl1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ring[i], bl2, acc[2], 0, 0, 0);
+              }
+              a_ring[i] = ap[min(ks + i + kAPF, ksteps - 1) * 256];
+            }
           }
         }
         {

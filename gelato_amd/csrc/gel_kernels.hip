@@ -43,10 +43,12 @@ GEL_DEV Tables table_view(const double* base, int Kw, int Kc) {
   return tb;
 }
 
-GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds) {
+// sync = false: the caller reaches a workgroup barrier of its own before the first table lookup (the cooperative D.X
+// forms do), so the copy shares that barrier -- and its memory latency -- with the caller's own first loads
+GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds, bool sync = true) {
   const int ntab = table_doubles(P.Kw, P.Kc);
   for (int i = threadIdx.x; i < ntab; i += blockDim.x) lds[i] = P.tables[i];
-  __syncthreads();
+  if (sync) __syncthreads();
   return table_view(lds, P.Kw, P.Kc);
 }
 
