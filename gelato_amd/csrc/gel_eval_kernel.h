@@ -79,6 +79,12 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_DX_PF_RES 4
 #endif
 
+#ifndef GEL_WIND_CACHE
+#define GEL_WIND_CACHE 1  // likewise the altitude interval of the wind table across a node's position sweeps
+#endif
+#ifndef GEL_CA_CACHE
+#define GEL_CA_CACHE 1  // the Mach interval of a node's first CA lookup serves its other aerodynamic-force evaluations
+#endif
 #ifndef GEL_XLDS_A_PF_JAC
 #define GEL_XLDS_A_PF_JAC 1  // LDS-staged cooperative D.X, one vector per wavefront: A slabs in flight, fused launch
 #endif
@@ -656,6 +662,18 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
       // direction are re-formed from the park after the atmosphere chain, sweep results go to the park.
       PosPart pp;
       double v[3], dir[3], w[3], F[3], T, fp8 = 0.0;
+#if GEL_CA_CACHE
+      Bracket ca_br = no_bracket();   // the node's Mach interval, shared by all of its aerodynamic-force evaluations
+#define GEL_CA_BRACKET (JAC ? &ca_br : (Bracket*)nullptr)   // a residual-only launch looks up once
+#else
+#define GEL_CA_BRACKET nullptr
+#endif
+#if GEL_WIND_CACHE
+      Bracket2 w_br = no_bracket2();  // the node's altitude interval in the wind table, shared by its four position evaluations
+#define GEL_WIND_BRACKET ((JAC && !SPLIT) ? &w_br : (Bracket2*)nullptr)
+#else
+#define GEL_WIND_BRACKET nullptr
+#endif
 #pragma unroll 1
 #ifdef GEL_ABL_NOPOS  // ablation: no position sweeps (their Jacobian slots are written with whatever the park holds)
       for (int k = 3;; k = SPLIT ? 3 : k + 1) {
@@ -665,11 +683,11 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         double r[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
-        pp = pos_part(r, tb, P.barC20);
+        pp = pos_part(r, tb, P.barC20, GEL_WIND_BRACKET);
         wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] = PARK_GET(PK_V0 + c) * P.uv;
-        aero_force(r, v, pp.rho, pp.inv_a, ea, w, ph.area, tb, F);
+        aero_force(r, v, pp.rho, pp.inv_a, ea, w, ph.area, tb, F, GEL_CA_BRACKET);
         T = ph.thrust - ph.nozzle * pp.P;
         {
           const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
@@ -722,7 +740,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
             double vp[3], Fp[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) vp[c] = ((k == c) ? (PARK_GET(PK_V0 + c) + dx) : PARK_GET(PK_V0 + c)) * P.uv;
-            aero_force(r, vp, pp.rho, pp.inv_a, ea, w, ph.area, tb, Fp);
+            aero_force(r, vp, pp.rho, pp.inv_a, ea, w, ph.area, tb, Fp, GEL_CA_BRACKET);
             accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
             // submat_vel[3j+c, 3(j+1)+k] = D[j][j+1]*(c==k) + rh_vel   (con_dynamics.py:341-343,415-416)
 #pragma unroll
@@ -768,7 +786,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
             const double rq[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
             wind_eci(rq, eq, PARK_GET(PK_FP0), PARK_GET(PK_FP1), PARK_GET(PK_FP2), PARK_GET(PK_FP3), PARK_GET(PK_FP4), wq);
             const double vq[3] = {PARK_GET(PK_V0) * P.uv, PARK_GET(PK_V1) * P.uv, PARK_GET(PK_V2) * P.uv};
-            aero_force(rq, vq, PARK_GET(PK_Q0), PARK_GET(PK_Q1), eq, wq, ph.area, tb, Fp);
+            aero_force(rq, vq, PARK_GET(PK_Q0), PARK_GET(PK_Q1), eq, wq, ph.area, tb, Fp, GEL_CA_BRACKET);
             const double Tq[3] = {PARK_GET(PK_Q2), PARK_GET(PK_Q3), PARK_GET(PK_DJJ)};
             const double gq[3] = {PARK_GET(PK_FP5), PARK_GET(PK_FP6), PARK_GET(PK_FP7)};
             accel(Tq, Fp, inv_m, gq, inv_uv, f);
@@ -841,6 +859,8 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   }
 
 #undef EMIT
+#undef GEL_CA_BRACKET
+#undef GEL_WIND_BRACKET
 #undef EMIT_AT
 #undef RSTORE
 #undef FDQ

@@ -378,12 +378,50 @@ GEL_DEV double interp_tab(double x, const double* tab, const double* slope, int 
   return (x <= tab[0]) ? tab[ycol] : ((x > tab[(n - 1) * stride]) ? tab[(n - 1) * stride + ycol] : v);
 }
 
+// The interval of the last lookup, kept by the caller across the sweeps of one node: a perturbed evaluation moves the
+// abscissa by 1e-8 of itself, so it falls into the same interval (xl < x <= xu) almost surely; then the count over the
+// table, the clamps and four LDS reads are skipped.  The same interval means the same operands in the same expression:
+// bit-identical to the full lookup.  A wavefront takes the short way only if all of its lanes can.
+struct Bracket { double xl, xu, yl, sl; };
+GEL_DEV Bracket no_bracket() { return Bracket{1.79769313486231570815e308, -1.79769313486231570815e308, 0.0, 0.0}; }
+GEL_DEV double interp_tab_cached(double x, const double* tab, const double* slope, int n, int stride, int ycol, Bracket& br) {
+  const bool hit = (br.xl < x) && (x <= br.xu);
+  if (__builtin_amdgcn_ballot_w64(!hit) == 0) return br.yl + (x - br.xl) * br.sl;   // wave-uniform branch
+  const int idx = min(max(lower_count(x, tab, n, stride) - 1, 0), n - 2);
+  br.xl = tab[idx * stride]; br.xu = tab[(idx + 1) * stride]; br.yl = tab[idx * stride + ycol]; br.sl = slope[idx];
+  const double v = br.yl + (x - br.xl) * br.sl;
+  return (x <= tab[0]) ? tab[ycol] : ((x > tab[(n - 1) * stride]) ? tab[(n - 1) * stride + ycol] : v);
+}
+
 // both wind components share one bracket search (src/wrapper_utils.hpp:82-87 runs it twice)
 GEL_DEV void wind_ned2(double h, const double* tab, const double* slope, int n, double& wn, double& we) {
   const int idx = min(max(lower_count(h, tab, n, 3) - 1, 0), n - 2);
   const double dxl = h - tab[idx * 3];
   const double vn = tab[idx * 3 + 1] + dxl * slope[2 * idx];
   const double ve = tab[idx * 3 + 2] + dxl * slope[2 * idx + 1];
+  const bool below = h <= tab[0], above = h > tab[(n - 1) * 3];
+  wn = below ? tab[1] : (above ? tab[(n - 1) * 3 + 1] : vn);
+  we = below ? tab[2] : (above ? tab[(n - 1) * 3 + 2] : ve);
+}
+
+// wind_ned2 with the altitude interval of the node's previous lookup (see Bracket): the three position sweeps and the
+// centre evaluation of a node sit within 1e-8 of each other
+struct Bracket2 { double xl, xu, y0, y1, s0, s1; };
+GEL_DEV Bracket2 no_bracket2() { return Bracket2{1.79769313486231570815e308, -1.79769313486231570815e308, 0.0, 0.0, 0.0, 0.0}; }
+GEL_DEV void wind_ned2_cached(double h, const double* tab, const double* slope, int n, double& wn, double& we, Bracket2& br) {
+  const bool hit = (br.xl < h) && (h <= br.xu);
+  if (__builtin_amdgcn_ballot_w64(!hit) == 0) {   // wave-uniform branch
+    const double dxl = h - br.xl;
+    wn = br.y0 + dxl * br.s0;
+    we = br.y1 + dxl * br.s1;
+    return;
+  }
+  const int idx = min(max(lower_count(h, tab, n, 3) - 1, 0), n - 2);
+  br.xl = tab[idx * 3]; br.xu = tab[idx * 3 + 3]; br.y0 = tab[idx * 3 + 1]; br.y1 = tab[idx * 3 + 2];
+  br.s0 = slope[2 * idx]; br.s1 = slope[2 * idx + 1];
+  const double dxl = h - br.xl;
+  const double vn = br.y0 + dxl * br.s0;
+  const double ve = br.y1 + dxl * br.s1;
   const bool below = h <= tab[0], above = h > tab[(n - 1) * 3];
   wn = below ? tab[1] : (above ? tab[(n - 1) * 3 + 1] : vn);
   we = below ? tab[2] : (above ? tab[(n - 1) * 3 + 2] : ve);

@@ -42,7 +42,7 @@ GEL_DEV void geodetic_sincos(double x, double y, double z, double& sl, double& c
   cl = pp * ihy;
 }
 
-GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
+GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20, Bracket2* wbr = nullptr) {
   PosPart o;
   // the reference feeds the ECI position to ecef2geodetic for altitude (src/pybind_dynamics.cpp:43)
   // The altitude p/cos(lat) - N cancels 6.4e6 m down to the altitude and the position sweeps difference
@@ -69,7 +69,9 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20) {
   const double h = geopotential_altitude(alt);
   const Air air = atmosphere(h, tb.atm);
   o.rho = air.rho; o.P = air.P; o.inv_a = air.inv_a;
-  wind_ned2(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we);  // wind looked up at geopotential altitude (:44,49)
+  // wind looked up at geopotential altitude (:44,49); wbr: the caller's altitude interval of this node's previous evaluations
+  if (wbr) wind_ned2_cached(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we, *wbr);
+  else wind_ned2(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we);
   gravity_eci(r, barC20, o.g);
   return o;
 }
@@ -127,7 +129,7 @@ GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double s_hp, doubl
 
 // aerodynamic force (ECI): src/pybind_dynamics.cpp:48-59 given the shared parts
 GEL_DEV void aero_force(const double r[3], const double v[3], double rho, double inv_a_sound, const EarthAngle& e,
-                        const double w[3], double area, const Tables& tb, double F[3]) {
+                        const double w[3], double area, const Tables& tb, double F[3], Bracket* br = nullptr) {
   // vel_eci2ecef: src/Coordinate.cpp:69-73 (omega x r = (-w y, w x, 0)), then ecef2eci (:41-49), minus wind
   const double d0 = v[0] + kOmega * r[1];
   const double d1 = v[1] - kOmega * r[0];
@@ -140,7 +142,8 @@ GEL_DEV void aero_force(const double r[3], const double v[3], double rho, double
   // fsqrt stays defined; the force is k * (-a) = 0 either way
   const double vn = fsqrt(fmax(a0 * a0 + a1 * a1 + a2 * a2, 1.0e-200));
   const double mach = vn * inv_a_sound;
-  const double ca = interp_tab(mach, tb.ca, tb.cas, tb.Kc, 2, 1);
+  // br: the caller's Mach interval of this node's previous evaluations (fused kernel), or none
+  const double ca = br ? interp_tab_cached(mach, tb.ca, tb.cas, tb.Kc, 2, 1, *br) : interp_tab(mach, tb.ca, tb.cas, tb.Kc, 2, 1);
   const double k = 0.5 * rho * area * ca * vn;
   F[0] = k * -a0; F[1] = k * -a1; F[2] = k * -a2;
 }
