@@ -103,6 +103,7 @@ SIGNATURES = {
     "gel_rows_eval_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gel_eval_callback": (C.c_int, [C.c_void_p, _dp, C.POINTER(GelCallbackIO)]),
     "gel_initial_guess": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp]),
+    "gel_output_table": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_double, _dp]),
     "gel_dynamics_velocity": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32,
                                          _dp, C.c_double, _dp]),
     "gel_dynamics_velocity_NoAir": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]),

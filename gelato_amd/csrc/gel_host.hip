@@ -1437,6 +1437,35 @@ int gel_rows_eval(gel_problem* p, int32_t B, const double* x, double* con, doubl
   return GEL_OK;
 }
 
+// ------------- post-processing table (output_result.py:37-263) -------------
+int gel_output_table(gel_problem* p, const double* x, const double* tx_res, double launch_lat_deg, double launch_lon_deg,
+                     double* out) {
+  if (!p || !x || !tx_res || !out) return fail(GEL_ERR_ARG, "null argument");
+  NEED_DEVICE(p);
+  HIPCHK(hipSetDevice(p->device));
+  const int M = p->dims.M;
+  // the section of every state node (output_result.py:121-143: section s owns its n + 1 state nodes)
+  std::vector<int32_t> sec((size_t)M);
+  for (size_t i = 0; i < p->ph.size(); i++)
+    for (int k = 0; k <= p->ph[i].n; k++) sec[(size_t)p->ph[i].xa + k] = (int32_t)i;
+  const size_t nx = (size_t)p->dims.num_vars, no = (size_t)M * gel::kOutputColumns;
+  int rc;
+  // one scratch buffer: x | tx | out | node sections (as doubles' worth of bytes)
+  const size_t words = nx + (size_t)M + no + ((size_t)M + 1) / 2;
+  if ((rc = grow(&p->d_rows_x, &p->d_rows_x_cap, words, false))) return rc;
+  double* d_x = p->d_rows_x;
+  double* d_tx = d_x + nx;
+  double* d_out = d_tx + M;
+  int32_t* d_sec = reinterpret_cast<int32_t*>(d_out + no);
+  HIPCHK(hipMemcpyAsync(d_x, x, nx * 8, hipMemcpyHostToDevice, p->stream));
+  HIPCHK(hipMemcpyAsync(d_tx, tx_res, (size_t)M * 8, hipMemcpyHostToDevice, p->stream));
+  HIPCHK(hipMemcpyAsync(d_sec, sec.data(), (size_t)M * 4, hipMemcpyHostToDevice, p->stream));
+  HIPCHK(gel::launch_output(p->dev, M, d_x, d_tx, d_sec, launch_lat_deg, launch_lon_deg, d_out, p->stream));
+  HIPCHK(hipMemcpyAsync(out, d_out, no * 8, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return GEL_OK;
+}
+
 // ------------- from-file initial guess on the host (initialize.py:322-409) -------------
 int gel_initial_guess(const gel_problem* p, int32_t nref, const double* t_ref, const double* table,
                       const double* knot_times, double* x) {

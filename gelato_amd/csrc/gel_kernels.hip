@@ -598,6 +598,206 @@ __global__ void rows_kernel(ProblemDev P, int nlin, const LinRowDev* __restrict_
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 
+// ---------------------------------------------------------------------------
+// Post-processing table (output_result.py:37-263): one thread per state node, kOutputCols values
+// per node in the order of include/gelato_amd.h GEL_OUTPUT_*.  Runs once after the optimiser has finished: written for
+// agreement with the reference's formulas (same operation order, libm calls where the reference has them), not speed.
+// ---------------------------------------------------------------------------
+struct Quat { double w, x, y, z; };
+GEL_DEV Quat qmul(const Quat& q, const Quat& p) {   // lib/coordinate.py:31-37
+  return Quat{q.w * p.w - q.x * p.x - q.y * p.y - q.z * p.z, q.x * p.w + q.w * p.x - q.z * p.y + q.y * p.z,
+              q.y * p.w + q.z * p.x + q.w * p.y - q.x * p.z, q.z * p.w - q.y * p.x + q.x * p.y + q.w * p.z};
+}
+GEL_DEV Quat qconj(const Quat& q) { return Quat{q.w, -q.x, -q.y, -q.z}; }
+GEL_DEV void qrot(const Quat& q, const double v[3], double o[3]) {   // conj(q) * v * q (:55-68)
+  const Quat r = qmul(qconj(q), qmul(Quat{0.0, v[0], v[1], v[2]}, q));
+  o[0] = r.x; o[1] = r.y; o[2] = r.z;
+}
+GEL_DEV double norm3(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+// Vincenty's inverse formula, lib/downrange.py:32-111 (iteration limit 5000, |d lambda| < 1e-12)
+GEL_DEV double distance_vincenty(double lat_o, double lon_o, double lat_t, double lon_t) {
+  const double Ra = 6378137.0, f = 1.0 / 298.257223563, Rb = Ra * (1.0 - f);
+  const double lat1 = lat_o * kPi / 180.0, lon1 = lon_o * kPi / 180.0, lat2 = lat_t * kPi / 180.0, lon2 = lon_t * kPi / 180.0;
+  if (lon2 - lon1 == 0.0) return 0.0;
+  const double U1 = atan((1.0 - f) * tan(lat1)), U2 = atan((1.0 - f) * tan(lat2)), dl = lon2 - lon1;
+  const double sU1 = sin(U1), cU1 = cos(U1), sU2 = sin(U2), cU2 = cos(U2);
+  double lam = dl, sin_sigma = 0.0, cos_sigma = 0.0, sigma = 0.0, cos_alpha = 0.0, cos_2sm = 0.0;
+  for (int it = 0; it < 5000; it++) {
+    const double sl = sin(lam), cl = cos(lam);
+    const double t1 = cU2 * sl, t2 = cU1 * sU2 - sU1 * cU2 * cl;
+    sin_sigma = sqrt(t1 * t1 + t2 * t2);
+    cos_sigma = sU1 * sU2 + cU1 * cU2 * cl;
+    sigma = atan2(sin_sigma, cos_sigma);
+    const double sin_alpha = cU1 * cU2 * sl / sin_sigma;
+    cos_alpha = sqrt(1.0 - sin_alpha * sin_alpha);
+    cos_2sm = cos_sigma - 2.0 * sU1 * sU2 / (cos_alpha * cos_alpha);
+    const double coeff = f / 16.0 * (cos_alpha * cos_alpha) * (4.0 + f * (4.0 - 3.0 * (cos_alpha * cos_alpha)));
+    const double prev = lam;
+    lam = dl + (1.0 - coeff) * f * sin_alpha * (sigma + coeff * sin_sigma * (cos_2sm + coeff * cos_sigma * (-1.0 + 2.0 * cos_2sm)));
+    if (fabs(lam - prev) < 1e-12) break;
+  }
+  const double u2 = (cos_alpha * cos_alpha) * (Ra * Ra - Rb * Rb) / (Rb * Rb);
+  const double A = 1.0 + u2 / 16384.0 * (4096.0 + u2 * (-768.0 + u2 * (320.0 - 175.0 * u2)));
+  const double Bc = u2 / 1024.0 * (256.0 + u2 * (-128.0 + u2 * (74.0 - 47.0 * u2)));
+  const double ds = Bc * sin_sigma * (cos_2sm + 0.25 * Bc * (cos_sigma * (-1.0 + 2.0 * (cos_2sm * cos_2sm)) -
+                    (1.0 / 6.0) * Bc * cos_2sm * (-3.0 + 4.0 * (sin_sigma * sin_sigma)) * (-3.0 + 4.0 * (cos_2sm * cos_2sm))));
+  return Rb * A * (sigma - ds);
+}
+
+// quat_ecef2nedg (lib/coordinate.py:335-359) from the geodetic latitude / longitude [rad]
+GEL_DEV Quat quat_ecef2nedg(double lat, double lon) {
+  double s_hl, c_hl, s_hp, c_hp;
+  sincos(lon / 2.0, &s_hl, &c_hl);
+  sincos(lat / 2.0, &s_hp, &c_hp);
+  const double r2 = sqrt(2.0);
+  return Quat{c_hl * (c_hp - s_hp) / r2, s_hl * (c_hp + s_hp) / r2, -c_hl * (c_hp + s_hp) / r2, s_hl * (c_hp - s_hp) / r2};
+}
+
+constexpr int kOutputCols = kOutputColumns;
+__global__ void output_kernel(ProblemDev P, int M, const double* __restrict__ x, const double* __restrict__ tx,
+                              const int32_t* __restrict__ node_sec, double lat0, double lon0, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const Tables tb = stage_tables(P, lds);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const PhaseDev ph = P.phases[node_sec[i]];
+  const double mass = x[i] * P.um;
+  const double pos[3] = {x[M + 3 * i] * P.up, x[M + 3 * i + 1] * P.up, x[M + 3 * i + 2] * P.up};
+  const double vel[3] = {x[4 * M + 3 * i] * P.uv, x[4 * M + 3 * i + 1] * P.uv, x[4 * M + 3 * i + 2] * P.uv};
+  Quat q{x[7 * M + 4 * i], x[7 * M + 4 * i + 1], x[7 * M + 4 * i + 2], x[7 * M + 4 * i + 3]};
+  {
+    const double qn = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);   // normalize(quat_[i]) (:129)
+    q = Quat{q.w / qn, q.x / qn, q.y / qn, q.z / qn};
+  }
+  const double t = tx[i];
+  double* o = out + (size_t)i * kOutputCols;
+  double sn, cs;
+  sincos(kOmega * t, &sn, &cs);
+  // eci2ecef, vel_eci2ecef (src/Coordinate.cpp:51-73)
+  const double pe[3] = {pos[0] * cs + pos[1] * sn, -pos[0] * sn + pos[1] * cs, pos[2]};
+  const double g0 = vel[0] + kOmega * pos[1], g1 = vel[1] - kOmega * pos[0];
+  const double ve[3] = {g0 * cs + g1 * sn, -g0 * sn + g1 * cs, vel[2]};
+  double lat, lon, alt;
+  geodetic_full(pe[0], pe[1], pe[2], lat, lon, alt);
+  const double lat_d = lat * (180.0 / kPi), lon_d = lon * (180.0 / kPi);
+  const double h = geopotential_altitude(alt);
+  o[1] = lat_d; o[2] = lon_d; o[6] = alt;
+  o[5] = distance_vincenty(lat0, lon0, lat_d, lon_d);
+  // orbital elements (lib/coordinate.py:591-649)
+  {
+    const double rn = norm3(pos);
+    const double nr[3] = {pos[0] / rn, pos[1] / rn, pos[2] / rn};
+    const double c[3] = {pos[1] * vel[2] - pos[2] * vel[1], pos[2] * vel[0] - pos[0] * vel[2], pos[0] * vel[1] - pos[1] * vel[0]};
+    const double f[3] = {vel[1] * c[2] - vel[2] * c[1] - kMu * nr[0], vel[2] * c[0] - vel[0] * c[2] - kMu * nr[1],
+                         vel[0] * c[1] - vel[1] * c[0] - kMu * nr[2]};
+    const double cn = norm3(c), fn = norm3(f);
+    const double c1[3] = {c[0] / cn, c[1] / cn, c[2] / cn}, f1[3] = {f[0] / fn, f[1] / fn, f[2] / fn};
+    const double inc = acos(c1[2]);
+    double asc, argp;
+    if (inc > 1e-10) {
+      asc = atan2(c1[0], -c1[1]);
+      argp = acos(cos(asc) * f1[0] + sin(asc) * f1[1]);
+      if (f[2] < 0) argp *= -1.0;
+    } else {
+      asc = 0.0;
+      argp = atan2(f[1], f[0]);
+    }
+    const double pp = cn * cn / kMu, e = fn / kMu, a = pp / (1.0 - e * e);
+    double ta = acos(f1[0] * nr[0] + f1[1] * nr[1] + f1[2] * nr[2]);
+    if (vel[0] * pos[0] + vel[1] * pos[1] + vel[2] * pos[2] < 0.0) ta = 2.0 * kPi - ta;
+    if (asc < 0.0) asc += 2.0 * kPi;
+    if (argp < 0.0) argp += 2.0 * kPi;
+    if (ta < 0.0) ta += 2.0 * kPi;
+    o[7] = a * (1.0 + e) - 6378137;
+    o[8] = a * (1.0 - e) - 6378137;
+    o[9] = inc * (180.0 / kPi); o[11] = asc * (180.0 / kPi); o[10] = argp * (180.0 / kPi); o[12] = ta * (180.0 / kPi);
+  }
+  // ground velocity in NED, inertial velocity in NED (output_result.py:166-186)
+  const Quat q_e2n = quat_ecef2nedg(lat, lon);
+  double sh, ch;
+  sincos(kOmega * t / 2.0, &sh, &ch);
+  const Quat q_i2n = qmul(Quat{ch, 0.0, 0.0, sh}, q_e2n);    // quat_eci2nedg (:386-397)
+  double vg_ned[3], v_ned[3];
+  qrot(q_e2n, ve, vg_ned);
+  qrot(q_i2n, vel, v_ned);
+  o[13] = vg_ned[0]; o[14] = vg_ned[1]; o[15] = vg_ned[2];
+  o[26] = norm3(ve);
+  o[22] = atan2(v_ned[1], v_ned[0]) * (180.0 / kPi);
+  o[21] = asin(-v_ned[2] / norm3(v_ned)) * (180.0 / kPi);
+  const Air air = atmosphere(h, tb.atm);
+  double wn, we;
+  wind_ned2(h, tb.wind, tb.winds, tb.Kw, wn, we);
+  const double va_ned[3] = {vg_ned[0] - wn, vg_ned[1] - we, vg_ned[2] - 0.0};
+  const double van = norm3(va_ned);
+  const double qdyn = 0.5 * (van * van) * air.rho;
+  o[31] = qdyn;
+  // air velocity in ECI (:225-231) = ecef2eci(vel_ecef) - quatrot(quat_nedg2eci, wind)
+  const double w_ned[3] = {wn, we, 0.0};
+  double w_eci[3];
+  qrot(qconj(q_i2n), w_ned, w_eci);
+  const double va[3] = {(ve[0] * cs - ve[1] * sn) - w_eci[0], (ve[0] * sn + ve[1] * cs) - w_eci[1], ve[2] - w_eci[2]};
+  const double vn = norm3(va);
+  const double ux[3] = {1.0, 0.0, 0.0};
+  double tdir[3];
+  qrot(qconj(q), ux, tdir);
+  o[23] = tdir[0]; o[24] = tdir[1]; o[25] = tdir[2];
+  // angles of attack (lib/utils.py:92-161).  They take the altitude for the wind from the ECI position fed to
+  // ecef2geodetic; a rotation about z leaves that altitude unchanged up to rounding, so the wind above is reused.
+  {
+    const double tn = norm3(tdir);
+    const double ca_ = (va[0] / vn) * (tdir[0] / tn) + (va[1] / vn) * (tdir[1] / tn) + (va[2] / vn) * (tdir[2] / tn);
+    const double a_all = (ca_ >= 1.0 || vn < 0.001) ? 0.0 : acos(ca_);
+    const double a_deg = a_all * 180.0 / kPi;
+    o[28] = a_deg;
+    o[32] = a_deg * qdyn;
+    double vb[3];
+    qrot(q, va, vb);
+    const bool none = vb[0] < 0.001;
+    o[29] = none ? 0.0 : atan2(vb[2], vb[0]) * 180.0 / kPi;
+    o[30] = none ? 0.0 : atan2(vb[1], vb[0]) * 180.0 / kPi;
+  }
+  // euler_from_quat(quat_nedg2body) (lib/coordinate.py:488-528)
+  {
+    const Quat qb = qmul(qconj(q_i2n), q);
+    double az, el, ro;
+    if (2.0 * (qb.w * qb.y - qb.z * qb.x) >= 1.0) { el = kPi / 2; az = 0.0; ro = 0.0; }
+    else {
+      az = atan2(2.0 * (qb.w * qb.z + qb.x * qb.y), 1.0 - 2.0 * (qb.y * qb.y + qb.z * qb.z));
+      el = asin(2.0 * (qb.w * qb.y - qb.z * qb.x));
+      ro = atan2(2.0 * (qb.w * qb.x + qb.y * qb.z), 1.0 - 2.0 * (qb.x * qb.x + qb.y * qb.y));
+    }
+    if (az < 0.0) az += 2.0 * kPi;
+    o[18] = az * (180.0 / kPi); o[19] = el * (180.0 / kPi); o[20] = ro * (180.0 / kPi);
+  }
+  // Mach number, axial force and acceleration, thrust (:233-256)
+  const double mach = vn / air.a;
+  o[33] = mach;
+  o[27] = vn;
+  const double ca = interp_tab(mach, tb.ca, tb.cas, tb.Kc, 2, 1);
+  const double kf = 0.5 * air.rho * vn;
+  const double aero[3] = {kf * -va[0] * ph.area * ca, kf * -va[1] * ph.area * ca, kf * -va[2] * ph.area * ca};
+  double aero_b[3];
+  qrot(q, aero, aero_b);
+  const double thrust = ph.thrust - ph.nozzle * air.P;
+  o[0] = thrust;
+  o[17] = aero_b[0];
+  o[16] = (thrust + aero_b[0]) / mass;
+  // impact point, NaN where there is none (posLLH_IIP_FAA(.., fill_na = False), :258-260)
+  double la, lo;
+  iip_faa(pe, ve, la, lo);
+  const bool no_iip = (la == 0.0 && lo == 0.0);
+  o[3] = no_iip ? __builtin_nan("") : la;
+  o[4] = no_iip ? __builtin_nan("") : lo;
+}
+
+hipError_t launch_output(const ProblemDev& P, int M, const double* d_x, const double* d_tx, const int32_t* d_node_sec,
+                         double lat0, double lon0, double* d_out, hipStream_t s) {
+  hipLaunchKernelGGL(output_kernel, dim3((M + 63) / 64), dim3(64), sizeof(double) * staged_table_doubles(P.Kw, P.Kc), s, P, M, d_x, d_tx, d_node_sec,
+                     lat0, lon0, d_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_rows(const ProblemDev& P, int nlin, const LinRowDev* lin, int nfn, const FnRowDev* fr, int B,
                        const double* d_x, double* d_con, double* d_jfn, hipStream_t s) {
   if (B <= 0 || nlin + nfn <= 0) return hipSuccess;

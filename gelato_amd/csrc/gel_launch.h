@@ -34,6 +34,11 @@ hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes
 hipError_t launch_rows(const ProblemDev& P, int nlin, const LinRowDev* lin, int nfn, const FnRowDev* fr, int B,
                        const double* d_x, double* d_con, double* d_jfn, hipStream_t s);
 
+// post-processing table (output_result.py): kOutputColumns values per state node, see include/gelato_amd.h
+constexpr int kOutputColumns = 34;
+hipError_t launch_output(const ProblemDev& P, int M, const double* d_x, const double* d_tx, const int32_t* d_node_sec,
+                         double lat0, double lon0, double* d_out, hipStream_t s);
+
 // US-1976 layer table as the kernels expect it: Lmb[11] | Tmb[11] | Pb[11] | R[11] | pexp[11] | gR[11] | Hb[11] | 1/Tmb[11]
 constexpr int kAtmTableDoubles = 88;  // must equal kAtmDoubles of gel_physics.h (static_assert in gel_kernels.hip)
 void fill_atmosphere_table(double* atm);

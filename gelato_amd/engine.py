@@ -393,6 +393,23 @@ class Engine:
             out["rows_jfn"] = out["rows_jfn"][:self._nfn]
         return out
 
+    OUTPUT_COLUMNS = ["thrust", "lat", "lon", "lat_IIP", "lon_IIP", "downrange", "altitude", "altitude_apogee", "altitude_perigee",
+                      "inclination", "argument_perigee", "lon_ascending_node", "true_anomaly", "vel_ground_NED_X",
+                      "vel_ground_NED_Y", "vel_ground_NED_Z", "accel_BODY_X", "aero_BODY_X", "heading_NED2BODY", "pitch_NED2BODY",
+                      "roll_NED2BODY", "flightpath_vel_inertial_geocentric", "azimuth_vel_inertial_geocentric",
+                      "thrust_direction_ECI_X", "thrust_direction_ECI_Y", "thrust_direction_ECI_Z", "vel_ground", "vel_air",
+                      "AOA_total", "AOA_pitch", "AOA_yaw", "dynamic_pressure", "Q_alpha", "M"]   # gel_output_column
+
+    def output_table(self, x, tx_res, launch_lat, launch_lon):
+        """x [nvars], tx_res [M] (seconds) -> [M, 34] derived quantities of the reference's post-processing table
+        (output_result.py:121-262), columns OUTPUT_COLUMNS; one device thread per state node"""
+        x, tx = _f64(x), _f64(tx_res)
+        if x.shape != (self.nvars,) or tx.shape != (self.M,):
+            raise ValueError("x must have nvars entries and tx_res one time per state node")
+        out = np.empty((self.M, len(self.OUTPUT_COLUMNS)))
+        check(lib().gel_output_table(self._h, _d(x), _d(tx), float(launch_lat), float(launch_lon), _d(out)))
+        return out
+
     def initial_guess(self, t_ref, table, knot_times):
         """initialize.py:322-409 behind the C-ABI: reference trajectory (t_ref [n], table [n, 13] = mass | pos 3 | vel 3 |
         quat 4 | body rates y, z) interpolated at the mesh's node times -> packed decision vector"""

@@ -96,6 +96,8 @@ def build_pdict(vehicle, rows, knots, nodes, ps_params=None):
     unitdict = {"mass": m_init, "position": 6378137, "velocity": 1000.0, "u": 1.0, "t": params[-1]["time"]}
     # Trajectory_Optimization.py:167-176: terminal targets + the initial state (the launch site in ECI at t = 0, the
     # velocity of the ground there and the launcher's attitude: plain numbers in the vehicle file)
+    if "LaunchCondition" in vehicle:
+        pdict["LaunchCondition"] = dict(vehicle["LaunchCondition"])      # Trajectory_Optimization.py:103 (downrange origin)
     condition = {"OptimizationMode": vehicle["OptimizationMode"]}
     condition.update(vehicle.get("TerminalCondition", {}))
     condition.update(vehicle.get("FlightConstraint", {}))     # :169 (aero limits, waypoints, antennas)

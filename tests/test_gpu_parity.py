@@ -378,7 +378,8 @@ def test_batch_matches_single_and_oracle():
 
 
 @pytest.mark.parametrize("name,Bs", [("example", (1, 2, 3, 5, 30, 31)), ("mixed-6x64", (45, 46, 47, 257)),
-                                     ("stress-12x128", (11, 13))])
+                                     ("stress-12x128", (11, 13, 37, 70))])   # 37, 70: 10 / 18 vector groups = one / two
+                                                                             # blocks of eight plus a short one (launch order)
 def test_cooperative_dx_form_equals_single_vector_calls(name, Bs):
     """Throughput launches form D.X per WORKGROUP (four decision vectors side by side on the matrix pipe, one row
     tile per wavefront); batches that are not a multiple of four leave wavefronts without a vector of their own.
