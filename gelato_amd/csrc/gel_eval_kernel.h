@@ -365,13 +365,12 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         {
           // k-steps of A slabs in flight ahead of the matrix pipe (an L2 round trip each; requested before the barrier)
           constexpr int kAPF = JAC ? GEL_XLDS_A_PF_JAC : GEL_XLDS_A_PF_RES;
-          const int kfirst = 0;
 #ifdef GEL_ABL_NODX
           const int klast = 0;
 #else
           const int klast = ksteps;
 #endif
-          for (int ks = kfirst; ks < klast; ks += kAPF) {
+          for (int ks = 0; ks < klast; ks += kAPF) {
 #pragma unroll
             for (int i = 0; i < kAPF; i++) {
               if (ks + i < klast) {   // wave-uniform
@@ -684,7 +683,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
 #pragma unroll
         for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
         pp = pos_part(r, tb, P.barC20, GEL_WIND_BRACKET);
-        wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
+        wind_eci_or_calm(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] = PARK_GET(PK_V0 + c) * P.uv;
         aero_force(r, v, pp.rho, pp.inv_a, ea, w, ph.area, tb, F, GEL_CA_BRACKET);
@@ -784,7 +783,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
             const EarthAngle eq = earth_angle(tnp);
             double wq[3], Fp[3];
             const double rq[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
-            wind_eci(rq, eq, PARK_GET(PK_FP0), PARK_GET(PK_FP1), PARK_GET(PK_FP2), PARK_GET(PK_FP3), PARK_GET(PK_FP4), wq);
+            wind_eci_or_calm(rq, eq, PARK_GET(PK_FP0), PARK_GET(PK_FP1), PARK_GET(PK_FP2), PARK_GET(PK_FP3), PARK_GET(PK_FP4), wq);
             const double vq[3] = {PARK_GET(PK_V0) * P.uv, PARK_GET(PK_V1) * P.uv, PARK_GET(PK_V2) * P.uv};
             aero_force(rq, vq, PARK_GET(PK_Q0), PARK_GET(PK_Q1), eq, wq, ph.area, tb, Fp, GEL_CA_BRACKET);
             const double Tq[3] = {PARK_GET(PK_Q2), PARK_GET(PK_Q3), PARK_GET(PK_DJJ)};

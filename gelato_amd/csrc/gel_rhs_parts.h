@@ -15,6 +15,10 @@
 #pragma once
 #include "gel_physics.h"
 
+#ifndef GEL_CALM_SHORTCUT
+#define GEL_CALM_SHORTCUT 1
+#endif
+
 namespace gel {
 
 // depends on position only
@@ -125,6 +129,21 @@ GEL_DEV void wind_eci(const double r[3], const EarthAngle& e, double s_hp, doubl
   w[0] = q0 * t1 - q1 * t0 - q2 * t3 + q3 * t2;
   w[1] = q0 * t2 + q1 * t3 - q2 * t0 - q3 * t1;
   w[2] = q0 * t3 - q1 * t2 + q2 * t1 - q3 * t0;
+}
+
+// wind_eci unless the whole wavefront is in calm air: where both wind components are exactly zero (below / above the
+// measured part of a wind table, as in the shipped example from 23 km up) the rotation of the zero vector is the zero
+// vector, so its ~110 instructions are skipped -- six times per node in the fused kernel.  Non-finite components are not
+// zero and take the full path.
+GEL_DEV void wind_eci_or_calm(const double r[3], const EarthAngle& e, double s_hp, double c_hp, double inv_p, double wn,
+                              double we, double w[3]) {
+#if GEL_CALM_SHORTCUT
+  if (__builtin_amdgcn_ballot_w64(!(wn == 0.0 && we == 0.0)) == 0) {   // wave-uniform branch
+    w[0] = 0.0; w[1] = 0.0; w[2] = 0.0;
+    return;
+  }
+#endif
+  wind_eci(r, e, s_hp, c_hp, inv_p, wn, we, w);
 }
 
 // aerodynamic force (ECI): src/pybind_dynamics.cpp:48-59 given the shared parts
