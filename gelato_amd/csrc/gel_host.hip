@@ -1567,8 +1567,8 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
 }
 
 int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux, int32_t aux_rows, double* out) {
-  static const int nin[9] = {1, 3, 3, 6, 7, 1, 1, 2, 2}, nout[9] = {5, 3, 3, 3, 3, 3, 1, 4, 6};
-  if (kind < 0 || kind > 8 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
+  static const int nin[11] = {1, 3, 3, 6, 7, 1, 1, 2, 2, 8, 8}, nout[11] = {5, 3, 3, 3, 3, 3, 1, 4, 6, 8, 16};
+  if (kind < 0 || kind > 10 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
   if (n == 0) return GEL_OK;
   int rc = need_device();
   if (rc) return rc;
@@ -1578,8 +1578,8 @@ int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux,
   std::vector<double> ext;  // kinds 5 / 6: the table rows followed by their per-interval slopes
   if (kind == 0) { gel::fill_atmosphere_table(atm); hax = atm; naux = gel::kAtmTableDoubles; aux_rows = 0; }
   else if (kind == 2) { if (!aux) return fail(GEL_ERR_ARG, "kind 2 needs aux[0] = barC20"); naux = 1; aux_rows = 0; }
-  else if (kind == 5 || kind == 6) {
-    const int w = (kind == 5) ? 3 : 2;
+  else if (kind == 5 || kind == 6 || kind == 9 || kind == 10) {
+    const int w = (kind == 5 || kind == 10) ? 3 : 2;
     if (!aux || aux_rows < 2) return fail(GEL_ERR_ARG, "kinds 5 and 6 need a table of at least two rows");
     for (int k = 1; k < aux_rows; k++)
       if (!(aux[(size_t)w * k] > aux[(size_t)w * (k - 1)])) return fail(GEL_ERR_ARG, "table abscissae must increase strictly");

@@ -189,7 +189,8 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
   extern __shared__ double lds[];
   // aux table (wind [K][3] or generic [K][2]) and the atmosphere table are staged in LDS
   // kinds 5 / 6: rows followed by the per-interval slopes (built by the host entry point)
-  const int naux = (kind == 5) ? 3 * aux_rows + 2 * (aux_rows - 1) : (kind == 6) ? 2 * aux_rows + (aux_rows - 1) : (kind == 0 ? kAtmDoubles : 0);
+  const int naux = (kind == 5 || kind == 10) ? 3 * aux_rows + 2 * (aux_rows - 1)
+                   : (kind == 6 || kind == 9) ? 2 * aux_rows + (aux_rows - 1) : (kind == 0 ? kAtmDoubles : 0);
   for (int i = threadIdx.x; i < naux; i += blockDim.x) lds[i] = aux[i];
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,6 +254,18 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       sincos(in[2 * i], &s2, &c2);
       out[6 * i] = s1; out[6 * i + 1] = c1; out[6 * i + 2] = s2; out[6 * i + 3] = c2;
       out[6 * i + 4] = flog_ratio(in[2 * i + 1]); out[6 * i + 5] = log(in[2 * i + 1]);
+    } break;
+    case 9: {  // eight lookups in a row through the interval kept from the previous one (the fused kernel's CA lookups)
+      Bracket br = no_bracket();
+      for (int k = 0; k < 8; k++) out[8 * i + k] = interp_tab_cached(in[8 * i + k], lds, lds + 2 * aux_rows, aux_rows, 2, 1, br);
+    } break;
+    case 10: {  // likewise the wind lookups of a node's position evaluations
+      Bracket2 br = no_bracket2();
+      for (int k = 0; k < 8; k++) {
+        double wn, we;
+        wind_ned2_cached(in[8 * i + k], lds, lds + 3 * aux_rows, aux_rows, wn, we, br);
+        out[16 * i + 2 * k] = wn; out[16 * i + 2 * k + 1] = we;
+      }
     } break;
     default: break;
   }

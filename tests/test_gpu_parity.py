@@ -466,6 +466,45 @@ def test_two_vectors_per_wavefront_equal_one_vector_per_wavefront(name):
     assert np.isnan(r[5]).any() and np.isfinite(np.delete(r, 5, axis=0)).all()
 
 
+def test_lookups_through_a_kept_interval_equal_fresh_lookups():
+    """The fused kernel keeps the table interval of a node's previous CA / wind lookup and takes a short way when every
+    lane of the wavefront falls into its own kept interval.  Sequences that sit on breakpoints, cross them by an ulp or by
+    1e-8, leave the table at both ends, and carry NaN / inf -- different in every lane -- give the bits of fresh lookups."""
+    from gelato_amd.dynamics import point_eval
+    rng = np.random.default_rng(99)
+    xp = np.array([0.0, 0.7, 1.0, 1.5, 2.0, 5.0, 100.0])
+    tab = np.column_stack([xp, [0.3, 0.3, 0.65, 0.65, 0.6, 0.3, 0.3]])
+    alt = np.array([-1e8, 0.0, 1e3, 3e3, 1.1e4, 1.5e4, 1.6e4, 2.3e4, 1e10])
+    wind = np.column_stack([alt, 3.0 * np.sin(np.arange(9.0)), 10.0 * np.cos(np.arange(9.0))])
+    wind[[0, 1, -1], 1:] = 0.0
+    n = 64 * 40 + 17
+    for kind_c, kind_f, t, cols in ((9, 6, tab, 1), (10, 5, wind, 3)):
+        bp = t[:, 0]
+        base = bp[rng.integers(0, len(bp), n)]
+        seq = np.empty((n, 8))
+        seq[:, 0] = base * (1.0 - 1e-9) - 1e-12                       # just below a breakpoint
+        seq[:, 1] = base                                              # on it
+        seq[:, 2] = np.nextafter(base, np.inf)                        # an ulp above
+        seq[:, 3] = base * (1.0 + 1e-8) + 1e-8                        # a forward-difference step above
+        seq[:, 4] = seq[:, 3] + 1e-8 * np.abs(seq[:, 3])              # and another (same interval: the short way)
+        seq[:, 5] = rng.uniform(bp[0] - 1.0, min(bp[-1], 3e4) * 1.1, n)   # anywhere, also beyond both ends
+        seq[:, 6] = seq[:, 5] * (1.0 + 1e-8)
+        seq[:, 7] = seq[:, 6]
+        calm = rng.random(n) < 0.5                                    # half of the lanes stay put: wavefronts with hits AND misses
+        seq[calm, :] = seq[calm, 5:6] * (1.0 + 1e-9 * np.arange(8)[None, :])
+        seq[rng.integers(0, n, 25), rng.integers(0, 8, 25)] = np.nan
+        seq[rng.integers(0, n, 25), rng.integers(0, 8, 25)] = np.inf
+        seq[rng.integers(0, n, 25), rng.integers(0, 8, 25)] = -np.inf
+        got = point_eval(kind_c, seq, aux=t)
+        fresh = point_eval(kind_f, seq.ravel(), aux=t)
+        if kind_f == 5:
+            fresh = fresh[:, :2].reshape(n, 16)
+        else:
+            fresh = fresh.reshape(n, 8)
+        assert np.array_equal(got, fresh, equal_nan=True), (kind_c, np.argwhere(~((got == fresh) | (np.isnan(got) & np.isnan(fresh))))[:5])
+        assert np.isnan(got).any() and np.isfinite(got).any()
+
+
 def test_device_pointer_api_and_full_expansion():
     import torch
     prob, x0, _ = named_problem("mixed-6x64")
