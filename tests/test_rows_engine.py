@@ -164,6 +164,12 @@ def test_callbacks_carry_every_row_group_and_a_sticky_status():
             assert funcs[key] is not None and fs[key] is not None, key
         assert funcs["ineqcon_user"] is None and fs["ineqcon_user"] is None
         assert funcs["eqcon_knot"].shape == (121,) and funcs["eqcon_terminal"].shape == (2,)
+        # the shipped FlightConstraint: FAIRING altitude (exact) and impact-point longitude (min), one antenna at SECO
+        assert funcs["eqcon_pos"].shape == (1,) and funcs["ineqcon_iip"].shape == (1,) and funcs["ineqcon_antenna"].shape == (1,)
+        assert funcs["eqcon_iip"] is None and funcs["ineqcon_pos"] is None and fs["eqcon_iip"] is None and fs["ineqcon_pos"] is None
+        assert sorted(fs["eqcon_pos"]) == ["position", "t"] and sorted(fs["ineqcon_iip"]) == ["position", "t", "velocity"]
+        assert sorted(fs["ineqcon_antenna"]) == ["position", "t"]
+        assert len(funcs) == 23 and sorted(funcs) == sorted(fs)          # every key of Trajectory_Optimization.py:194-312
         # a NaN that only the terminal rows see (velocity of the very last node feeds no defect row's RHS ... but does
         # feed D.X of the last phase): whatever group sees it first, the callback reports it once, at the end
         bad = {k: v.copy() for k, v in xdict.items()}
