@@ -289,8 +289,9 @@ def main():
                            # restores negated / shared / structurally constant entries) -- `achieved` uses SURVEY 8(d)'s
                            # A_min as the contract prescribes, `traffic` shows the bytes that really moved
                            "stored_bytes_per_eval": 8 * E.nres if a.residual_only else E.stored_bytes,
-                           "note": "bound by the fp64 pipe (VALU + MFMA share it) and by the clock the chip holds under the "
-                                   "store stream, not by HBM bandwidth; see DESIGN.md 3.1"}
+                           "note": "bound by the fp64 pipe (VALU + MFMA share it; ~80 % busy) together with the store stream it "
+                                   "overlaps imperfectly (the launch moves its bytes at ~70 % of the pure-write rate of this "
+                                   "pattern), at the clock the chip holds under both; see DESIGN.md 3.1"}
     else:
         out["shard"] = {"step_ms": kern_ms, "step_ms_cold": kern_ms_cold,
                         "units_per_rank": [c for _, c in shards.ranges],
