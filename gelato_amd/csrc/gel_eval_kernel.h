@@ -13,7 +13,7 @@
 // inputs are in registers, and what the velocity group needs late is parked in
 // LDS (its own lgkmcnt) instead of being re-read or kept in VGPRs.
 //
-// Register discipline (fp64 = 2 VGPRs per value, 64-wide; 112 VGPRs -> 4 waves
+// Register discipline (fp64 = 2 VGPRs per value, 64-wide; <= 128 VGPRs -> 4 waves
 // per SIMD): the heavy chain (geodetic -> atmosphere -> wind -> Earth-angle
 // quaternion -> aero) has ONE instance, in a loop whose LAST trip is the centre
 // point and leaves through `break`; across a trip only the node position, the
@@ -61,7 +61,7 @@ static_assert(wave_lds_doubles(false, true, true) >= kParkRes && wave_lds_double
 constexpr int kSlotPT = 0, kSlotVM = 3, kSlotVP = 6;
 
 #ifndef GEL_MIN_WAVES_PER_SIMD
-#define GEL_MIN_WAVES_PER_SIMD 4  // 112 VGPRs, no scratch: 4 waves/SIMD (16 per CU, matching the LDS budget); 5 spills
+#define GEL_MIN_WAVES_PER_SIMD 4  // 121-128 VGPRs: 4 waves/SIMD (16 per CU, matching the LDS budget); 5 spills heavily
 #endif
 #ifndef GEL_MIN_WAVES_PER_SIMD_RES
 #define GEL_MIN_WAVES_PER_SIMD_RES 5  // residual-only, two vectors per wavefront: 94 VGPRs, 25 KB of LDS per workgroup
