@@ -223,8 +223,9 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
 #else
   // Buffer store: wave-uniform resource (base = this wavefront's first value), lane offset in a VGPR, slot offset
   // on the scalar unit -- no vector address arithmetic at all (69 v_lshl_add_u64 gone, 4 VGPRs less).  Streamed
-  // once and never re-read by this kernel: non-temporal.  Measured: nt over plain stores -2..4 %, buffer form
-  // over global_store another -1.8 %.
+  // once and never re-read by this kernel: non-temporal.  Measured: nt over plain stores -2..4 % in round 1; with the
+  // round-2 kernel (less arithmetic per stored byte) -7 % on mixed-6x64 and -15 % on 12x128 (sc0 like plain, sc1 and
+  // sc1+nt +25..45 % slower); buffer form over global_store another -1.8 %.
   typedef unsigned gel_u2 __attribute__((ext_vector_type(2)));
   const __amdgpu_buffer_rsrc_t jrs =
 #ifdef GEL_ABL_SAMEADDR  // ablation: every vector writes over vector 0's values (same instructions, L2-resident target)
