@@ -40,12 +40,19 @@ static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wav
 // wavefronts of its workgroup still write their tiles.
 constexpr int kCoopStageOff = PK_LV0 * 64;
 static_assert(kWaveLds - kCoopStageOff >= 64 * 11, "the cooperative hand-over area must fit behind the early park slots");
+#ifndef GEL_XLDS_PIPE
+#define GEL_XLDS_PIPE 1  // longer phases: double-buffered LDS slabs of state rows (1) or operands from global memory (0)
+#endif
+#ifndef GEL_XLDS_PIPE_FROM
+#define GEL_XLDS_PIPE_FROM 68  // ... from this many nodes per phase on (below: one slab, staged at once)
+#endif
 // Residual-only instantiations park PK_Q0 .. PK_LV2 only: their region is the D.X operand image (cooperative LDS-staged
 // form: a 68-row slab, or two 36-row vectors when two decision vectors share a wavefront), the hand-over area over it and
 // then, once the wavefront has taken its rows, the park over that -- 6 KB instead of 9.5 KB per wavefront.
 constexpr int kSlabRowsMax = 68, kPackRows = 36, kParkRes = (PK_LV2 + 1) * 64;
+constexpr int kPipeSlabK = 11;   // k-steps per double-buffered slab of the long-phase form (44 state rows)
 constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack) {
-  return jac ? kWaveLds : (!mfma ? kParkRes : (pack ? 2 * kPackRows * 11 : kSlabRowsMax * 11));
+  return jac ? kWaveLds : (!mfma ? kParkRes : (pack ? 2 * kPackRows * 11 : (GEL_XLDS_PIPE ? 2 * 4 * kPipeSlabK * 11 : kSlabRowsMax * 11)));
 }
 static_assert(wave_lds_doubles(false, true, true) >= 64 * 11 && wave_lds_doubles(false, true, false) >= 64 * 11, "hand-over area");
 static_assert(wave_lds_doubles(false, true, true) >= kParkRes && wave_lds_doubles(false, true, false) >= kParkRes, "residual-only park");
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   // 8-byte global loads in the matrix loop.  Measured against fetching B per k-step from global memory (same box,
   // B = 16384 / 65536): fused launch -2 % at 6x64, residual-only -9 % at 3x32; with two slabs (n = 128) the extra
   // workgroup barriers cost what the loads save (residual-only +10 %), so longer phases keep the global form.
-  const bool XLDS = PACK || (COOP && (GEL_COOP_XLDS != 0) && n < 68);   // wave-uniform
+  const bool XLDS = PACK || (COOP && (GEL_COOP_XLDS != 0) && (n < 68 || GEL_XLDS_PIPE));   // wave-uniform: the node's own state row comes from LDS
   double me = 0.0, re[3] = {0.0, 0.0, 0.0};
   if (!XLDS) { me = xm[xj]; re[0] = xr[3 * xj]; re[1] = xr[3 * xj + 1]; re[2] = xr[3 * xj + 2]; }
   const double tau = P.tau[ph.toff + jc];
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
     // D.X rows (lib/con_dynamics.py:54,146,256,524)
     double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
     if (rb) {
-      if (XLDS) {
+      if (XLDS && (PACK || n < GEL_XLDS_PIPE_FROM || !GEL_XLDS_PIPE)) {
         // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP, operands as in the branch below, but B comes from LDS: every wavefront
         // stages ITS OWN vector's n + 1 <= 68 state rows (17 k-steps) -- lane = row, the eleven interleaved columns (mass |
         // pos xyz | vel xyz | quat wxyz) side by side, [row][11] at the start of its region -- and all four read the 44
@@ -418,6 +425,99 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
 #pragma unroll
         for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
+#if GEL_XLDS_PIPE
+      } else if (XLDS) {
+        // Longer phases (GEL_XLDS_PIPE_FROM nodes and more): the LDS-staged product in slabs of 44 state rows (11 k-steps), double
+        // buffered -- the rows of slab s + 1 are requested before slab s is multiplied and written to the other buffer after,
+        // one workgroup barrier per slab.  11 row-coalesced loads per wavefront and slab instead of 3 scattered 8-byte
+        // loads per lane and k-step (the texture addresser sees ~5x fewer line accesses at 128 nodes).
+        const int c16 = lane & 15, kq = lane >> 4;
+        constexpr int kPipeK = kPipeSlabK, kPipeRows = 4 * kPipeK, kPipeBuf = kPipeRows * 11;
+        static_assert(!COOP || PACK || 2 * kPipeBuf <= kWL, "two slab buffers must fit the wave's region");
+        lds_double* regions = (lds_double*)lds + park_off;
+        int xoff[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) {
+          const int c = 16 * ct + c16;
+          const int vb = min(c / 11, 3);
+          xoff[ct] = vb * kWL + ((c < 44) ? c - 11 * vb : 0) + kq * 11;
+        }
+        gel_double4 acc[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
+        const double* ap = P.Dst + (size_t)dsw * 4 + wv * 64 + lane;
+        const int ksteps = (n + 4) >> 2, nslab = (ksteps + kPipeK - 1) / kPipeK;
+        const int own = jc + 1;
+        double st[11];
+        const bool stager = lane < kPipeRows;
+#define GEL_PIPE_LOAD(slab)                                                              \
+  do {                                                                                   \
+    const int _k = (slab) * kPipeRows + lane;                                            \
+    const bool _in = stager && _k <= n;                                                  \
+    const int _xk = ph.xa + (_in ? _k : 0);                                              \
+    st[0] = _in ? xm[_xk] : 0.0;                                                         \
+    _Pragma("unroll") for (int c = 0; c < 3; c++) { st[1 + c] = _in ? xr[3 * _xk + c] : 0.0; st[4 + c] = _in ? xv[3 * _xk + c] : 0.0; } \
+    _Pragma("unroll") for (int c = 0; c < 4; c++) st[7 + c] = _in ? xq[4 * _xk + c] : 0.0; \
+  } while (0)
+#define GEL_PIPE_WRITE(buf)                                                              \
+  do {                                                                                   \
+    if (stager) {                                                                        \
+      lds_double* _d = wave_lds + (buf) * kPipeBuf + lane * 11;                          \
+      _Pragma("unroll") for (int c = 0; c < 11; c++) _d[c] = st[c];                      \
+    }                                                                                    \
+  } while (0)
+        GEL_PIPE_LOAD(0);
+        double a = ap[0];
+        GEL_PIPE_WRITE(0);
+        __syncthreads();
+        for (int sl = 0; sl < nslab; sl++) {
+          const int bo = (sl & 1) * kPipeBuf;
+          if (sl + 1 < nslab) GEL_PIPE_LOAD(sl + 1);      // in flight while this slab multiplies
+          const int k0 = sl * kPipeK, kcount = min(kPipeK, ksteps - k0);
+          for (int ks = 0; ks < kcount; ks++) {
+            const double a_next = ap[min(k0 + ks + 1, ksteps - 1) * 256];
+            const int ro = bo + ks * 44;
+            const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl2, acc[2], 0, 0, 0);
+            a = a_next;
+          }
+          {
+            const int ol = own - sl * kPipeRows;          // the node's own state row, if it lies in this slab
+            if (ol >= 0 && ol < kPipeRows) {
+              lds_double* src = wave_lds + bo + ol * 11;
+              me = src[0];
+#pragma unroll
+              for (int c = 0; c < 3; c++) { re[c] = src[1 + c]; ve[c] = src[4 + c]; }
+#pragma unroll
+              for (int c = 0; c < 4; c++) q[c] = src[7 + c];
+            }
+          }
+          if (sl + 1 < nslab) GEL_PIPE_WRITE((sl + 1) & 1);
+          __syncthreads();                                // slab sl is consumed everywhere, slab sl + 1 is in place
+        }
+#undef GEL_PIPE_LOAD
+#undef GEL_PIPE_WRITE
+        lds_double* wg_lds = regions + kHO;
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) {
+          const int c = 16 * ct + c16;
+          const int vb = c / 11, col = c - 11 * vb;
+          if (c < 44) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) wg_lds[vb * kWL + (16 * wv + kq + 4 * i) * 11 + col] = acc[ct][i];
+          }
+        }
+        __syncthreads();
+        if (ghost) return;
+        lds_double* row = wave_lds + kHO + lane * 11;
+        lm = row[0];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
+#pragma unroll
+        for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
+#endif
       } else if (COOP && !PACK) {
         // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP: A = the work item's rows of D, shared by all four wavefronts;
         // B = the 11 state columns of the workgroup's four decision vectors side by side (44 of 48 columns used,
