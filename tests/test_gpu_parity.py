@@ -1027,6 +1027,45 @@ def test_random_problem_structures_values(seed):
     assert rc == 0 and np.array_equal(res[B - 1], res1) and np.array_equal(E.expand(jv[B - 1]), vals1)
 
 
+@pytest.mark.parametrize("nn", [(68,), (131,), (200, 5), (87, 129, 64)])
+def test_long_phases_slab_staged_product(nn):
+    """Phases of 68 nodes and more form D.X from double-buffered 44-row slabs of state rows: 2 .. 5 slabs, ragged last
+    slabs and ragged last chunks, against the oracle and -- the same vector inside a batch -- against the split form."""
+    prob, _, _ = named_problem("example")
+    rng = np.random.default_rng(sum(nn))
+    S = len(nn)
+    prob = dict(prob)
+    prob["num_nodes"] = np.array(nn, dtype=np.int32)
+    prob["engine_on"] = np.ones(S, dtype=np.int32)
+    prob["thrust"] = rng.uniform(1e4, 5e5, S)
+    prob["massflow"] = rng.uniform(1.0, 150.0, S)
+    prob["reference_area"] = np.where(np.arange(S) % 2 == 0, 2.0, 0.0)
+    prob["nozzle_area"] = rng.uniform(0.0, 1.0, S)
+    prob["attitude_hold"] = np.zeros(S, dtype=np.int32)
+    E, P = make_pair(prob)
+    N, M = E.N, E.M
+    up = prob["units"][1]
+    lat = rng.uniform(-1.0, 1.0, M)
+    lon = rng.uniform(-np.pi, np.pi, M)
+    R = (6378137.0 - 21385.0 * np.sin(lat) ** 2 + rng.uniform(0.0, 150e3, M)) / up
+    pos = np.column_stack([R * np.cos(lat) * np.cos(lon), R * np.cos(lat) * np.sin(lon), R * np.sin(lat)])
+    vel = rng.standard_normal((M, 3)) * rng.uniform(0.05, 4.0, (M, 1))
+    quat = rng.standard_normal((M, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([0.2 + rng.random(M), pos.ravel(), vel.ravel(), quat.ravel(), rng.standard_normal(2 * N),
+                        np.sort(rng.random(S + 1))])
+    res1, vals1 = check_against_oracle(E, P, x, "long-%s" % (nn,))
+    for B in (300, 517):                                             # cooperative form (not the split latency form); ragged groups
+        X = np.tile(x, (B, 1))
+        X[B // 2] *= 1.0 + 1e-9
+        res, jv, rc = E.eval_batch(X)
+        assert rc == 0 and E.launch_info(B)[2] == 0
+        assert np.array_equal(res[B - 1], res1) and np.array_equal(E.expand(jv[B - 1]), vals1)
+        assert np.array_equal(res[0], res1) and not np.array_equal(res[B // 2], res1)
+        r2, _, rc = E.eval_batch(X, want_jac=False)                  # the residual-only launch stages the same way
+        assert rc == 0 and np.array_equal(r2, res)
+
+
 def test_path_sincos_and_log_accuracy():
     """gel::fsincos (|x| <= 3 pi/4: latitudes, half Earth angles) and gel::flog_ratio (0.5 < x < 2: temperature ratios
     inside a layer) against numpy: at most 1 ulp resp. 2 ulp off the correctly rounded value, and not more often
