@@ -3,7 +3,12 @@
 // One wavefront = one (decision vector b, phase, 64-node chunk) work item; one
 // lane = one collocation node.  The phase is wave-uniform: its parameters sit in
 // SGPRs, every phase-type branch (air / NoAir, hold, engine off) is a scalar
-// branch, and the X rows of the D.X product are scalar (SMEM, broadcast) loads.
+// branch.  Forms (template parameters):
+//   throughput (MFMA, !SPLIT): a workgroup = one work item x four decision vectors, D.X formed together on the
+//     matrix pipe from state rows staged in LDS -- at once for phases below 68 nodes, in double-buffered 44-row
+//     slabs above; PACK (every phase <= 32 nodes): two vectors per wavefront, eight per workgroup;
+//   latency (SPLIT, a handful of vectors): four wavefronts per work item, one position sweep each;
+//   !MFMA: wavefront dot-products with scalar (SMEM, broadcast) X loads -- selectable, not the default.
 //
 // Memory discipline: vector-memory operations retire in order (one vmcnt per
 // wave), so a global load issued after a store waits for that store to drain to
