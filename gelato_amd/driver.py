@@ -13,13 +13,47 @@ from . import con_aero, con_dynamics, con_trajectory, con_user, con_waypoint
 from . import con_init_terminal_knot as con_a
 from .cost_gradient import cost_6DoF, cost_jac
 
-# wrt map of the four groups (Trajectory_Optimization.py:361-364)
+# wrt map of every constraint group (Trajectory_Optimization.py:356-383)
 WRT = {
+    "eqcon_init": ["mass", "position", "velocity", "quaternion"],
+    "eqcon_time": ["t"],
     "eqcon_dyn_mass": ["mass", "t"],
     "eqcon_dyn_pos": ["position", "velocity", "t"],
     "eqcon_dyn_vel": ["mass", "position", "velocity", "quaternion", "t"],
     "eqcon_dyn_quat": ["quaternion", "u", "t"],
+    "eqcon_knot": ["mass", "position", "velocity", "quaternion"],
+    "eqcon_terminal": ["position", "velocity"],
+    "eqcon_rate": ["u"],
+    "eqcon_pos": ["position", "t"],
+    "eqcon_iip": ["position", "velocity", "t"],
+    "eqcon_user": ["mass", "position", "velocity", "quaternion", "u", "t"],
+    "ineqcon_alpha": ["position", "velocity", "quaternion", "t"],
+    "ineqcon_q": ["position", "velocity", "quaternion", "t"],
+    "ineqcon_qalpha": ["position", "velocity", "quaternion", "t"],
+    "ineqcon_mass": ["mass"],
+    "ineqcon_kick": ["u"],
+    "ineqcon_time": ["t"],
+    "ineqcon_pos": ["position", "t"],
+    "ineqcon_iip": ["position", "velocity", "t"],
+    "ineqcon_antenna": ["position", "t"],
+    "ineqcon_user": ["mass", "position", "velocity", "quaternion", "u", "t"],
 }
+
+
+def constraint_groups(f_init, jac_init, condition):
+    """What the reference hands to ``optProb.addConGroup`` for every group that exists (Trajectory_Optimization.py:385-421):
+    (key, size, lower, upper, wrt, jac); equality groups are pinned to 0, inequality groups are >= 0; in Payload mode
+    the initial mass is free."""
+    wrt = {k: list(v) for k, v in WRT.items()}
+    if condition["OptimizationMode"] == "Payload":
+        wrt["eqcon_init"] = ["position", "velocity", "quaternion"]
+    out = []
+    for key, val in f_init.items():
+        if key == "obj" or val is None:
+            continue
+        size = len(val) if hasattr(val, "__len__") else 1
+        out.append((key, size, 0.0, None if "ineqcon" in key else 0.0, wrt[key], jac_init[key]))
+    return out
 
 
 def make_callbacks(pdict, unitdict, condition):

@@ -170,6 +170,16 @@ def test_callbacks_carry_every_row_group_and_a_sticky_status():
         assert sorted(fs["eqcon_pos"]) == ["position", "t"] and sorted(fs["ineqcon_iip"]) == ["position", "t", "velocity"]
         assert sorted(fs["ineqcon_antenna"]) == ["position", "t"]
         assert len(funcs) == 23 and sorted(funcs) == sorted(fs)          # every key of Trajectory_Optimization.py:194-312
+        # the registration the reference does with pyoptsparse: every existing group with its wrt list; the Jacobian of a
+        # group names exactly variables of that list (a block the list lacks would be dropped silently by addConGroup)
+        groups = driver.constraint_groups(funcs, fs, condition)
+        assert len(groups) == sum(v is not None for k, v in funcs.items() if k != "obj")
+        for key, size, lo, up, wrt, jac in groups:
+            assert set(jac) <= set(wrt), (key, sorted(jac), wrt)
+            assert size == np.size(funcs[key]) and lo == 0.0 and (up is None) == key.startswith("ineqcon")
+            for var, blk in jac.items():
+                shape = blk["shape"] if isinstance(blk, dict) else blk.shape
+                assert shape[0] == size, (key, var, shape)
         # a NaN that only the terminal rows see (velocity of the very last node feeds no defect row's RHS ... but does
         # feed D.X of the last phase): whatever group sees it first, the callback reports it once, at the end
         bad = {k: v.copy() for k, v in xdict.items()}
