@@ -505,6 +505,51 @@ def test_lookups_through_a_kept_interval_equal_fresh_lookups():
         assert np.isnan(got).any() and np.isfinite(got).any()
 
 
+@pytest.mark.parametrize("name,B,jac", [("mixed-6x64", 16384, True), ("dense-6x64", 16384, True), ("stress-12x128", 4096, True),
+                                        ("3x32", 65536, False)])
+def test_full_size_batches_size_independent_properties(name, B, jac):
+    """The bench's own launches (BASELINE.json configs at their full batch sizes), checked through properties that do not
+    need a reference of that size: equal decision vectors give equal output rows wherever they sit in the batch (the batch
+    tiles 256 distinct vectors), the reversed batch gives the reversed output, a second launch reproduces the first bit for
+    bit, everything is finite, and sampled rows are the single-vector (split latency form) results."""
+    import torch
+    from gelato_amd import Engine, problem
+    prob, x0, _ = named_problem(name)
+    E = Engine(prob)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    P = 256
+    Xd = problem.synthetic_batch(x0, E.M, P, seed=3)
+    dXd = torch.from_numpy(Xd).to(dev)
+    dX = dXd.repeat(B // P, 1).contiguous()
+    dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    djv = torch.empty((B, E.V), dtype=torch.float64, device=dev) if jac else None
+    E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr() if jac else 0, s)
+    assert E.sync(s) == 0
+    outs = [dres] + ([djv] if jac else [])
+    for o in outs:
+        assert bool(torch.isfinite(o).all())
+        t = o.view(B // P, P, -1)
+        assert bool((t == t[0:1]).all()), "equal vectors, different rows"
+    # determinism
+    dres2 = torch.empty_like(dres)
+    djv2 = torch.empty_like(djv) if jac else None
+    E.eval_batch_device(B, dX.data_ptr(), dres2.data_ptr(), djv2.data_ptr() if jac else 0, s)
+    assert E.sync(s) == 0 and torch.equal(dres2, dres) and (not jac or torch.equal(djv2, djv))
+    # the reversed batch
+    dXr = torch.flip(dX, dims=[0]).contiguous()
+    E.eval_batch_device(B, dXr.data_ptr(), dres2.data_ptr(), djv2.data_ptr() if jac else 0, s)
+    assert E.sync(s) == 0 and torch.equal(torch.flip(dres2, dims=[0]), dres) and (not jac or torch.equal(torch.flip(djv2, dims=[0]), djv))
+    # sampled rows against single-vector calls
+    for b in (0, 77, P - 1):
+        if jac:
+            r1, v1, rc = E.eval(Xd[b])
+            assert rc == 0 and np.array_equal(dres[b].cpu().numpy(), r1) and np.array_equal(djv[B - P + b].cpu().numpy(), v1[E.var_index()])
+        else:
+            r1, rc = E.eval_residual(Xd[b])
+            assert rc == 0 and np.array_equal(dres[B - P + b].cpu().numpy(), r1)
+
+
 def test_device_pointer_api_and_full_expansion():
     import torch
     prob, x0, _ = named_problem("mixed-6x64")
