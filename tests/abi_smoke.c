@@ -75,6 +75,12 @@ int main(int argc, char** argv) {
   double* vals = malloc(sizeof(double) * dm.total_nnz);
   if (!gpu) {
     CHECK(gel_eval_residual(p, x, res) == GEL_ERR_HIP); /* host-only handles never evaluate */
+    {
+      static double tx[77], table[77 * GEL_OUTPUT_COLUMNS];
+      CHECK(gel_output_table(p, x, tx, 42.5, 143.4, table) == GEL_ERR_HIP);
+      CHECK(gel_output_table(p, x, NULL, 42.5, 143.4, table) == GEL_ERR_ARG);
+      CHECK(GEL_OUT_MACH == GEL_OUTPUT_COLUMNS - 1);
+    }
     CHECK(gel_problem_destroy(p) == GEL_OK);
     printf("abi_smoke host OK\n");
     return 0;
