@@ -56,17 +56,27 @@ class _State:
         self.status = 0
         self._frame = None      # everything the device produced for the last xdict (one round trip)
         self._frame_sig = None
+        # begin_callback() .. end_callback(): the caller vouches that this xdict object is not modified in between, so its
+        # packed copy is formed once and the frame is recognised by identity instead of an element-wise comparison
+        self._pinned = None
+        self._pinned_x = None
+        self._pinned_cond = None
 
     def frame(self, xdict, need_jac):
         """All device outputs for `xdict`: the first function of a callback that asks evaluates the four defect groups,
         the knot / terminal / user row table and the aero path constraints -- whatever is configured on the handle -- in
         ONE round trip (gel_eval_callback); the other functions of the callback read their share.  A derivative asked
         for after a values-only frame of the same xdict re-evaluates with derivatives."""
-        x = pack_x(xdict)
+        if xdict is self._pinned:
+            if self._pinned_x is None:
+                self._pinned_x = pack_x(xdict)
+            x = self._pinned_x
+        else:
+            x = pack_x(xdict)
         eng = self.engine
         sig = eng._cfg_gen      # a frame is only valid for the row table / aero specs it was evaluated with
         fr = self._frame
-        if fr is None or self._frame_sig != sig or (need_jac and not fr["jac"]) or not np.array_equal(fr["x"], x):
+        if fr is None or self._frame_sig != sig or (need_jac and not fr["jac"]) or not (fr["x"] is x or np.array_equal(fr["x"], x)):
             fr = dict(eng.eval_callback(x, need_jac))
             fr["x"], fr["jac"] = x, bool(need_jac)
             self._frame, self._frame_sig = fr, sig
@@ -104,6 +114,25 @@ def reset_status(pdict):
     st = pdict.get(_KEY)
     if st is not None:
         st.status = 0
+
+
+def begin_callback(pdict, xdict):
+    """First line of objfunc / sens: resets the sticky status and pins `xdict` -- until end_callback() the caller vouches
+    that this dict and its arrays are not modified, so the ~15 constraint functions of the callback share one packed copy
+    and recognise their frame by identity (saves ~0.1 ms of host time per callback at 6 x 64)."""
+    st = pdict.get(_KEY)
+    if st is not None:
+        st.status = 0
+        st._pinned, st._pinned_x, st._pinned_cond = xdict, None, None
+
+
+def end_callback(pdict):
+    """Last line of objfunc / sens: -> the callback's status (0 fine, 1 some output was NaN / Inf); unpins xdict."""
+    st = pdict.get(_KEY)
+    if st is None:
+        return 0
+    st._pinned, st._pinned_x, st._pinned_cond = None, None, None
+    return st.status
 
 
 def note_status(pdict, rc):

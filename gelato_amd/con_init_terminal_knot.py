@@ -242,6 +242,8 @@ class _Rows:
 def rows_of(pdict, unitdict, condition):
     """The (cached) row table of this problem; rebuilt when the terminal targets or the user rows change."""
     st = con_dynamics._state(pdict, unitdict)
+    if st._pinned_cond is condition and st.__dict__.get("rows") is not None:
+        return st.rows[1]           # inside begin_callback() .. end_callback(): the key was checked once for this callback
     user = tuple(tuple(r) for r in (pdict.get("gelato_amd_user_rows") or ()))
     key = (id(condition), condition["OptimizationMode"], tuple(condition.get(k) for k in (
         "altitude_perigee", "altitude_apogee", "inclination", "radius", "vel_tangential_geocentric",
@@ -250,6 +252,8 @@ def rows_of(pdict, unitdict, condition):
     cached = st.__dict__.get("rows")
     if cached is None or cached[0] != key:
         st.rows = (key, _Rows(pdict, unitdict, condition, user))
+    if st._pinned is not None:
+        st._pinned_cond = condition
     return st.rows[1]
 
 

@@ -69,7 +69,7 @@ def make_callbacks(pdict, unitdict, condition):
                    for st in pdict["RocketStage"].values()) and all("attitude" in q for q in pdict["params"])
 
     def objfunc(xdict):
-        con_dynamics.reset_status(pdict)         # the status is sticky over ALL device evaluations of this callback
+        con_dynamics.begin_callback(pdict, xdict)    # sticky status over ALL device evaluations of this callback; xdict pinned
         funcs = {"obj": cost_6DoF(xdict, condition)}
         if rows:  # Trajectory_Optimization.py:197-198,212-216,220,233,241
             funcs["eqcon_init"] = con_a.equality_init(xdict, pdict, unitdict, condition)
@@ -95,10 +95,10 @@ def make_callbacks(pdict, unitdict, condition):
             funcs["ineqcon_alpha"] = con_aero.inequality_max_alpha(xdict, pdict, unitdict, condition)
             funcs["ineqcon_q"] = con_aero.inequality_max_q(xdict, pdict, unitdict, condition)
             funcs["ineqcon_qalpha"] = con_aero.inequality_max_qalpha(xdict, pdict, unitdict, condition)
-        return funcs, bool(con_dynamics.last_status(pdict))
+        return funcs, bool(con_dynamics.end_callback(pdict))
 
     def sens(xdict, funcs):
-        con_dynamics.reset_status(pdict)
+        con_dynamics.begin_callback(pdict, xdict)
         fs = {"obj": cost_jac(xdict, condition)}
         if rows:  # Trajectory_Optimization.py:248-249,264-269,279-281,297-299,309-311
             fs["eqcon_init"] = con_a.equality_jac_init(xdict, pdict, unitdict, condition)
@@ -124,7 +124,7 @@ def make_callbacks(pdict, unitdict, condition):
             fs["ineqcon_alpha"] = con_aero.inequality_jac_max_alpha(xdict, pdict, unitdict, condition)
             fs["ineqcon_q"] = con_aero.inequality_jac_max_q(xdict, pdict, unitdict, condition)
             fs["ineqcon_qalpha"] = con_aero.inequality_jac_max_qalpha(xdict, pdict, unitdict, condition)
-        return fs, bool(con_dynamics.last_status(pdict))
+        return fs, bool(con_dynamics.end_callback(pdict))
 
     return objfunc, sens
 
