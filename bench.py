@@ -15,6 +15,7 @@ vectors per rank, no data-path collective) -> "scaling": "weak".  Rank 0 prints 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,6 +26,41 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def launcher_command(n_gpus, argv, port=None):
+    """The command that runs this script as `n_gpus` ranks, one per GPU, over RCCL: what the driver itself uses for N > 1
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:   # a free port of this host; nothing here touches the GPU
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n_gpus, argv, dry=False):
+    """`bench.py --gpus N` typed without torch.distributed.run: start the N ranks as a CHILD process (never an exec:
+    this process has not touched HIP yet and must not, the child ranks own the GPUs), relay rank 0's JSON line and
+    the exit code.  Fails loudly -- it never falls back to one rank."""
+    cmd = launcher_command(n_gpus, argv)
+    if dry:
+        print(json.dumps({"launcher": cmd}))
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if pr.returncode != 0 or len(lines) != 1:
+        sys.stdout.write(pr.stdout)
+        raise SystemExit("bench.py --gpus %d: the %d-rank child run failed (exit code %d, %d result lines)"
+                         % (n_gpus, n_gpus, pr.returncode, len(lines)))
+    line = json.loads(lines[0])
+    if line.get("n_gpus") != n_gpus:
+        raise SystemExit("bench.py --gpus %d: the child run reported n_gpus = %r" % (n_gpus, line.get("n_gpus")))
+    print(lines[0])
+    return 0
 
 
 def cpu_baseline(prob, D, tau, X, gpu_first=None, budget_s=12.0, residual_only=False):
@@ -134,7 +170,20 @@ def main():
                     help="RHS + defect residuals only, no Jacobian (BASELINE.json configs[1]: 3x32 residual only vs CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational full-COO and B=1 legs")
+    ap.add_argument("--dry-launcher", action="store_true", help="print the N-rank launcher command and exit (no GPU touched)")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # ---- N ranks: before torch is imported and before anything touches HIP ----
+    world_env = os.environ.get("WORLD_SIZE")
+    if "RANK" not in os.environ:
+        if a.gpus > 1 or a.dry_launcher:
+            argv = [v for v in sys.argv[1:] if v != "--dry-launcher"]
+            raise SystemExit(launch_ranks(a.gpus, argv, dry=a.dry_launcher))
+    elif int(world_env or "1") != a.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE = %s: the rank count and --gpus must agree "
+                         "(the line reports n_gpus = WORLD_SIZE and nothing else)" % (a.gpus, world_env))
 
     import torch
     import torch.distributed as dist
@@ -261,6 +310,7 @@ def main():
     out = {
         "metric": "residual+Jacobian evals/sec (and ms/eval), 6-phase x 64-node LGR mesh",
         "value": evals / T, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
+        "world_size": world, "collective_backend": ("nccl (RCCL over xGMI)" if use_dist else None),
         "ms_per_step": 1e3 * T / K, "ms_per_eval": 1e3 * T / (B * K), "higher_is_better": True,
         "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         # the same K steps timed right after the W warm-up steps from an idle GPU, i.e. inside the chip's

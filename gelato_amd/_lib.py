@@ -80,8 +80,6 @@ SIGNATURES = {
     "gel_eval_batch": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
     "gel_eval_batch_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gel_expand_full_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gel_eval_shard_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                         C.c_int32, C.c_void_p]),
     "gel_eval_shard_units_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_void_p]),
     "gel_unit_owner": (C.c_int, [C.c_void_p, _ip, _ip]),

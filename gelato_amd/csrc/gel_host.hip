@@ -936,21 +936,6 @@ int gel_eval_batch_device(gel_problem* p, int32_t B, const double* d_x, double* 
   return GEL_OK;
 }
 
-int gel_eval_shard_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar,
-                          int32_t chunk_begin, int32_t chunk_count, void* stream) {
-  if (!p || !d_x || B < 1 || (!d_res && !d_jvar)) return fail(GEL_ERR_ARG, "bad argument");
-  NEED_DEVICE(p);
-  if (chunk_begin < 0 || chunk_count < 0 || chunk_begin + chunk_count > p->dev.nchunks)
-    return fail(GEL_ERR_ARG, "work-item range out of bounds");
-  if (chunk_count == 0) return GEL_OK;
-  gel::ProblemDev dv = p->dev;
-  dv.chunks = p->d_chunks;  // shard ranges index the phase-ordered list
-  dv.chunk0 = chunk_begin;
-  dv.nchunks = chunk_count;
-  HIPCHK(gel::launch_eval(dv, B, d_x, d_res, d_jvar, stream ? (hipStream_t)stream : p->stream));
-  return GEL_OK;
-}
-
 int gel_eval_shard_units_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar,
                                 int32_t unit_begin, int32_t unit_count, void* stream) {
   if (!p || !d_x || B < 1 || !d_jvar) return fail(GEL_ERR_ARG, "bad argument (the unit form always writes Jacobian values)");

@@ -257,10 +257,6 @@ class Engine:
         check(lib().gel_unit_owner(self._h, ro.ctypes.data_as(_ip), jo.ctypes.data_as(_ip)))
         return ro, jo
 
-    def eval_shard_device(self, B, d_x, d_res, d_jvar, chunk_begin, chunk_count, stream=0):
-        check(lib().gel_eval_shard_device(self._h, B, d_x, d_res or None, d_jvar or None, int(chunk_begin),
-                                          int(chunk_count), stream or None))
-
     def eval_shard_units_device(self, B, d_x, d_res, d_jvar, unit_begin, unit_count, stream=0):
         """unit = 4 * work_item + part (part 0: all but the three position sweeps; 1..3: one position sweep)."""
         check(lib().gel_eval_shard_units_device(self._h, B, d_x, d_res or None, d_jvar, int(unit_begin),

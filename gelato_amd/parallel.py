@@ -25,19 +25,6 @@ def replica_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def chunk_costs(engine_or_desc):
-    """Relative cost of every work item (64-node chunk), from its phase type: an aerodynamic phase
-    runs the heavy chain 4x + 2 time sweeps, a NoAir phase only gravity.  Accepts an Engine (host-only
-    is enough) or a dict with chunk_phase / reference_area / attitude_hold arrays."""
-    if isinstance(engine_or_desc, dict):
-        ph, area, hold = engine_or_desc["chunk_phase"], engine_or_desc["reference_area"], engine_or_desc["attitude_hold"]
-    else:
-        e = engine_or_desc
-        ph, area, hold = e.chunk_phase(), e.prob["reference_area"], e.prob["attitude_hold"]
-    cost = np.where(np.asarray(area)[ph] != 0.0, 10.0, 1.5) + np.where(np.asarray(hold)[ph] != 0, 0.0, 0.5)
-    return cost
-
-
 def unit_costs(engine_or_desc):
     """Relative cost of every unit = (work item, part) in unit-id order 4 * item + part: part 0 is the centre
     evaluation with the light sweeps, parts 1..3 one position sweep (plus a centre evaluation) each; phases
@@ -142,29 +129,6 @@ class UnitShards:
         self.pack(res, jvar, send)
         dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
         return self.unpack(recv, res, jvar, skip=self.rank)
-
-
-def all_reduce_owned(buffers, group=None):
-    """Sum all-reduce of buffers whose every entry is non-zero on at most one rank (its owner)."""
-    import torch.distributed as dist
-    for b in buffers:
-        if b is not None:
-            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
-    return buffers
-
-
-def phase_sharded_eval(evaluate_range, res, jvar, ranges, rank, group=None):
-    """Generic driver of the phase-shard mode.  `evaluate_range(begin, count, res, jvar)` must fill
-    ONLY the entries owned by work items [begin, begin+count) (gel_eval_shard_device does exactly
-    that); res / jvar are torch tensors that this function zeroes first and all-reduces after."""
-    res.zero_()
-    if jvar is not None:
-        jvar.zero_()
-    begin, count = ranges[rank]
-    if count > 0:
-        evaluate_range(begin, count, res, jvar)
-    all_reduce_owned([res, jvar], group)
-    return res, jvar
 
 
 def max_over_ranks(value, device=None, group=None):

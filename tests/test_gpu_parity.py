@@ -727,36 +727,6 @@ def test_full_size_batch_properties():
 # --------------------------------------------------------------------------
 # multi-GPU phase shards, exercised on one GPU: disjoint work-item ranges fill disjoint entries
 # --------------------------------------------------------------------------
-def test_phase_shards_compose_to_the_full_evaluation():
-    import torch
-    from gelato_amd import parallel, problem
-    prob, x0, _ = named_problem("mixed-6x64")
-    E, _ = make_pair(prob)
-    B = 3
-    X = problem.synthetic_batch(x0, E.M, B)
-    dev = torch.device("cuda:0")
-    dX = torch.from_numpy(X).to(dev)
-    s = torch.cuda.current_stream().cuda_stream
-    ref_r = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
-    ref_j = torch.empty((B, E.V), dtype=torch.float64, device=dev)
-    E.eval_batch_device(B, dX.data_ptr(), ref_r.data_ptr(), ref_j.data_ptr(), s)
-    assert E.sync(s) == 0
-    for world in (2, 4, 8):
-        ranges = parallel.shard_chunks(parallel.chunk_costs(E), world)
-        tot_r = torch.zeros_like(ref_r)
-        tot_j = torch.zeros_like(ref_j)
-        for rank in range(world):                       # what each rank would hold before the all-reduce
-            r = torch.zeros_like(ref_r)
-            jv = torch.zeros_like(ref_j)
-            b, c = ranges[rank]
-            E.eval_shard_device(B, dX.data_ptr(), r.data_ptr(), jv.data_ptr(), b, c, s)
-            assert E.sync(s) == 0
-            assert torch.all((tot_r == 0) | (r == 0)) and torch.all((tot_j == 0) | (jv == 0))   # disjoint owners
-            tot_r += r
-            tot_j += jv
-        assert torch.equal(tot_r, ref_r) and torch.equal(tot_j, ref_j)
-
-
 @pytest.mark.parametrize("name,B", [("mixed-6x64", 3), ("example", 1), ("mixed-6x64", 300)])
 def test_unit_shards_compose_to_the_full_evaluation(name, B):
     """BASELINE.json configs[3]: phases AND Jacobian columns dealt to GPUs.  unit = 4 * work item + part; every

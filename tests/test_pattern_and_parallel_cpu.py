@@ -274,3 +274,36 @@ def test_random_problem_structures_pattern_and_constants(seed):
             # entry may be 0 at both points, e.g. d/dquaternion of a zero-thrust phase)
             b += 1
     assert b == 13 and len(np.unique(vidx)) == E.V
+
+
+# --------------------------------------------------------------------------
+# bench.py --gpus N: the launcher (N ranks as a child torch.distributed.run, before anything touches HIP)
+# --------------------------------------------------------------------------
+def _bench(args, env=None, timeout=300):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_launcher_command_is_formed():
+    import json
+    pr = _bench(["--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-launcher"])
+    assert pr.returncode == 0, pr.stderr
+    cmd = json.loads(pr.stdout)["launcher"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "20", "--warmup", "5"]     # the ranks get the caller's own flags
+
+
+def test_bench_gpus_2_without_gpus_fails_loudly_instead_of_running_one_rank():
+    pr = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert pr.returncode != 0
+    assert '"metric"' not in pr.stdout                      # no line, in particular no n_gpus: 1 line
+    assert "2-rank child run failed" in pr.stderr
+
+
+def test_bench_rank_count_must_agree_with_gpus_flag():
+    pr = _bench(["--gpus", "8"], env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert pr.returncode != 0 and "must agree" in pr.stderr and '"metric"' not in pr.stdout
