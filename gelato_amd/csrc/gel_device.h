@@ -11,6 +11,7 @@ struct PhaseDev {
   int32_t n, ua, xa;
   int32_t air;        // reference_area != 0  -> dynamics_velocity, else _NoAir (lib/con_dynamics.py:257,346)
   int32_t air_fd;     // reference_area  > 0  -> velocity / t0 / tf sweeps are finite differences (:403,454)
+  int32_t t_fd;       // air_fd and GEL_FLAG_FD_RECOMPUTE: the t0 / tf columns by two more sweeps (else in closed form, tf = -t0)
   int32_t engine_on;  // lib/con_dynamics.py:53,80
   int32_t hold;       // attitude in ("hold","vertical")  (lib/con_dynamics.py:521,559)
   int32_t K;          // compact Jacobian slots per node of this phase
@@ -33,7 +34,7 @@ __device__ __forceinline__ T load_const(const T* p) {
 __device__ __forceinline__ PhaseDev load_phase(const PhaseDev* g) {
   PhaseDev q;
   q.n = load_const(&g->n); q.ua = load_const(&g->ua); q.xa = load_const(&g->xa);
-  q.air = load_const(&g->air); q.air_fd = load_const(&g->air_fd); q.engine_on = load_const(&g->engine_on);
+  q.air = load_const(&g->air); q.air_fd = load_const(&g->air_fd); q.t_fd = load_const(&g->t_fd); q.engine_on = load_const(&g->engine_on);
   q.hold = load_const(&g->hold); q.K = load_const(&g->K);
   q.s_vv = load_const(&g->s_vv); q.s_vq = load_const(&g->s_vq); q.s_vt = load_const(&g->s_vt); q.s_qq = load_const(&g->s_qq);
   q.doff = load_const(&g->doff); q.toff = load_const(&g->toff); q.voff = load_const(&g->voff);
@@ -72,6 +73,7 @@ struct ProblemDev {
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
   int32_t unit0, nunits;     // split form only: first unit and number of units (unit = 4 * work item + part)
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)
+  int32_t fd_recompute;      // GEL_FLAG_FD_RECOMPUTE: every finite-difference sweep re-runs the reference's chain
   const int4* chunks;        // [nchunks] {phase, first node of the chunk, offset of its MFMA-ordered D in Dsw / 4,
                              //  (position in the run of this phase's chunks) << 16 | chunks of the phase in the list}:
                              // dearest phase type first for a whole launch, the natural (phase) order for a

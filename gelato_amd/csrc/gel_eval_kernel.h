@@ -218,9 +218,14 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   const double* xq = xb + 7 * M;
   const double* xu = xb + 11 * M;
   const double* xt = xb + 11 * M + 2 * N;
-  const double to = xt[sec], tf = xt[sec + 1];
+  // wave-uniform scalars live in SGPRs (two decision vectors per wavefront: per half, so they stay vector values there)
+#define GEL_UNI(v) (PACK ? (v) : wave_uniform(v))
+  const double to = GEL_UNI(xt[sec]), tf = GEL_UNI(xt[sec + 1]);
   const double dx = P.dx, ut = P.ut;
-  double chk = 0.0;  // running sum of everything written: NaN/Inf detector
+  // NaN / Inf detector: lanes that wrote a non-finite value, accumulated on the scalar unit (a running per-lane sum would hold
+  // two VGPRs for the whole kernel)
+  unsigned long long bad = 0;
+#define GEL_CHK(v) (bad |= __builtin_amdgcn_ballot_w64(!(fabs(v) <= 1.79769313486231570815e308)))
 
   double* rb = (res && lead) ? res + (size_t)b * 11 * N : nullptr;
 #ifdef GEL_ABL_NOSTORE  // ablation (tools/variant.sh): everything computed, (almost) nothing stored
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   do {                                                    \
     const double _v = (val);                              \
     if (_v == 1.2345e300) jb[(byteoff) / 8] = _v;         \
-    chk += _v;                                            \
+    GEL_CHK(_v);                                            \
   } while (0)
 #else
   // Buffer store: wave-uniform resource (base = this wavefront's first value), lane offset in a VGPR, slot offset
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
     gel_u2 _d;                                                                          \
     __builtin_memcpy(&_d, &_v, 8);                                                      \
     __builtin_amdgcn_raw_buffer_store_b64(_d, jrs, jvo, (byteoff), GEL_STORE_AUX);      \
-    chk += _v;                                                                          \
+    GEL_CHK(_v);                                                                          \
   } while (0)
 #endif
 #define EMIT(slot, val) EMIT_AT((int)(slot) * cw8, val)
@@ -267,9 +272,9 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   // Jacobian entry from a perturbed/centre pair: -(f_p - f_c)/dx*(tf-to)*unit_t/2  (con_dynamics.py:372),
   // as (f_c - f_p) times the wave-uniform scale (tf-to)*unit_t/2/dx
   const double inv_dx = 1.0 / dx;
-  const double fds = inv_dx * (tf - to) * ut / 2.0;
-  const double fdt = inv_dx * ut / 2.0;
-  const double inv_uv = 1.0 / P.uv;
+  const double fds = GEL_UNI(inv_dx * (tf - to) * ut / 2.0);
+  const double fdt = GEL_UNI(inv_dx * ut / 2.0);
+  const double inv_uv = GEL_UNI(1.0 / P.uv);
 #define FDQ(fp, fc) (((fc) - (fp)) * fds)
 
   // ======================= phase A: every global load =======================
@@ -694,7 +699,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
           const double rh = fq[c] * (tf - to) * ut / 2.0;
           const double cq = lq[c] - rh;
           RSTORE(7 * N + 4 * g + c, cq);  // ordinary store: the interleaved residual rows are partial lines that
-          chk += cq;                   // L2 merges; written non-temporally they cost 4 % more HBM writes (PMC)
+          GEL_CHK(cq);                   // L2 merges; written non-temporally they cost 4 % more HBM writes (PMC)
         }
       }
       if (JAC) {
@@ -732,20 +737,20 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         cm = me - m0;
       }
       RSTORE(g, cm);
-      chk += cm;
+      GEL_CHK(cm);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const double rh = ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
         const double cp = lr[c] - rh;
         RSTORE(N + 3 * g + c, cp);
-        chk += cp;
+        GEL_CHK(cp);
       }
       if (ph.hold) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const double cq = q[c] - q0[c];
           RSTORE(7 * N + 4 * g + c, cq);
-          chk += cq;
+          GEL_CHK(cq);
         }
       }
     }
@@ -761,150 +766,233 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
     const double inv_m = frcp(me * P.um);
 
     if (ph.air) {
-      const EarthAngle ea = earth_angle(tn);  // position sweeps do not change it
-      // Trips k = 0,1,2: position sweeps (pos_k + dx); trip k = 3: centre, leaves by break.  Nothing but
-      // the node position, the Earth angle and 1/m stays in registers across a trip: velocity and thrust
-      // direction are re-formed from the park after the atmosphere chain, sweep results go to the park.
-      PosPart pp;
-      double v[3], dir[3], w[3], F[3], T, fp8 = 0.0;
+      EarthHalf eh;   // position sweeps do not change the Earth angle; only its half-angle pair is kept (full_angle())
+      {
+        const EarthAngle e0 = earth_angle(tn);
+        eh.ch = e0.ch; eh.sh = e0.sh;
+      }
+      // Order of this branch (register and park discipline; the kernel runs 4 waves/SIMD on 128 VGPRs and a spilled value
+      // would be reloaded through vmcnt, i.e. behind every Jacobian store in flight):
+      // (1) the centre evaluation; the intermediates of its position part that the position sweeps will need (PosCentre) go to
+      //     the park as soon as they exist -- FP0-7 at once, LV0-2 once the velocity defect has been stored;
+      // (2) the light sweeps (velocity, quaternion, mass) and the t columns, while the centre's wind, force, gravity and
+      //     thrust are in registers, where they then die; the centre value f_c and the thrust direction go to Q0-3 / DJJ;
+      // (3) the three position sweeps in exact-difference form (pos_delta(): the change of altitude, atmosphere and wind from
+      //     algebraic identities, ~130 operations instead of the ~450 of a second run of the chain), reading PosCentre back
+      //     from the park, each sweep's three entries written at once;
+      // (4) a wavefront with a lane the difference form does not cover (perturbed point in another atmosphere layer or table
+      //     piece, node next to the polar axis), and every wavefront of a problem created with GEL_FLAG_FD_RECOMPUTE, re-runs
+      //     the chain on the perturbed position like the reference does;
+      // (5) GEL_FLAG_FD_RECOMPUTE only: the t0 / tf sweeps.
+      // The scaled position r = re * unit is formed where it is used (fresh_product) instead of living next to re.
+      PosCentreTail pt;
+      double cen_rho = 0.0, cen_P = 0.0, cen_inv_a = 0.0;   // the centre's density, pressure, 1 / speed of sound
+      double dir2 = 0.0;   // z component of the thrust direction (x, y are parked)
 #if GEL_CA_CACHE
       Bracket ca_br = no_bracket();   // the node's Mach interval, shared by all of its aerodynamic-force evaluations
 #define GEL_CA_BRACKET (JAC ? &ca_br : (Bracket*)nullptr)   // a residual-only launch looks up once
 #else
 #define GEL_CA_BRACKET nullptr
 #endif
-#if GEL_WIND_CACHE
-      Bracket2 w_br = no_bracket2();  // the node's altitude interval in the wind table, shared by its four position evaluations
-#define GEL_WIND_BRACKET ((JAC && !SPLIT) ? &w_br : (Bracket2*)nullptr)
-#else
-#define GEL_WIND_BRACKET nullptr
-#endif
-#pragma unroll 1
-#ifdef GEL_ABL_NOPOS  // ablation: no position sweeps (their Jacobian slots are written with whatever the park holds)
-      for (int k = 3;; k = SPLIT ? 3 : k + 1) {
-#else
-      for (int k = SPLIT ? (part ? part - 1 : 3) : (JAC ? 0 : 3);; k = SPLIT ? 3 : k + 1) {
-#endif
-        double r[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
-        pp = pos_part(r, tb, P.barC20, GEL_WIND_BRACKET);
+      struct ParkSink { lds_double* park; GEL_DEV void put(int i, double v) const { park[(PK_FP0 + i) * 64] = v; } };
+      static_assert(PCS_COUNT == 8 && PK_FP7 == PK_FP0 + 7, "PosCentre's early members fill FP0-7");
+      {
+        PosPart pp;
+        double v[3], w[3], F[3], dir[3];
+        const EarthAngle ea = full_angle(eh);
+        const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
+        if (JAC) pp = pos_part<true, ParkSink>(r, tb, P.barC20, nullptr, ParkSink{park}, &pt);
+        else pp = pos_part(r, tb, P.barC20);
         wind_eci_or_calm(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] = PARK_GET(PK_V0 + c) * P.uv;
         aero_force(r, v, pp.rho, pp.inv_a, ea, w, ph.area, tb, F, GEL_CA_BRACKET);
-        T = ph.thrust - ph.nozzle * pp.P;
+        // thrust = T * direction is formed where it is used (T from the parked pressure): three registers instead of eight
+#define GEL_T (ph.thrust - ph.nozzle * pp.P)
+#define GEL_TDC(name) const double name[3] = {GEL_T * dir[0], GEL_T * dir[1], GEL_T * dir[2]}
         {
           const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
           thrust_dir(q, dir);
         }
-        const double Td[3] = {T * dir[0], T * dir[1], T * dir[2]};
-        accel(Td, F, inv_m, pp.g, inv_uv, fc);
-        if (k == 3) break;
-        // park the sweep result (9 values: 8 LDS slots + one register)
-        if (k < 2) {
-#pragma unroll
-          for (int c = 0; c < 3; c++) PARK_SET(PK_FP0 + 3 * k + c, fc[c]);
-        } else {
-          PARK_SET(PK_FP6, fc[0]);
-          PARK_SET(PK_FP7, fc[1]);
-          fp8 = fc[2];
-        }
-      }
-      // here pp, w, F, T, v, dir, fc are the centre values
-      if (JAC && SPLIT && part) {
-        // this wavefront's one position sweep (parked like in the unsplit form)
-        const int k = part - 1;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const int i = 3 * k + c;
-          EMIT(kSlotVP + i, FDQ((i < 8) ? PARK_GET(PK_FP0 + i) : fp8, fc[c]));
-        }
-      }
-      if (JAC && lead) {
-        if (!SPLIT) {
-#pragma unroll
-          for (int i = 0; i < 8; i++) EMIT(kSlotVP + i, FDQ(PARK_GET(PK_FP0 + i), fc[i % 3]));
-          EMIT(kSlotVP + 8, FDQ(fp8, fc[2]));
-        }
-
-        // The position-sweep slots are free now.  Values that only LATER blocks need leave the registers:
-        // the t0/tf sweeps' inputs (half-latitude pair, 1/p, wind) and the centre aero force.
-        PARK_SET(PK_FP0, pp.shp); PARK_SET(PK_FP1, pp.chp); PARK_SET(PK_FP2, pp.inv_p); PARK_SET(PK_FP3, pp.wn); PARK_SET(PK_FP4, pp.we);
-        PARK_SET(PK_FP5, F[0]); PARK_SET(PK_FP6, F[1]); PARK_SET(PK_FP7, F[2]);
-        asm volatile("" ::: "memory");
-
-        const double r[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
-        const double Tdc[3] = {T * dir[0], T * dir[1], T * dir[2]};
-        double f[3];
-        // velocity sweeps: only the aerodynamic force changes
-        if (ph.air_fd) {
-          const double djj = PARK_GET(PK_DJJ);
-#pragma unroll 1
-          for (int k = 0; k < 3; k++) {
-            double vp[3], Fp[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) vp[c] = ((k == c) ? (PARK_GET(PK_V0 + c) + dx) : PARK_GET(PK_V0 + c)) * P.uv;
-            aero_force(r, vp, pp.rho, pp.inv_a, ea, w, ph.area, tb, Fp, GEL_CA_BRACKET);
-            accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
-            // submat_vel[3j+c, 3(j+1)+k] = D[j][j+1]*(c==k) + rh_vel   (con_dynamics.py:341-343,415-416)
-#pragma unroll
-            for (int c = 0; c < 3; c++) EMIT(ph.s_vv + 3 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fc[c]));
-          }
-        }
-        const double Fc[3] = {PARK_GET(PK_FP5), PARK_GET(PK_FP6), PARK_GET(PK_FP7)};
-        // quaternion sweeps: only the thrust direction changes
         {
-          const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
-#pragma unroll 1
-          for (int k = 0; k < 4; k++) {
-            double qp[4];
+          GEL_TDC(Tdc);
+          accel(Tdc, F, inv_m, pp.g, inv_uv, fc);
+        }
+        if (rb) {  // velocity defect (:216-289)
 #pragma unroll
-            for (int c = 0; c < 4; c++) qp[c] = (k == c) ? (q[c] + dx) : q[c];
-            double dp[3];
-            thrust_dir(qp, dp);
-            const double Td[3] = {T * dp[0], T * dp[1], T * dp[2]};
-            accel(Td, Fc, inv_m, pp.g, inv_uv, f);
-#pragma unroll
-            for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
+          for (int c = 0; c < 3; c++) {
+            const double rh = fc[c] * (tf - to) * ut / 2.0;
+            const double cv = PARK_GET(PK_LV0 + c) - rh;
+            RSTORE(4 * N + 3 * g + c, cv);
+            GEL_CHK(cv);
           }
         }
-        // mass sweep: only the division by mass changes
-        accel(Tdc, Fc, frcp((me + dx) * P.um), pp.g, inv_uv, f);
-#pragma unroll
-        for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
-        // t0 / tf sweeps (con_dynamics.py:452-480): only the Earth angle changes
-        if (ph.air_fd) {
-          // quaternion, D[j][j+1] and force slots are free now: the rest of what these two sweeps need is
-          // parked there, so that only the node position lives in registers across the sincos chains of
-          // earth_angle()
-          PARK_SET(PK_Q0, pp.rho); PARK_SET(PK_Q1, pp.inv_a); PARK_SET(PK_Q2, Tdc[0]); PARK_SET(PK_Q3, Tdc[1]); PARK_SET(PK_DJJ, Tdc[2]);
-          PARK_SET(PK_FP5, pp.g[0]); PARK_SET(PK_FP6, pp.g[1]); PARK_SET(PK_FP7, pp.g[2]);
+        if (JAC) {   // the half-latitude pair and 1/p wait in the slots of the D.X row for the position sweeps
+          asm volatile("" ::: "memory");
+          PARK_SET(PK_LV0, pp.shp); PARK_SET(PK_LV1, pp.chp); PARK_SET(PK_LV2, pp.inv_p);
+        }
+        if (JAC && lead) {
+          double f[3];
+          // velocity sweeps: only the aerodynamic force changes
+          if (ph.air_fd) {
+            const double djj = PARK_GET(PK_DJJ);
 #pragma unroll 1
-          for (int k = 0; k < 2; k++) {
-            asm volatile("" ::: "memory");  // re-read the park inside every trip
-            const double to_p = (k == 0) ? to + dx : to;
-            const double tf_p = (k == 1) ? tf + dx : tf;
-            const double tnp = tau * (tf_p - to_p) / 2 + (tf_p + to_p) / 2;
-            const EarthAngle eq = earth_angle(tnp);
-            double wq[3], Fp[3];
-            const double rq[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
-            wind_eci_or_calm(rq, eq, PARK_GET(PK_FP0), PARK_GET(PK_FP1), PARK_GET(PK_FP2), PARK_GET(PK_FP3), PARK_GET(PK_FP4), wq);
-            const double vq[3] = {PARK_GET(PK_V0) * P.uv, PARK_GET(PK_V1) * P.uv, PARK_GET(PK_V2) * P.uv};
-            aero_force(rq, vq, PARK_GET(PK_Q0), PARK_GET(PK_Q1), eq, wq, ph.area, tb, Fp, GEL_CA_BRACKET);
-            const double Tq[3] = {PARK_GET(PK_Q2), PARK_GET(PK_Q3), PARK_GET(PK_DJJ)};
-            const double gq[3] = {PARK_GET(PK_FP5), PARK_GET(PK_FP6), PARK_GET(PK_FP7)};
-            accel(Tq, Fp, inv_m, gq, inv_uv, f);
-            // -(f_p*(tf_p - to_p) - f_c*(tf - to))/dx*unit_t/2   (con_dynamics.py:463-477)
+            for (int k = 0; k < 3; k++) {
+              double vp[3], Fp[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-              EMIT(ph.s_vt + 3 * k + c, (fc[c] * (tf - to) - f[c] * (tf_p - to_p)) * fdt);
+              for (int c = 0; c < 3; c++) vp[c] = ((k == c) ? (PARK_GET(PK_V0 + c) + dx) : PARK_GET(PK_V0 + c)) * P.uv;
+              const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
+              aero_force(r, vp, pp.rho, pp.inv_a, ea, w, ph.area, tb, Fp, GEL_CA_BRACKET);
+              GEL_TDC(Tdc);
+              accel(Tdc, Fp, inv_m, pp.g, inv_uv, f);
+              // submat_vel[3j+c, 3(j+1)+k] = D[j][j+1]*(c==k) + rh_vel   (con_dynamics.py:341-343,415-416)
+#pragma unroll
+              for (int c = 0; c < 3; c++) EMIT(ph.s_vv + 3 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fc[c]));
+            }
           }
-        } else {
+          // quaternion sweeps: only the thrust direction changes
+          {
+            const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+              double qp[4];
 #pragma unroll
-          for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * ut / 2.0);  // t0 column; tf = its negative (:478-480)
+              for (int c = 0; c < 4; c++) qp[c] = (k == c) ? (q[c] + dx) : q[c];
+              double dp[3];
+              thrust_dir(qp, dp);
+              const double Td[3] = {GEL_T * dp[0], GEL_T * dp[1], GEL_T * dp[2]};
+              accel(Td, F, inv_m, pp.g, inv_uv, f);
+#pragma unroll
+              for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
+            }
+          }
+          // mass sweep: only the division by mass changes
+          {
+            GEL_TDC(Tdc);
+            accel(Tdc, F, frcp((me + dx) * P.um), pp.g, inv_uv, f);
+          }
+#pragma unroll
+          for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
+          // t0 / tf columns (con_dynamics.py:452-480): their two sweeps move only the Earth angle -- and the RHS does not depend on
+          // it: the rotation by omega t is applied and undone (src/Coordinate.cpp:41-59), and the NED axes at an inertial position
+          // do not move with t, so f_p = f_c up to rounding and the reference's quotient -(f_p (tf_p - to_p) - f_c (tf - to))/dx ut/2
+          // is +-f_c ut/2 plus the noise of f_p - f_c (measured against the reference's own values: <= 2e-6 on entries of 109,
+          // 1e-8 typically).  The entries are therefore written in that closed form, which is also what the reference itself
+          // uses for the phases without aerodynamics (:478-480); GEL_FLAG_FD_RECOMPUTE keeps the two sweeps (below).
+          if (!ph.t_fd) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * ut / 2.0);  // t0 column; tf = its negative
+          }
+        }
+        if (JAC) {   // quaternion and D[j][j+1] are no longer needed: their slots take f_c and the thrust direction
+          asm volatile("" ::: "memory");
+          PARK_SET(PK_Q0, fc[0]); PARK_SET(PK_Q1, fc[1]); PARK_SET(PK_Q2, fc[2]); PARK_SET(PK_Q3, dir[0]); PARK_SET(PK_DJJ, dir[1]);
+          dir2 = dir[2];
+          cen_rho = pp.rho; cen_P = pp.P; cen_inv_a = pp.inv_a;
+        }
+#undef GEL_TDC
+#undef GEL_T
+      }
+      // position sweeps (lib/con_dynamics.py:381-400); SPLIT: this wavefront's one
+#ifndef GEL_ABL_NOPOS
+      if (JAC && (!SPLIT || part)) {
+        const int k0 = SPLIT ? part - 1 : 0, k1 = SPLIT ? part : 3;
+        // the tail of a sweep, given the position part at the perturbed point
+#define GEL_POS_SWEEP_TAIL(kk, rp, pq)                                                                        \
+  do {                                                                                                        \
+    double wq_[3], Fp_[3], f_[3];                                                                             \
+    const EarthAngle ea = full_angle(eh);                                                                     \
+    wind_eci_or_calm(rp, ea, (pq).shp, (pq).chp, (pq).inv_p, (pq).wn, (pq).we, wq_);                          \
+    const double vq_[3] = {PARK_GET(PK_V0) * P.uv, PARK_GET(PK_V1) * P.uv, PARK_GET(PK_V2) * P.uv};           \
+    aero_force(rp, vq_, (pq).rho, (pq).inv_a, ea, wq_, ph.area, tb, Fp_, GEL_CA_BRACKET);                     \
+    const double Tp_ = ph.thrust - ph.nozzle * (pq).P;                                                        \
+    const double Td_[3] = {Tp_ * PARK_GET(PK_Q3), Tp_ * PARK_GET(PK_DJJ), Tp_ * dir2};                        \
+    accel(Td_, Fp_, inv_m, (pq).g, inv_uv, f_);                                                               \
+    _Pragma("unroll") for (int c = 0; c < 3; c++) EMIT(kSlotVP + 3 * (kk) + c, FDQ(f_[c], PARK_GET(PK_Q0 + c))); \
+  } while (0)
+        unsigned todo = 0;   // sweeps left to the recomputing loop (wave-uniform)
+        if (P.fd_recompute) {
+          todo = ((1u << k1) - 1u) & ~((1u << k0) - 1u);
+        } else {
+#pragma unroll 1
+          for (int k = k0; k < k1; k++) {
+            asm volatile("" ::: "memory");   // PosCentre is read from the park inside every trip
+            PosCentre pc;
+            pc.p = PARK_GET(PK_FP0 + PCS_P); pc.ih = PARK_GET(PK_FP0 + PCS_IH); pc.ihy = PARK_GET(PK_FP0 + PCS_IHY);
+            pc.sl = PARK_GET(PK_FP0 + PCS_SL); pc.cl = PARK_GET(PK_FP0 + PCS_CL); pc.icl = PARK_GET(PK_FP0 + PCS_ICL);
+            pc.N = PARK_GET(PK_FP0 + PCS_N); pc.G = PARK_GET(PK_FP0 + PCS_G);
+            PosPart pcv;   // the centre's position part as far as pos_delta() reads it
+            pcv.rho = cen_rho; pcv.P = cen_P; pcv.inv_a = cen_inv_a;
+            pcv.shp = PARK_GET(PK_LV0); pcv.chp = PARK_GET(PK_LV1); pcv.inv_p = PARK_GET(PK_LV2);
+            pos_centre_tail(pt, cen_rho, cen_P, tb, pc, pcv.wn, pcv.we);
+            const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
+            double rp[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) rp[c] = (k == c) ? (re[c] + dx) * P.up : r[c];
+            const double dlt = (k == 0) ? rp[0] - r[0] : ((k == 1) ? rp[1] - r[1] : rp[2] - r[2]);   // exact
+            PosPart pq;
+            if (__builtin_amdgcn_ballot_w64(!pos_delta(r, k, dlt, pcv, pc, tb, pq)) != 0) { todo |= 1u << k; continue; }
+            gravity_eci(rp, P.barC20, pq.g);
+            GEL_POS_SWEEP_TAIL(k, rp, pq);
+          }
+        }
+#ifndef GEL_EXP_NOFALLBACK
+        if (todo) {
+#pragma unroll 1
+          for (int k = k0; k < k1; k++) {
+            if (!((todo >> k) & 1u)) continue;
+            asm volatile("" ::: "memory");
+            double rp[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) rp[c] = fresh_product((k == c) ? re[c] + dx : re[c], P.up);
+            const PosPart pq = pos_part(rp, tb, P.barC20);
+            GEL_POS_SWEEP_TAIL(k, rp, pq);
+          }
+        }
+#endif
+#undef GEL_POS_SWEEP_TAIL
+      }
+#endif
+#ifndef GEL_EXP_NOTFD
+      if (JAC && lead && ph.t_fd) {
+        // GEL_FLAG_FD_RECOMPUTE: the t0 / tf sweeps (con_dynamics.py:452-480); only the Earth angle changes.  This form is for
+        // audits, not for speed: the position part of the centre is formed once more (bit-identical) and parked, so that only
+        // the node position lives in registers across the sincos chains of earth_angle(); quaternion and node abscissa are
+        // fetched again (a load behind the stores: it waits for them).
+        asm volatile("" ::: "memory");
+        const double fcc[3] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2)};
+        const double tau2 = P.tau[ph.toff + jc];
+        {
+          const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
+          const PosPart p2 = pos_part(r, tb, P.barC20);
+          const double T2 = ph.thrust - ph.nozzle * p2.P;
+          PARK_SET(PK_FP0, p2.shp); PARK_SET(PK_FP1, p2.chp); PARK_SET(PK_FP2, p2.inv_p); PARK_SET(PK_FP3, p2.wn); PARK_SET(PK_FP4, p2.we);
+          PARK_SET(PK_FP5, p2.rho); PARK_SET(PK_FP6, p2.inv_a);
+          PARK_SET(PK_LV0, p2.g[0]); PARK_SET(PK_LV1, p2.g[1]); PARK_SET(PK_LV2, p2.g[2]);
+          PARK_SET(PK_Q0, T2 * PARK_GET(PK_Q3)); PARK_SET(PK_Q1, T2 * PARK_GET(PK_DJJ)); PARK_SET(PK_Q2, T2 * dir2);
+        }
+#pragma unroll 1
+        for (int k = 0; k < 2; k++) {
+          asm volatile("" ::: "memory");  // re-read the park inside every trip
+          const double to_p = (k == 0) ? to + dx : to;
+          const double tf_p = (k == 1) ? tf + dx : tf;
+          const double tnp = tau2 * (tf_p - to_p) / 2 + (tf_p + to_p) / 2;
+          const EarthAngle eq = earth_angle(tnp);
+          double wq[3], Fp[3], f[3];
+          const double rq[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
+          wind_eci_or_calm(rq, eq, PARK_GET(PK_FP0), PARK_GET(PK_FP1), PARK_GET(PK_FP2), PARK_GET(PK_FP3), PARK_GET(PK_FP4), wq);
+          const double vq[3] = {PARK_GET(PK_V0) * P.uv, PARK_GET(PK_V1) * P.uv, PARK_GET(PK_V2) * P.uv};
+          aero_force(rq, vq, PARK_GET(PK_FP5), PARK_GET(PK_FP6), eq, wq, ph.area, tb, Fp, GEL_CA_BRACKET);
+          const double Tq[3] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2)};
+          const double gq[3] = {PARK_GET(PK_LV0), PARK_GET(PK_LV1), PARK_GET(PK_LV2)};
+          accel(Tq, Fp, inv_m, gq, inv_uv, f);
+          // -(f_p*(tf_p - to_p) - f_c*(tf - to))/dx*unit_t/2   (con_dynamics.py:463-477)
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            EMIT(ph.s_vt + 3 * k + c, (fcc[c] * (tf - to) - f[c] * (tf_p - to_p)) * fdt);
         }
       }
+#endif
     } else {
       // NoAir (reference_area == 0): thrust + gravity only (src/pybind_dynamics.cpp:73-92)
       const double T = ph.thrust;
@@ -920,6 +1008,15 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         gravity_eci(r, P.barC20, gc);
       }
       accel_noair(Td, inv_m, gc, inv_uv, fc);
+      if (rb) {  // velocity defect (:216-289)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const double rh = fc[c] * (tf - to) * ut / 2.0;
+          const double cv = PARK_GET(PK_LV0 + c) - rh;
+          RSTORE(4 * N + 3 * g + c, cv);
+          GEL_CHK(cv);
+        }
+      }
       if (JAC) {
         double f[3];
         accel_noair(Td, frcp((me + dx) * P.um), gc, inv_uv, f);
@@ -953,25 +1050,17 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
       }
     }
   }
-  if (rb) {  // velocity defect (:216-289)
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const double rh = fc[c] * (tf - to) * ut / 2.0;
-      const double cv = PARK_GET(PK_LV0 + c) - rh;
-      RSTORE(4 * N + 3 * g + c, cv);
-      chk += cv;
-    }
-  }
-
 #undef EMIT
 #undef GEL_CA_BRACKET
 #undef GEL_WIND_BRACKET
 #undef EMIT_AT
 #undef RSTORE
 #undef FDQ
+#undef GEL_CHK
+#undef GEL_UNI
 #undef PARK_GET
 #undef PARK_SET
-  if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
+  if (bad) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 
 }  // namespace gel

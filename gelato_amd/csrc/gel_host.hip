@@ -112,7 +112,7 @@ int lgr_diffmat_ld(int n, std::vector<double>& D, std::vector<double>& tau_out) 
 // ---------------------------------------------------------------------------
 struct HostPhase {
   int n, ua, xa;
-  int air, air_fd, engine_on, hold;
+  int air, air_fd, t_fd, engine_on, hold;
   int K, s_vv, s_vq, s_vt, s_qq;
   int64_t voff;
   double thrust, massflow, area, nozzle;
@@ -123,6 +123,7 @@ struct HostPhase {
 
 struct gel_problem {
   int device = 0;
+  bool fd_recompute = false;   // GEL_FLAG_FD_RECOMPUTE (or a step too long for the difference form): the reference's recomputing sweeps
   hipStream_t stream = nullptr;
   gel::ProblemDev dev{};
   std::vector<HostPhase> ph;
@@ -264,7 +265,7 @@ void walk_pattern(const gel_problem& P, const Visitor& vis) {
     // (reference_area > 0), else the tf column is the exact negative of the t0 column (:478-480)
     for (int jj = 0; jj < 3 * n; jj++) vis(9, k[9]++, 3 * ua + jj, i, 1, 0, cs(h, h.s_vt + jj % 3, jj / 3));
     for (int jj = 0; jj < 3 * n; jj++)
-      vis(9, k[9]++, 3 * ua + jj, i + 1, h.air_fd ? 1 : 2, 0, cs(h, h.s_vt + (h.air_fd ? 3 : 0) + jj % 3, jj / 3));
+      vis(9, k[9]++, 3 * ua + jj, i + 1, h.t_fd ? 1 : 2, 0, cs(h, h.s_vt + (h.t_fd ? 3 : 0) + jj % 3, jj / 3));
     // ---- group 3: quaternion ----
     if (h.hold) {
       for (int jj = 0; jj < 4 * n; jj++) vis(10, k[10]++, 4 * ua + jj, 4 * xa + jj % 4, 0, -1.0, -1);
@@ -593,6 +594,10 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   p->device = d->device;
   p->um = d->unit_mass; p->up = d->unit_position; p->uv = d->unit_velocity; p->uu = d->unit_u; p->ut = d->unit_t;
   p->dx = d->dx;
+  // Position sweeps in exact-difference form and the t0 / tf columns in closed form (gel_rhs_parts.h pos_delta, gel_eval_kernel.h),
+  // unless the caller asks for the reference's recomputing sweeps or the step dx * unit_position is beyond the 1 m the
+  // truncated series of the difference form are sized for (the reference's own dx = 1e-8 gives 0.064 m).
+  p->fd_recompute = ((d->flags & GEL_FLAG_FD_RECOMPUTE) != 0) || !(std::fabs(d->dx * d->unit_position) <= 1.0);
   p->barC20 = (d->barC20 == 0.0) ? -0.484165371736e-3 : d->barC20;
   const int S = d->num_sections;
   int N = 0;
@@ -604,8 +609,9 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     h.n = d->num_nodes[i]; h.ua = N; h.xa = N + i; N += h.n;
     h.thrust = d->thrust[i]; h.massflow = d->massflow[i]; h.area = d->reference_area[i]; h.nozzle = d->nozzle_area[i];
     h.air = (h.area != 0.0); h.air_fd = (h.area > 0.0);
+    h.t_fd = h.air_fd && p->fd_recompute;
     h.engine_on = d->engine_on[i] != 0; h.hold = d->attitude_hold[i] != 0;
-    h.s_vv = 15; h.s_vq = h.air_fd ? 24 : 15; h.s_vt = h.s_vq + 12; h.s_qq = h.s_vt + (h.air_fd ? 6 : 3);
+    h.s_vv = 15; h.s_vq = h.air_fd ? 24 : 15; h.s_vt = h.s_vq + 12; h.s_qq = h.s_vt + (h.t_fd ? 6 : 3);
     h.K = h.s_qq + (h.hold ? 0 : 20);
     h.voff = V; V += (int64_t)h.K * h.n + 1;  // node slots + the phase's pos/velocity diagonal scalar
     const size_t nd = (size_t)h.n * (h.n + 1);
@@ -704,7 +710,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   for (int i = 0; i < S; i++) {
     const HostPhase& h = p->ph[i];
     gel::PhaseDev& q = dph[i];
-    q.n = h.n; q.ua = h.ua; q.xa = h.xa; q.air = h.air; q.air_fd = h.air_fd; q.engine_on = h.engine_on; q.hold = h.hold;
+    q.n = h.n; q.ua = h.ua; q.xa = h.xa; q.air = h.air; q.air_fd = h.air_fd; q.t_fd = h.t_fd; q.engine_on = h.engine_on; q.hold = h.hold;
     q.K = h.K; q.s_vv = h.s_vv; q.s_vq = h.s_vq; q.s_vt = h.s_vt; q.s_qq = h.s_qq;
     q.doff = (int32_t)Dt.size(); q.toff = (int32_t)tau.size(); q.voff = h.voff;
     q.thrust = h.thrust; q.massflow = h.massflow; q.area = h.area; q.nozzle = h.nozzle;
@@ -815,6 +821,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     dv.use_mfma = (d->flags & GEL_FLAG_DX_VALU) ? 0 : 1;
     dv.pack = (nmax <= 32) && !(d->flags & GEL_FLAG_NO_PACK);
   }
+  dv.fd_recompute = p->fd_recompute ? 1 : 0;
   dv.um = p->um; dv.up = p->up; dv.uv = p->uv; dv.uu = p->uu; dv.ut = p->ut; dv.dx = p->dx; dv.barC20 = p->barC20;
   *out = p;
   return GEL_OK;

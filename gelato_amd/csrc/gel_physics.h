@@ -84,6 +84,25 @@ GEL_DEV double fdiv(double a, double b) { return a / b; }
 #endif
 GEL_DEV double frcp(double b) { return fdiv(1.0, b); }
 
+// A wave-uniform double moved into an SGPR pair (two v_readfirstlane_b32): frees the VGPR pair it would occupy for the rest
+// of the kernel; vector instructions read it as their scalar operand.
+GEL_DEV double wave_uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// x * s (s wave-uniform) as a product the compiler can neither merge with an earlier identical one nor hoist: the cheap way
+// to NOT carry a scaled copy of a value in registers across the kernel -- recompute it where it is used.  Same bits as x * s.
+GEL_DEV double fresh_product(double x, double s) {
+  double r;
+  asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(s));
+  return r;
+}
+GEL_DEV double fresh_mul(double a, double b) {   // likewise, both factors per-lane
+  double r;
+  asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // sqrt and 1/sqrt of the same argument from ONE Goldschmidt iteration: s is bit-identical to fsqrt(x); r comes
 // from one more step on the companion value (<= 1 ulp from 1/sqrt(x)).  13 operations instead of the 18 of
 // fsqrt + frcp, and one quarter-rate instruction (v_rsq_f64) instead of two (v_rsq_f64, v_rcp_f64).  Used where
@@ -266,7 +285,10 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
 // (a/h, b/h with h = hypot(a, b)), identical up to rounding to sincos(atan2(a, b)).
 // inv_p = 1/p (<= 1 ulp; it only scales the longitude pair of wind_eci()); exactly on the polar axis p = 0 and
 // inv_p = 0, which wind_eci() reads as longitude 0 = the reference's atan2(0, 0)
-GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p, double& inv_p) {
+// Optional exports for the exact-difference position sweeps (pos_delta()): 1/hypot(z Ra, p Rb) and 1/hypot(zz, pp) of the
+// latitude's atan2 arguments.
+GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p, double& inv_p, double* ih_out = nullptr,
+                            double* ihy_out = nullptr) {
   const double p2 = x * x + y * y;
   fsqrt_rsqrt(fmax(p2, 1.0e-300), p, inv_p);
   if (!(p2 > 0.0)) { p = 0.0; inv_p = 0.0; }
@@ -277,7 +299,10 @@ GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p
   const double ih = frsqrt(fmax(h2, 1.0e-300));
   const double st = (h2 > 0.0) ? a * ih : 0.0;
   const double ct = (h2 > 0.0) ? b * ih : 1.0;
-  lat = atan2(z + kEp2 * kRb * (st * st * st), p - kE2 * kRa * (ct * ct * ct));
+  const double zz = z + kEp2 * kRb * (st * st * st), pp = p - kE2 * kRa * (ct * ct * ct);
+  lat = atan2(zz, pp);
+  if (ih_out) *ih_out = ih;
+  if (ihy_out) *ihy_out = frsqrt(fmax(zz * zz + pp * pp, 1.0e-300));
 }
 
 // altitude from (p, sin lat, cos lat): src/Earth.cpp:58-59
@@ -380,16 +405,21 @@ GEL_DEV double interp_tab(double x, const double* tab, const double* slope, int 
 
 // The interval of the last lookup, kept by the caller across the sweeps of one node: a perturbed evaluation moves the
 // abscissa by 1e-8 of itself, so it falls into the same interval (xl < x <= xu) almost surely; then the count over the
-// table, the clamps and four LDS reads are skipped.  The same interval means the same operands in the same expression:
-// bit-identical to the full lookup.  A wavefront takes the short way only if all of its lanes can.
-struct Bracket { double xl, xu, yl, sl; };
-GEL_DEV Bracket no_bracket() { return Bracket{1.79769313486231570815e308, -1.79769313486231570815e308, 0.0, 0.0}; }
+// table and the clamps are skipped.  The same interval means the same operands in the same expression: bit-identical to the
+// full lookup.  A wavefront takes the short way only if all of its lanes can.  Only the interval's INDEX is kept (one
+// register): its four numbers are read from the LDS table again -- they used to occupy eight registers for the whole kernel.
+struct Bracket { int idx; };
+GEL_DEV Bracket no_bracket() { return Bracket{-1}; }
 GEL_DEV double interp_tab_cached(double x, const double* tab, const double* slope, int n, int stride, int ycol, Bracket& br) {
-  const bool hit = (br.xl < x) && (x <= br.xu);
-  if (__builtin_amdgcn_ballot_w64(!hit) == 0) return br.yl + (x - br.xl) * br.sl;   // wave-uniform branch
+  {
+    const int i = max(br.idx, 0);
+    const double xl = tab[i * stride], xu = tab[(i + 1) * stride];
+    const bool hit = (br.idx >= 0) && (xl < x) && (x <= xu);
+    if (__builtin_amdgcn_ballot_w64(!hit) == 0) return tab[i * stride + ycol] + (x - xl) * slope[i];   // wave-uniform branch
+  }
   const int idx = min(max(lower_count(x, tab, n, stride) - 1, 0), n - 2);
-  br.xl = tab[idx * stride]; br.xu = tab[(idx + 1) * stride]; br.yl = tab[idx * stride + ycol]; br.sl = slope[idx];
-  const double v = br.yl + (x - br.xl) * br.sl;
+  br.idx = idx;
+  const double v = tab[idx * stride + ycol] + (x - tab[idx * stride]) * slope[idx];
   return (x <= tab[0]) ? tab[ycol] : ((x > tab[(n - 1) * stride]) ? tab[(n - 1) * stride + ycol] : v);
 }
 
@@ -425,6 +455,88 @@ GEL_DEV void wind_ned2_cached(double h, const double* tab, const double* slope, 
   const bool below = h <= tab[0], above = h > tab[(n - 1) * 3];
   wn = below ? tab[1] : (above ? tab[(n - 1) * 3 + 1] : vn);
   we = below ? tab[2] : (above ? tab[(n - 1) * 3 + 2] : ve);
+}
+
+// wind_ned2 for the centre evaluation of a node whose position sweeps take the exact-difference form: the same value
+// expressions (bit-identical to wind_ned2), plus the index of the node's piece of the table: >= 0 inside the table,
+// -1 below its first row, -2 above its last (the two clamped ends, where the wind does not change with altitude).
+GEL_DEV void wind_ned2_centre(double h, const double* tab, const double* slope, int n, double& wn, double& we, int& piece) {
+  const int idx = min(max(lower_count(h, tab, n, 3) - 1, 0), n - 2);
+  const double dxl = h - tab[idx * 3];
+  const double vn = tab[idx * 3 + 1] + dxl * slope[2 * idx];
+  const double ve = tab[idx * 3 + 2] + dxl * slope[2 * idx + 1];
+  const bool below = h <= tab[0], above = h > tab[(n - 1) * 3];
+  wn = below ? tab[1] : (above ? tab[(n - 1) * 3 + 1] : vn);
+  we = below ? tab[2] : (above ? tab[(n - 1) * 3 + 2] : ve);
+  piece = below ? -1 : (above ? -2 : idx);
+}
+// What a position sweep in exact-difference form reads back from (h, piece): the wind at h (the same expressions: bit-identical
+// to the centre's), the slopes of its piece (zero in the clamped ends) and how far h may move without leaving the piece.
+// Branch-free: every operand is read, then selected.
+GEL_DEV void wind_piece(double h, int piece, const double* tab, const double* slope, int n, double& wn, double& we, double& s0,
+                        double& s1, double& margin) {
+  const int idx = max(piece, 0);
+  const double xl = tab[idx * 3], xu = tab[idx * 3 + 3];
+  const double sl0 = slope[2 * idx], sl1 = slope[2 * idx + 1];
+  const double dxl = h - xl;
+  const double vn = tab[idx * 3 + 1] + dxl * sl0;
+  const double ve = tab[idx * 3 + 2] + dxl * sl1;
+  const double x0 = tab[0], xe = tab[(n - 1) * 3];
+  const bool below = piece == -1, above = piece == -2, in = piece >= 0;
+  wn = below ? tab[1] : (above ? tab[(n - 1) * 3 + 1] : vn);
+  we = below ? tab[2] : (above ? tab[(n - 1) * 3 + 2] : ve);
+  s0 = in ? sl0 : 0.0;
+  s1 = in ? sl1 : 0.0;
+  margin = below ? x0 - h : (above ? h - xe : fmin(dxl, xu - h));
+}
+
+// ---------------------------------------------------------------------------
+// Exact-difference atmosphere: the state at h + dh from the state at h, for a dh that stays inside the layer (the caller
+// checks that).  Every change is an algebraic identity of the reference's formula (src/Air.cpp:71-111), not a recomputation:
+//   T linear in h                         dT = Lmb dh
+//   T = Tc + A sqrt(1 - y^2) (91..110 km) ds = s (sqrt(1 + us) - 1), us = -d(y^2)/s^2
+//   T = Tinf - (Tinf - Tmb) exp(-l xi)    dT = (T - Tinf) expm1(-l dxi)
+//   P = Pb (Tl/Tmb)^y                     P'/P = exp(y log1p(dTl/Tl));   P = Pb exp(gR (Hb - h)/Tmb): P'/P = exp(-gR dh/Tmb)
+//   rho = P/(R T)                         rho'/rho = (1 + uP)/(1 + uT);   1/a = (1.4 R T)^-1/2: (1 + uT)^-1/2
+// with the series of log1p / expm1 / (1 + u)^-1/2 cut where the next term is below 1e-13 of the change for |dh| <= 1 m
+// (gel_host.hip selects the recomputing form for larger steps).  The result differs from the reference's recomputation
+// by the rounding noise of THAT (1e-16 of the value = 1e-8 .. 1e-4 of the change); tests/test_delta_model.py has the model.
+// ---------------------------------------------------------------------------
+struct AirCentre { double iT, h; int k; };   // what the difference form needs besides Air: 1/T, geopotential altitude, layer
+// geopotential altitude of 86 km geometric, the end of the geopotential branch (src/Air.cpp:47-54), rounded DOWN: a node of layer 6
+// (71 .. 86 km geopotential) below it has altitude < 86 km
+constexpr double kGeopot86 = 84852.0;
+GEL_DEV void atmosphere_delta(const Air& c, const AirCentre& ac, double dh, const double* atm, double& P1, double& rho1, double& inv_a1) {
+  const int k = ac.k;
+  const double r0 = 6356766.0;
+  const double Lmb = atm[k];
+  const double dTl = Lmb * dh;
+  double dT = dTl, iTl = ac.iT;   // h <= 91 km and 110 .. 120 km: T is the layer's linear profile
+  if (k == 8) {                   // 91 .. 110 km: elliptic profile (src/Air.cpp:75-78); the pressure keeps the linear one
+    const double ia = 1.0 / -19942.9;
+    const double yv = (ac.h - 91000.0) * ia, dyv = dh * ia;
+    const double dy2 = dyv * (2.0 * yv + dyv);
+    const double s = (frcp(ac.iT) - 263.1905) * (1.0 / -76.3232);
+    const double us = -dy2 * frcp(s * s);
+    dT = (-76.3232 * s) * (us * (0.5 + us * (-0.125 + 0.0625 * us)));
+    iTl = frcp(atm[11 + k] + Lmb * (ac.h - atm[66 + k]));
+  } else if (k == 10) {           // above 120 km: exponential profile (:83-87)
+    const double Hb = atm[66 + k];
+    const double irh = frcp(r0 + ac.h);
+    const double dxi = ((r0 + Hb) * (r0 + Hb)) * dh * irh * irh * (1.0 - dh * irh);
+    const double zc = -0.01875e-3 * dxi;
+    dT = (frcp(ac.iT) - 1000.0) * (zc * (1.0 + zc * (0.5 + zc * (1.0 / 6.0))));
+    iTl = frcp(atm[11 + k] + Lmb * (ac.h - Hb));
+  }
+  const double uT = dT * ac.iT;
+  const double ul = dTl * iTl;
+  const double e_lapse = atm[44 + k] * (ul * (1.0 + ul * (-0.5 + ul * (1.0 / 3.0))));
+  const double e_iso = -(atm[55 + k] * atm[77 + k]) * dh;
+  const double ee = (fabs(Lmb) > 1.0e-6) ? e_lapse : e_iso;
+  const double uP = ee * (1.0 + ee * (0.5 + ee * (1.0 / 6.0)));
+  P1 = __builtin_fma(c.P, uP, c.P);
+  rho1 = __builtin_fma(c.rho, (uP - uT) * (1.0 + uT * (uT - 1.0)), c.rho);
+  inv_a1 = __builtin_fma(c.inv_a, uT * (-0.5 + uT * (0.375 - 0.3125 * uT)), c.inv_a);
 }
 
 }  // namespace gel

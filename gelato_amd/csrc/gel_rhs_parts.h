@@ -46,20 +46,49 @@ GEL_DEV void geodetic_sincos(double x, double y, double z, double& sl, double& c
   cl = pp * ihy;
 }
 
-GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20, Bracket2* wbr = nullptr) {
+// What the exact-difference position sweeps (pos_delta) need of the centre evaluation besides PosPart.
+struct PosCentre {
+  double p, ih, ihy;     // sqrt(x^2 + y^2); 1/hypot(z Ra, p Rb) (Bowring's auxiliary angle); 1/hypot of the latitude's atan2 arguments
+  double sl, cl, icl;    // sin, cos of the geodetic latitude; 1/cos
+  double N;              // prime-vertical radius Ra / sqrt(1 - e^2 sin^2 lat)
+  double G;              // d(geopotential altitude)/d(altitude) = (r0/(r0 + alt))^2 is G^2; 1 above 86 km
+  double s0, s1;         // slopes of the wind components on the node's piece of the table (0 in the clamped ends)
+  double margin;         // how far altitude / geopotential altitude may move without leaving the atmosphere layer, the wind
+                         // table's piece or the geopotential branch
+  AirCentre air;         // 1/temperature, geopotential altitude, layer
+};
+// Where pos_part() leaves the PosCentre members: the first eight go to the sink AS SOON AS they exist (the fused kernel parks
+// them in LDS, so that they do not occupy registers across the atmosphere chain), the rest come back in the struct.
+enum PosCentreSlot { PCS_P = 0, PCS_IH, PCS_IHY, PCS_SL, PCS_CL, PCS_ICL, PCS_N, PCS_G, PCS_COUNT };
+// ... the rest is re-derived by pos_centre_tail() from three small items, where a sweep needs it
+struct PosCentreTail { double h; int k, piece; };   // geopotential altitude, atmosphere layer, piece of the wind table
+struct NoSink { GEL_DEV void put(int, double) const {} };
+struct PosCentreSink {   // collects into a PosCentre (hooks, aero kernel)
+  PosCentre* pc;
+  GEL_DEV void put(int i, double v) const {
+    if (i == PCS_P) pc->p = v; else if (i == PCS_IH) pc->ih = v; else if (i == PCS_IHY) pc->ihy = v; else if (i == PCS_SL) pc->sl = v;
+    else if (i == PCS_CL) pc->cl = v; else if (i == PCS_ICL) pc->icl = v; else if (i == PCS_N) pc->N = v; else pc->G = v;
+  }
+};
+
+template <bool CENTRE = false, class Sink = NoSink>
+GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20, Bracket2* wbr = nullptr, Sink sink = Sink(),
+                         PosCentreTail* tail = nullptr) {
   PosPart o;
   // the reference feeds the ECI position to ecef2geodetic for altitude (src/pybind_dynamics.cpp:43)
-  // The altitude p/cos(lat) - N cancels 6.4e6 m down to the altitude and the position sweeps difference
-  // exactly that round-off, so sin/cos(lat) are taken the reference's way (atan2, then sincos): measured,
-  // the algebraic pair of geodetic_sincos() is equally accurate but decorrelates the FD noise from the
-  // reference's (3e-4 on vel/position entries of a polar, high-dynamic-pressure test state).
+  // The altitude p/cos(lat) - N cancels 6.4e6 m down to the altitude; sin/cos(lat) are taken the reference's way (atan2,
+  // then sincos), so that the centre value rounds like the reference's.
   double p, sl, cl;
-#ifdef GEL_AB_LATALG  // A/B switch for tools/variant.sh only: the algebraic pair (see the comment above)
+#ifdef GEL_AB_LATALG  // A/B switch for tools/variant.sh only: the algebraic pair
   geodetic_sincos(r[0], r[1], r[2], sl, cl, p);
   o.inv_p = frcp(p);
 #else
   double lat;
-  geodetic_lat_p(r[0], r[1], r[2], lat, p, o.inv_p);
+  if (CENTRE) {
+    double ih, ihy;
+    geodetic_lat_p(r[0], r[1], r[2], lat, p, o.inv_p, &ih, &ihy);
+    sink.put(PCS_IH, ih); sink.put(PCS_IHY, ihy); sink.put(PCS_P, p);
+  } else geodetic_lat_p(r[0], r[1], r[2], lat, p, o.inv_p);
   fsincos(lat, &sl, &cl);
 #endif
   // half-angle pair of the NED quaternion (src/Coordinate.cpp:89-90): cos(lat/2) = sqrt((1+cos lat)/2)
@@ -69,15 +98,104 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20, Bra
     fsqrt_rsqrt(0.5 * (1.0 + cl), o.chp, irt);
     o.shp = (0.5 * sl) * irt;
   }
-  const double alt = geodetic_alt_from(p, sl, cl);
+  // src/Earth.cpp:58-59 (geodetic_alt_from(), spelled out for the exports)
+  const double N = fdiv(kRa, fsqrt(1.0 - kE2 * sl * sl));
+  const double q = fdiv(p, cl);
+  const double alt = q - N;
+  if (CENTRE) {
+    sink.put(PCS_SL, sl); sink.put(PCS_CL, cl); sink.put(PCS_N, N);
+    sink.put(PCS_ICL, q * o.inv_p);                                          // 1/cos(lat) = (p/cos lat)/p
+    sink.put(PCS_G, (alt < 86000.0) ? fdiv(6356766.0, 6356766.0 + alt) : 1.0);
+  }
   const double h = geopotential_altitude(alt);
   const Air air = atmosphere(h, tb.atm);
   o.rho = air.rho; o.P = air.P; o.inv_a = air.inv_a;
   // wind looked up at geopotential altitude (:44,49); wbr: the caller's altitude interval of this node's previous evaluations
-  if (wbr) wind_ned2_cached(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we, *wbr);
+  if (CENTRE) {
+    wind_ned2_centre(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we, tail->piece);
+    tail->h = h; tail->k = us76_layer(h);
+  } else if (wbr) wind_ned2_cached(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we, *wbr);
   else wind_ned2(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we);
   gravity_eci(r, barC20, o.g);
   return o;
+}
+
+// The members of PosCentre that are not parked, re-derived for a sweep from (h, layer, wind piece) and the centre's
+// density and pressure: the wind slopes and the margin (how far the altitude may move inside the atmosphere layer -- for
+// layer 6 also inside the geopotential branch, which ends at 84852 m -- and inside the piece of the wind table), and 1/T = rho R / P.
+// Also returns the centre's wind (bit-identical to pos_part's), so that it need not live in registers either.
+GEL_DEV void pos_centre_tail(const PosCentreTail& t, double rho, double P, const Tables& tb, PosCentre& pc, double& wn, double& we) {
+  double wm;
+  wind_piece(t.h, t.piece, tb.wind, tb.winds, tb.Kw, wn, we, pc.s0, pc.s1, wm);
+  const double lo = tb.atm[66 + t.k];
+  const double hi = (t.k == 6) ? kGeopot86 : ((t.k < 10) ? tb.atm[67 + min(t.k, 9)] : 1.0e300);
+  pc.margin = fmin(wm, fmin(t.h - lo, hi - t.h));
+  pc.air.iT = rho * tb.atm[33 + t.k] * frcp(P);
+  pc.air.h = t.h; pc.air.k = t.k;
+}
+
+// ---------------------------------------------------------------------------
+// Exact-difference form of pos_part() for a position sweep: component kk of r moved by dlt = r'_kk - r_kk (an exact
+// floating-point difference).  The reference re-runs the whole chain on r' (lib/con_dynamics.py:381-400) and differences
+// two values of 6.4e6 m magnitude; here the CHANGE of every intermediate is formed directly from an algebraic identity
+// of the reference's own formula (src/Earth.cpp:49-61, src/Air.cpp:47-111, src/wrapper_utils.hpp:82-87):
+//   p = sqrt(x^2 + y^2)          d(p^2) = dlt (2 x_k + dlt),  dp = p (sqrt(1 + u) - 1),  u = d(p^2)/p^2
+//   sin/cos(theta) = a/h, b/h    dh2 = da (2a + da) + db (2b + db),  d(1/h) = (1/h)((1 + uh)^-1/2 - 1)
+//   lat = atan2(zz, pp)          dlat = atan((dzz pp - zz dpp)/(zz zz' + pp pp'))   (tan of a difference)
+//   sin, cos, half-angle pair    angle-addition with sin(dlat) = dlat, 1 - cos(dlat) = dlat^2/2
+//   alt = p/cos(lat) - N         d(p/cl) = (dp cl - p dcl)/(cl cl'),  dN = N ((1 + uw)^-1/2 - 1)
+//   h = r0 alt/(r0 + alt)        dh = r0^2 dalt/((r0 + alt)(r0 + alt'))
+//   atmosphere, wind             atmosphere_delta(); linear piece of the table
+// with every series cut where the next term is below 1e-13 of the change for |dlt| <= 1 m.  ~130 fp64 operations instead
+// of ~450, and the change is accurate to ~1e-12 of itself, where the recomputation's is accurate to 1e-16 of the VALUE
+// (1e-8 .. 1e-4 of the change: the reference's own finite-difference noise).  Gravity is recomputed by the caller.
+// Returns false for a lane whose perturbed point leaves the centre's atmosphere layer / table piece / geopotential branch
+// or sits too close to the polar axis for the series: the caller then recomputes the wavefront's sweep in full.
+// ---------------------------------------------------------------------------
+GEL_DEV bool pos_delta(const double r[3], int kk, double dlt, const PosPart& c, const PosCentre& pc, const Tables& tb, PosPart& o) {
+  const double dz = (kk == 2) ? dlt : 0.0;
+  const double xs = (kk == 0) ? r[0] : r[1];
+  const double dp2 = (kk == 2) ? 0.0 : dlt * __builtin_fma(2.0, xs, dlt);
+  const double u = dp2 * c.inv_p * c.inv_p;
+  const double dp = (0.5 * dp2 * c.inv_p) * (1.0 + u * (-0.25 + 0.125 * u));
+  o.inv_p = c.inv_p * (1.0 + u * (-0.5 + 0.375 * u));
+  // Bowring's auxiliary angle (src/Earth.cpp:53-55)
+  const double a = r[2] * kRa, b = pc.p * kRb;
+  const double da = dz * kRa, db = dp * kRb;
+  const double dh2 = da * __builtin_fma(2.0, a, da) + db * __builtin_fma(2.0, b, db);
+  const double uh = dh2 * pc.ih * pc.ih;
+  const double dih = pc.ih * (uh * (-0.5 + 0.375 * uh));
+  const double ih1 = pc.ih + dih;
+  const double st = a * pc.ih, ct = b * pc.ih;
+  const double dst = da * ih1 + a * dih, dct = db * ih1 + b * dih;
+  const double dst3 = dst * (3.0 * st * (st + dst) + dst * dst);
+  const double dct3 = dct * (3.0 * ct * (ct + dct) + dct * dct);
+  const double dzz = dz + (kEp2 * kRb) * dst3, dpp = dp - (kE2 * kRa) * dct3;
+  // latitude: tan(lat' - lat) = (dzz pp - zz dpp)/(zz zz' + pp pp'), with (zz, pp)/hypot = (sin, cos) lat
+  const double e = (pc.cl * dpp + pc.sl * dzz) * pc.ihy;
+  const double dlat = ((dzz * pc.cl - dpp * pc.sl) * pc.ihy) * (1.0 + e * (e - 1.0));
+  const double hl2 = 0.5 * dlat * dlat;
+  const double dsl = pc.cl * dlat - pc.sl * hl2, dcl = -(pc.sl * dlat + pc.cl * hl2);
+  // half-angle pair of the NED quaternion
+  const double hd = 0.5 * dlat, hd2 = 0.5 * hd * hd;
+  o.shp = c.shp + (c.chp * hd - c.shp * hd2);
+  o.chp = c.chp - (c.shp * hd + c.chp * hd2);
+  // altitude (src/Earth.cpp:58-59)
+  const double v = dcl * pc.icl;
+  const double dq = ((dp - (pc.p * pc.icl) * dcl) * pc.icl) * (1.0 + v * (v - 1.0));
+  const double nr = pc.N * (1.0 / kRa);
+  const double uw = (-kE2 * dsl * __builtin_fma(2.0, pc.sl, dsl)) * (nr * nr);   // 1/(1 - e^2 sin^2 lat) = (N/Ra)^2
+  const double dN = pc.N * (uw * (-0.5 + 0.375 * uw));
+  const double dalt = dq - dN;
+  // geopotential altitude (src/Air.cpp:47-54)
+  const double g1 = (pc.air.k <= 6) ? pc.G * (1.0 / 6356766.0) : 0.0;           // 1/(r0 + alt) below 86 km (h < 84852 m: layers 0..6)
+  const double dh = (pc.G * pc.G) * dalt * (1.0 - dalt * g1);
+  Air ca_;
+  ca_.P = c.P; ca_.rho = c.rho; ca_.inv_a = c.inv_a; ca_.T = 0.0; ca_.a = 0.0;
+  atmosphere_delta(ca_, pc.air, dh, tb.atm, o.P, o.rho, o.inv_a);
+  o.wn = __builtin_fma(pc.s0, dh, c.wn);
+  o.we = __builtin_fma(pc.s1, dh, c.we);
+  return (c.inv_p > 0.0) && (fabs(u) < 1.0e-4) && (fabs(v) < 1.0e-4) && (fmax(fabs(dalt), fabs(dh)) < pc.margin);
 }
 
 // depends on time only: src/Coordinate.cpp:41-59 (cos/sin(omega t)), :75-79 (half angle)
@@ -85,6 +203,16 @@ struct EarthAngle { double c, s, ch, sh; };
 
 // One sincos of the half angle; the full angle by the double-angle identities (<= 2 ulp from a second
 // sincos, and the same pair serves the centre and every sweep that does not move t).
+// The half-angle pair alone (what the fused kernel keeps across its sweeps) and the full set formed from it where it is
+// used: the same two products as in earth_angle(), as products the compiler cannot merge and carry (fresh_mul).
+struct EarthHalf { double ch, sh; };
+GEL_DEV EarthAngle full_angle(const EarthHalf& h) {
+  EarthAngle e;
+  e.ch = h.ch; e.sh = h.sh;
+  e.s = fresh_mul(2.0 * h.sh, h.ch);
+  e.c = fresh_mul(h.ch - h.sh, h.ch + h.sh);
+  return e;
+}
 GEL_DEV EarthAngle earth_angle(double t) {
   EarthAngle e;
   fsincos(kOmega * t / 2.0, &e.sh, &e.ch);

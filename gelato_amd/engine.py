@@ -82,7 +82,7 @@ class Engine:
         else:
             d.D, d.tau = None, None
         d.device = device
-        d.flags = int(flags)  # 0, or GEL_FLAG_DX_MFMA (1) / GEL_FLAG_DX_VALU (2) to force the D.X path, GEL_FLAG_NO_PACK (4)
+        d.flags = int(flags)  # 0, or GEL_FLAG_DX_MFMA (1) / GEL_FLAG_DX_VALU (2) to force the D.X path, GEL_FLAG_NO_PACK (4), GEL_FLAG_FD_RECOMPUTE (8)
         h = C.c_void_p()
         check(L.gel_problem_create(C.byref(d), C.byref(h)))
         self._h = h

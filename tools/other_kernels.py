@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Every device kernel besides the fused eval_kernel, launched back to back with device-resident buffers so that
+`rocprofv3 --kernel-trace --stats` / `--pmc FETCH_SIZE|WRITE_SIZE` passes can record them (tools/record_others.sh):
+
+  aero_kernel              the three aero path-constraint kinds, values + FD gradients, B = 1024 and B = 16384
+  expand_kernel            compact -> full COO values, B = 1024
+  perturb_local_kernel /
+  quotient_local_kernel    the generic column-batched jac_fd (velocity group), host call
+  rows_kernel              knot / terminal / user rows, B = 4096, device buffers
+
+Prints one JSON object: HIP-event time per launch, the algorithmic bytes per launch (A_min: inputs read once + outputs
+written once) and the fraction of the 8 TB/s HBM roofline.  GPU box only."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from gelato_amd import Engine, con_dynamics, pack_x, problem  # noqa: E402
+
+HBM = 8.0e12
+
+
+def ev(f, n):
+    for _ in range(3):
+        f()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        f()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "mixed-6x64"
+    reps = int(os.environ.get("OK_REPS", "20"))
+    pdict, unitdict, condition, xdict = problem.make_problem(wl)
+    prob = con_dynamics.problem_arrays(pdict, unitdict)
+    E = Engine(prob)
+    x0 = pack_x(xdict)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    S = len(prob["num_nodes"])
+    out = {"workload": wl}
+
+    # ---- aero_kernel ----
+    for kind, lim in (("alpha", 0.2), ("q", 4.0e4), ("qalpha", 5.0e3)):
+        E.aero_configure(kind, [(i, 1, lim) for i in range(S - 1)])
+    dims = [E.aero_dims(k) for k in E.AERO_KINDS]
+    rows = sum(d[0] for d in dims)
+    grads = sum(sum(d[1]) for d in dims)
+    for B in (1024, 16384):
+        X = problem.synthetic_batch(x0, E.M, min(B, 1024))
+        X = np.tile(X, (B // len(X) + 1, 1))[:B]
+        dX = torch.from_numpy(X).to(dev)
+        dcon = [torch.empty((B, d[0]), dtype=torch.float64, device=dev) for d in dims]
+        djac = [torch.empty((B, sum(d[1])), dtype=torch.float64, device=dev) for d in dims]
+        cp, jp = [t.data_ptr() for t in dcon], [t.data_ptr() for t in djac]
+        ms = ev(lambda: E.eval_aero_all_device(B, dX.data_ptr(), cp, jp, s), reps)
+        amin = 8 * (E.nvars + rows + grads) * B
+        out["aero_kernel_B%d" % B] = {"ms": ms, "rows": rows, "gradient_values": grads, "A_min_bytes": amin,
+                                      "hbm_frac": amin / (ms * 1e-3) / HBM, "vectors_per_s": B / (ms * 1e-3)}
+        del dcon, djac
+    # ---- expand_kernel ----
+    B = 1024
+    djv = torch.randn((B, E.V), dtype=torch.float64, device=dev)
+    dfull = torch.empty((B, E.total_nnz), dtype=torch.float64, device=dev)
+    ms = ev(lambda: E.expand_full_device(B, djv.data_ptr(), dfull.data_ptr(), s), reps)
+    amin = 8 * (E.V + E.total_nnz) * B
+    out["expand_kernel_B%d" % B] = {"ms": ms, "A_min_bytes": amin, "hbm_frac": amin / (ms * 1e-3) / HBM}
+    del dfull, djv
+    # ---- rows_kernel: the shipped knot / terminal / user rows need the example's condition; synthetic table here ----
+    nlin, nfn = 256, 64
+    lin = [(i % E.nvars, 1.0, (i * 7 + 3) % E.nvars, -1.0, 0.0) for i in range(nlin)]
+    fn = [(k % 9, (k * 5) % E.M, 1.0, 0.0) for k in range(nfn)]
+    E.rows_configure(lin, fn)
+    B = 4096
+    X = problem.synthetic_batch(x0, E.M, 256)
+    X = np.tile(X, (B // len(X) + 1, 1))[:B]
+    dX = torch.from_numpy(X).to(dev)
+    dcon = torch.empty((B, nlin + nfn), dtype=torch.float64, device=dev)
+    djfn = torch.empty((B, nfn, 7), dtype=torch.float64, device=dev)
+    ms = ev(lambda: E.rows_eval_device(B, dX.data_ptr(), dcon.data_ptr(), djfn.data_ptr(), s), reps)
+    amin = 8 * (2 * nlin + 6 * nfn + nlin + nfn + 7 * nfn) * B       # the x entries the rows read + outputs
+    out["rows_kernel_B%d" % B] = {"ms": ms, "linear_rows": nlin, "node_function_rows": nfn, "A_min_bytes": amin,
+                                  "hbm_frac": amin / (ms * 1e-3) / HBM, "note": "launch-latency bound at callback sizes"}
+    # ---- perturb_local / quotient_local (jac_fd, velocity group; host arrays out) ----
+    E.jac_fd("vel", x0)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        J, _ = E.jac_fd("vel", x0)
+    dt = (time.perf_counter() - t0) / 3
+    out["jac_fd_vel"] = {"wall_ms": 1e3 * dt, "rows": int(J.shape[0]), "columns": int(J.shape[1]),
+                         "dense_bytes_to_host": int(J.nbytes)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
