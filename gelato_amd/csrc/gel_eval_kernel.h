@@ -910,21 +910,24 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
     accel(Td_, Fp_, inv_m, (pq).g, inv_uv, f_);                                                               \
     _Pragma("unroll") for (int c = 0; c < 3; c++) EMIT(kSlotVP + 3 * (kk) + c, FDQ(f_[c], PARK_GET(PK_Q0 + c))); \
   } while (0)
-        unsigned todo = 0;   // sweeps left to the recomputing loop (wave-uniform)
+        // PosCentre and the centre's position part as far as pos_delta() reads them, from the park
+#define GEL_LOAD_POS_CENTRE(pc, pcv)                                                                                   \
+  PosCentre pc;                                                                                                        \
+  pc.p = PARK_GET(PK_FP0 + PCS_P); pc.ih = PARK_GET(PK_FP0 + PCS_IH); pc.ihy = PARK_GET(PK_FP0 + PCS_IHY);             \
+  pc.sl = PARK_GET(PK_FP0 + PCS_SL); pc.cl = PARK_GET(PK_FP0 + PCS_CL); pc.icl = PARK_GET(PK_FP0 + PCS_ICL);           \
+  pc.N = PARK_GET(PK_FP0 + PCS_N); pc.G = PARK_GET(PK_FP0 + PCS_G);                                                    \
+  PosPart pcv;                                                                                                         \
+  pcv.rho = cen_rho; pcv.P = cen_P; pcv.inv_a = cen_inv_a;                                                             \
+  pcv.shp = PARK_GET(PK_LV0); pcv.chp = PARK_GET(PK_LV1); pcv.inv_p = PARK_GET(PK_LV2);                                \
+  pos_centre_tail(pt, cen_rho, cen_P, tb, pc, pcv.wn, pcv.we)
+        unsigned todo = 0;   // sweeps with a lane the difference form does not cover (wave-uniform)
         if (P.fd_recompute) {
           todo = ((1u << k1) - 1u) & ~((1u << k0) - 1u);
         } else {
 #pragma unroll 1
           for (int k = k0; k < k1; k++) {
             asm volatile("" ::: "memory");   // PosCentre is read from the park inside every trip
-            PosCentre pc;
-            pc.p = PARK_GET(PK_FP0 + PCS_P); pc.ih = PARK_GET(PK_FP0 + PCS_IH); pc.ihy = PARK_GET(PK_FP0 + PCS_IHY);
-            pc.sl = PARK_GET(PK_FP0 + PCS_SL); pc.cl = PARK_GET(PK_FP0 + PCS_CL); pc.icl = PARK_GET(PK_FP0 + PCS_ICL);
-            pc.N = PARK_GET(PK_FP0 + PCS_N); pc.G = PARK_GET(PK_FP0 + PCS_G);
-            PosPart pcv;   // the centre's position part as far as pos_delta() reads it
-            pcv.rho = cen_rho; pcv.P = cen_P; pcv.inv_a = cen_inv_a;
-            pcv.shp = PARK_GET(PK_LV0); pcv.chp = PARK_GET(PK_LV1); pcv.inv_p = PARK_GET(PK_LV2);
-            pos_centre_tail(pt, cen_rho, cen_P, tb, pc, pcv.wn, pcv.we);
+            GEL_LOAD_POS_CENTRE(pc, pcv);
             const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
             double rp[3];
 #pragma unroll
@@ -938,6 +941,8 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         }
 #ifndef GEL_EXP_NOFALLBACK
         if (todo) {
+          // the chain once more on the perturbed position, for the whole wavefront; a lane the difference form does cover
+          // still takes its values from there (each lane's entries do not depend on which other nodes share its wavefront)
 #pragma unroll 1
           for (int k = k0; k < k1; k++) {
             if (!((todo >> k) & 1u)) continue;
@@ -945,11 +950,26 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
             double rp[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) rp[c] = fresh_product((k == c) ? re[c] + dx : re[c], P.up);
-            const PosPart pq = pos_part(rp, tb, P.barC20);
+            // ... its atmosphere, the part that feels the altitude cancellation; wind and NED pair are insensitive to how the
+            // altitude was rounded and come from the recomputation
+            bool ok = false;
+            double d_rho = 0.0, d_P = 0.0, d_inv_a = 0.0;
+            if (!P.fd_recompute) {
+              GEL_LOAD_POS_CENTRE(pc, pcv);
+              const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
+              const double dlt = (k == 0) ? rp[0] - r[0] : ((k == 1) ? rp[1] - r[1] : rp[2] - r[2]);
+              PosPart pd;
+              ok = pos_delta(r, k, dlt, pcv, pc, tb, pd);
+              d_rho = pd.rho; d_P = pd.P; d_inv_a = pd.inv_a;
+            }
+            asm volatile("" ::: "memory");
+            PosPart pq = pos_part(rp, tb, P.barC20);
+            pq.rho = ok ? d_rho : pq.rho; pq.P = ok ? d_P : pq.P; pq.inv_a = ok ? d_inv_a : pq.inv_a;
             GEL_POS_SWEEP_TAIL(k, rp, pq);
           }
         }
 #endif
+#undef GEL_LOAD_POS_CENTRE
 #undef GEL_POS_SWEEP_TAIL
       }
 #endif

@@ -305,6 +305,35 @@ GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p
   if (ihy_out) *ihy_out = frsqrt(fmax(zz * zz + pp * pp, 1.0e-300));
 }
 
+// Bowring's one-step latitude (src/Earth.cpp:49-57) delivered as (sin lat, cos lat): the reference forms lat = atan2(zz, pp)
+// and then only ever uses sin / cos of it (and of lat / 2), so the pair is taken directly as (zz, pp) / hypot(zz, pp) -- the
+// same two numbers up to 2 ulp, without the atan2 -> sincos round trip (166 fp64 operations of the 507 of the position part).
+// Rounds 1-2 kept the round trip because the position SWEEPS differenced the altitude p / cos(lat) - N computed from the
+// pair, so its rounding had to correlate with the reference's; the sweeps now take the exact-difference form (pos_delta) and
+// no longer see how the centre pair was rounded.  pp == 0 (the polar axis, where the reference gets cos(pi/2) = 6.1e-17 and
+// an altitude of -N) returns the reference's pair.  ih_out / ihy_out: 1/hypot(z Ra, p Rb) and 1/hypot(zz, pp) for pos_delta().
+GEL_DEV void geodetic_sincos_p(double x, double y, double z, double& sl, double& cl, double& p, double& inv_p,
+                               double* ih_out = nullptr, double* ihy_out = nullptr) {
+  const double p2 = x * x + y * y;
+  fsqrt_rsqrt(fmax(p2, 1.0e-300), p, inv_p);
+  if (!(p2 > 0.0)) { p = 0.0; inv_p = 0.0; }
+  const double a = z * kRa, b = p * kRb;
+  const double h2 = a * a + b * b;
+  const double ih = frsqrt(fmax(h2, 1.0e-300));
+  const double st = (h2 > 0.0) ? a * ih : 0.0;
+  const double ct = (h2 > 0.0) ? b * ih : 1.0;
+  const double zz = z + kEp2 * kRb * (st * st * st), pp = p - kE2 * kRa * (ct * ct * ct);
+  const double ihy = frsqrt(fmax(zz * zz + pp * pp, 1.0e-300));
+  sl = zz * ihy;
+  cl = pp * ihy;
+  if (pp == 0.0) {   // sincos(atan2(zz, 0)): (+-1, cos(pi/2) as fp64 has it); atan2(0, 0) = 0
+    sl = (zz == 0.0) ? 0.0 : copysign(1.0, zz);
+    cl = (zz == 0.0) ? 1.0 : 6.123233995736766e-17;
+  }
+  if (ih_out) *ih_out = ih;
+  if (ihy_out) *ihy_out = ihy;
+}
+
 // altitude from (p, sin lat, cos lat): src/Earth.cpp:58-59
 GEL_DEV double geodetic_alt_from(double p, double sl, double cl) {
   const double N = fdiv(kRa, fsqrt(1.0 - kE2 * sl * sl));

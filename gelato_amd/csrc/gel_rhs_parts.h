@@ -76,20 +76,20 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20, Bra
                          PosCentreTail* tail = nullptr) {
   PosPart o;
   // the reference feeds the ECI position to ecef2geodetic for altitude (src/pybind_dynamics.cpp:43)
-  // The altitude p/cos(lat) - N cancels 6.4e6 m down to the altitude; sin/cos(lat) are taken the reference's way (atan2,
-  // then sincos), so that the centre value rounds like the reference's.
   double p, sl, cl;
-#ifdef GEL_AB_LATALG  // A/B switch for tools/variant.sh only: the algebraic pair
-  geodetic_sincos(r[0], r[1], r[2], sl, cl, p);
-  o.inv_p = frcp(p);
+#ifdef GEL_AB_LATRT  // A/B switch: latitude by atan2, then sincos (rounds 1-2)
+  {
+    double lat, ih = 0.0, ihy = 0.0;
+    geodetic_lat_p(r[0], r[1], r[2], lat, p, o.inv_p, &ih, &ihy);
+    fsincos(lat, &sl, &cl);
+    if (CENTRE) { sink.put(PCS_IH, ih); sink.put(PCS_IHY, ihy); sink.put(PCS_P, p); }
+  }
 #else
-  double lat;
   if (CENTRE) {
     double ih, ihy;
-    geodetic_lat_p(r[0], r[1], r[2], lat, p, o.inv_p, &ih, &ihy);
+    geodetic_sincos_p(r[0], r[1], r[2], sl, cl, p, o.inv_p, &ih, &ihy);
     sink.put(PCS_IH, ih); sink.put(PCS_IHY, ihy); sink.put(PCS_P, p);
-  } else geodetic_lat_p(r[0], r[1], r[2], lat, p, o.inv_p);
-  fsincos(lat, &sl, &cl);
+  } else geodetic_sincos_p(r[0], r[1], r[2], sl, cl, p, o.inv_p);
 #endif
   // half-angle pair of the NED quaternion (src/Coordinate.cpp:89-90): cos(lat/2) = sqrt((1+cos lat)/2)
   // (cos lat >= 0), sin(lat/2) = sin lat / (2 cos(lat/2)); root and reciprocal root from one iteration
@@ -127,7 +127,7 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20, Bra
 GEL_DEV void pos_centre_tail(const PosCentreTail& t, double rho, double P, const Tables& tb, PosCentre& pc, double& wn, double& we) {
   double wm;
   wind_piece(t.h, t.piece, tb.wind, tb.winds, tb.Kw, wn, we, pc.s0, pc.s1, wm);
-  const double lo = tb.atm[66 + t.k];
+  const double lo = (t.k == 0) ? -1.0e300 : tb.atm[66 + t.k];   // the bottom layer extends below sea level (src/Air.cpp:56-61)
   const double hi = (t.k == 6) ? kGeopot86 : ((t.k < 10) ? tb.atm[67 + min(t.k, 9)] : 1.0e300);
   pc.margin = fmin(wm, fmin(t.h - lo, hi - t.h));
   pc.air.iT = rho * tb.atm[33 + t.k] * frcp(P);

@@ -1,0 +1,123 @@
+"""Synthetic extreme states shared by the parity tests and by tests/golden/make_exact_fd.py (which pins them with
+exact-arithmetic finite-difference values).  Every builder returns (prob, x): the static problem as the engine / oracle take
+it and a packed decision vector.  Deterministic (seeded)."""
+import numpy as np
+
+
+def _example_prob():
+    from gelato_amd import con_dynamics, problem
+    pdict, unitdict, condition, xdict = problem.make_problem("example")
+    return dict(con_dynamics.problem_arrays(pdict, unitdict))
+
+
+def ragged_state():
+    """n = 2 phases, engine-off + free attitude, NoAir + hold, zero thrust with aero, a multi-chunk phase (n = 100 > 64) with a
+    ragged tail; positions anywhere on the sphere (all latitudes, the poles' neighbourhood included) at 0 .. 127 km, speeds of
+    several km/s in whatever air there is: dynamic pressures far beyond any flight."""
+    prob = _example_prob()
+    rng = np.random.default_rng(7)
+    S = 7
+    prob["num_nodes"] = np.array([2, 3, 100, 2, 17, 64, 5], dtype=np.int32)
+    prob["thrust"] = np.array([420000.0, 0.0, 420000.0, 30700.0, 0.0, 30700.0, 1000.0])
+    prob["massflow"] = np.array([140.0, 0.0, 140.0, 9.8, 0.0, 9.8, 0.3])
+    prob["reference_area"] = np.array([2.21, 2.21, 2.21, 0.0, 0.0, 2.21, 0.0])
+    prob["nozzle_area"] = np.array([0.68, 0.0, 0.68, 0.0, 0.0, 0.1, 0.0])
+    prob["engine_on"] = np.array([1, 0, 1, 1, 0, 1, 1], dtype=np.int32)
+    prob["attitude_hold"] = np.array([1, 0, 0, 1, 1, 0, 0], dtype=np.int32)
+    N = int(prob["num_nodes"].sum())
+    M = N + S
+    # physically sensible random state: radius 1.0..1.02 Earth radii, speeds up to 7 km/s
+    pos = rng.standard_normal((M, 3))
+    pos = pos / np.linalg.norm(pos, axis=1, keepdims=True) * (1.0 + 0.02 * rng.random((M, 1)))
+    vel = rng.standard_normal((M, 3)) * 3.0
+    quat = rng.standard_normal((M, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([0.2 + rng.random(M), pos.ravel(), vel.ravel(), quat.ravel(), rng.standard_normal(2 * N),
+                        np.sort(rng.random(S + 1))])
+    return prob, x
+
+
+def long_state(nn):
+    """phases of 68 nodes and more (slab-staged D.X), every second one aerodynamic, |lat| <= 57 deg, 0 .. 150 km, up to ~12 km/s"""
+    prob = _example_prob()
+    rng = np.random.default_rng(sum(nn))
+    S = len(nn)
+    prob["num_nodes"] = np.array(nn, dtype=np.int32)
+    prob["engine_on"] = np.ones(S, dtype=np.int32)
+    prob["thrust"] = rng.uniform(1e4, 5e5, S)
+    prob["massflow"] = rng.uniform(1.0, 150.0, S)
+    prob["reference_area"] = np.where(np.arange(S) % 2 == 0, 2.0, 0.0)
+    prob["nozzle_area"] = rng.uniform(0.0, 1.0, S)
+    prob["attitude_hold"] = np.zeros(S, dtype=np.int32)
+    N = int(sum(nn))
+    M = N + S
+    up = prob["units"][1]
+    lat = rng.uniform(-1.0, 1.0, M)
+    lon = rng.uniform(-np.pi, np.pi, M)
+    R = (6378137.0 - 21385.0 * np.sin(lat) ** 2 + rng.uniform(0.0, 150e3, M)) / up
+    pos = np.column_stack([R * np.cos(lat) * np.cos(lon), R * np.cos(lat) * np.sin(lon), R * np.sin(lat)])
+    vel = rng.standard_normal((M, 3)) * rng.uniform(0.05, 4.0, (M, 1))
+    quat = rng.standard_normal((M, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([0.2 + rng.random(M), pos.ravel(), vel.ravel(), quat.ravel(), rng.standard_normal(2 * N),
+                        np.sort(rng.random(S + 1))])
+    return prob, x
+
+
+def all_layers_state(lat_lo=-0.95, lat_hi=1.45):
+    """One aerodynamic phase whose 64 nodes climb from 300 m below the ellipsoid to 700 km: every US-1976 layer (lapse,
+    isothermal, the 91-110 km ellipse, the exponential above 120 km), the geopotential switch at 86 km, wind / CA clamps on both
+    sides, southern and northern latitudes (geocentric lat_lo .. lat_hi rad along the climb), Mach 0.03 ... 30, long flight times."""
+    prob = _example_prob()
+    rng = np.random.default_rng(23)
+    n = 64
+    prob["num_nodes"] = np.array([n], dtype=np.int32)
+    for k, v in [("thrust", 420000.0), ("massflow", 140.9), ("reference_area", 2.21), ("nozzle_area", 0.68)]:
+        prob[k] = np.array([v])
+    prob["engine_on"] = np.array([1], dtype=np.int32)
+    prob["attitude_hold"] = np.array([0], dtype=np.int32)
+    up, uv, ut = prob["units"][1], prob["units"][2], prob["units"][4]
+    alt = np.concatenate([[-300.0, -50.0, 0.0, 10.0], np.linspace(2e3, 130e3, 53), [150e3, 200e3, 300e3, 400e3, 500e3, 600e3, 700e3, 700e3]])
+    assert len(alt) == n + 1
+    lat = np.linspace(lat_lo, lat_hi, n + 1)
+    lon = np.linspace(-3.0, 3.0, n + 1)
+    a_e, b_e = 6378137.0, 6356752.314245
+    R = (a_e * b_e / np.sqrt((b_e * np.cos(lat)) ** 2 + (a_e * np.sin(lat)) ** 2) + alt) / up   # ellipsoid radius + altitude
+    pos = np.column_stack([R * np.cos(lat) * np.cos(lon), R * np.cos(lat) * np.sin(lon), R * np.sin(lat)])
+    speed = np.geomspace(10.0, 9000.0, n + 1) / uv
+    d = rng.standard_normal((n + 1, 3))
+    vel = d / np.linalg.norm(d, axis=1, keepdims=True) * speed[:, None]
+    quat = rng.standard_normal((n + 1, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([np.linspace(1.0, 0.3, n + 1), pos.ravel(), vel.ravel(), quat.ravel(),
+                        2.0 * rng.standard_normal(2 * n), [100.0 / ut, 9000.0 / ut]])
+    return prob, x
+
+
+def polar_dense_state():
+    """What rounds 1-2 kept out of the parity claim: dense air at high latitude.  One aerodynamic phase of 48 nodes at
+    geodetic-ish latitudes 55 .. 89.9 deg, both hemispheres, sea level .. 30 km, 300 .. 2500 m/s (max-q conditions and
+    beyond), nozzle area 0.68 (the sea-level pressure-thrust term)."""
+    prob = _example_prob()
+    rng = np.random.default_rng(91)
+    n = 48
+    prob["num_nodes"] = np.array([n], dtype=np.int32)
+    for k, v in [("thrust", 420000.0), ("massflow", 140.9), ("reference_area", 2.21), ("nozzle_area", 0.68)]:
+        prob[k] = np.array([v])
+    prob["engine_on"] = np.array([1], dtype=np.int32)
+    prob["attitude_hold"] = np.array([0], dtype=np.int32)
+    up, uv, ut = prob["units"][1], prob["units"][2], prob["units"][4]
+    lat = np.deg2rad(np.concatenate([np.linspace(55.0, 89.9, 25), -np.linspace(56.0, 89.5, 24)]))
+    alt = np.concatenate([np.linspace(0.0, 30e3, 25), np.linspace(29e3, 100.0, 24)])
+    lon = rng.uniform(-np.pi, np.pi, n + 1)
+    a_e, b_e = 6378137.0, 6356752.314245
+    R = (a_e * b_e / np.sqrt((b_e * np.cos(lat)) ** 2 + (a_e * np.sin(lat)) ** 2) + alt) / up
+    pos = np.column_stack([R * np.cos(lat) * np.cos(lon), R * np.cos(lat) * np.sin(lon), R * np.sin(lat)])
+    speed = rng.uniform(300.0, 2500.0, n + 1) / uv
+    d = rng.standard_normal((n + 1, 3))
+    vel = d / np.linalg.norm(d, axis=1, keepdims=True) * speed[:, None]
+    quat = rng.standard_normal((n + 1, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([np.linspace(1.0, 0.5, n + 1), pos.ravel(), vel.ravel(), quat.ravel(),
+                        2.0 * rng.standard_normal(2 * n), [10.0 / ut, 160.0 / ut]])
+    return prob, x

@@ -259,7 +259,33 @@ def test_rhs_shape_errors_like_pybind():
 # --------------------------------------------------------------------------
 # a12..a19: residuals and COO Jacobians
 # --------------------------------------------------------------------------
-def check_against_oracle(E, P, x, what):
+def reference_noise_per_row(P, prob, x, barC20=None):
+    """What the REFERENCE's finite-difference entries of the velocity defect may be off the exact quotient, per residual row
+    of the group (tests/fd_noise.py: derived from the arithmetic, checked against exact-arithmetic quotients in
+    tests/test_exact_fd.py): {var: [3N]} -- zero for phases without aerodynamics."""
+    import fd_noise
+    oracle = _setup()
+    pr = dict(prob)
+    pr["tau"] = [P.tau(i) for i in range(P.S)]
+    terms = fd_noise.velocity_noise_terms(oracle, pr, x, barC20)
+    N = int(np.sum(prob["num_nodes"]))
+    pos, oth = np.zeros(N), np.zeros(N)
+    ua = 0
+    for i, n in enumerate(prob["num_nodes"]):
+        n = int(n)
+        if terms[i] is not None:
+            pos[ua:ua + n] = fd_noise.reference_bound(terms[i])
+            oth[ua:ua + n] = fd_noise.reference_bound_other(terms[i])
+        ua += n
+    return {"position": np.repeat(pos, 3), "mass": np.repeat(oth, 3), "velocity": np.repeat(oth, 3),
+            "quaternion": np.repeat(oth, 3), "t": np.repeat(oth, 3)}
+
+
+def check_against_oracle(E, P, x, what, prob=None, barC20=None):
+    """Engine against oracle: residuals 1e-12 + 1e-10 |ref| (+ the D.X summation bound), constants and pattern bit-exact,
+    x-dependent Jacobian entries 1e-5 + 1e-6 |ref| -- plus, for the velocity group of aerodynamic phases when `prob` is given,
+    the derived rounding noise of the reference's OWN finite differences at that node (high latitude, dense air: the
+    oracle recomputes like the reference and carries that noise; the engine's exact-difference sweeps do not)."""
     oracle = _setup()
     res, rc = E.eval_residual(x)
     assert rc == 0
@@ -269,6 +295,7 @@ def check_against_oracle(E, P, x, what):
     J = E.jac_dicts(vals)
     var_mask = E.var_mask()
     bound = dx_roundoff_bound(E, x)
+    noise = reference_noise_per_row(P, prob, x, barC20) if prob is not None else None
     b = 0
     for grp in oracle.GROUPS:
         close(R[grp], P.residual(grp, x), atol=1e-12 + bound[grp], what="%s residual %s" % (what, grp))
@@ -281,7 +308,10 @@ def check_against_oracle(E, P, x, what):
             assert J[grp][var]["shape"] == Jo[var]["shape"]
             m = var_mask[E.block_off[b]:E.block_off[b + 1]]
             d = np.abs(v - vo)
-            assert np.all(d[m] <= 1e-5 + 1e-6 * np.abs(vo[m])), "%s %s/%s var max %g" % (what, grp, var, d[m].max())
+            tol = 1e-5 + 1e-6 * np.abs(vo)
+            if noise is not None and grp == "vel":
+                tol = tol + noise[var][r]
+            assert np.all(d[m] <= tol[m]), "%s %s/%s var max %g (max excess %g)" % (what, grp, var, d[m].max(), (d[m] - tol[m]).max())
             assert np.array_equal(v[~m], vo[~m]), "%s %s/%s constants" % (what, grp, var)
             b += 1
     return res, vals
@@ -328,29 +358,20 @@ def test_full_size_configs_vs_oracle(name):
 
 def test_ragged_and_edge_phases():
     """n = 2 phases, engine-off + free attitude, NoAir + hold, zero thrust with aero, and a
-    multi-chunk phase (n = 100 > 64) with a ragged tail."""
-    prob, x0, _ = named_problem("example")
-    rng = np.random.default_rng(7)
-    S = 7
-    prob = dict(prob)
-    prob["num_nodes"] = np.array([2, 3, 100, 2, 17, 64, 5], dtype=np.int32)
-    prob["thrust"] = np.array([420000.0, 0.0, 420000.0, 30700.0, 0.0, 30700.0, 1000.0])
-    prob["massflow"] = np.array([140.0, 0.0, 140.0, 9.8, 0.0, 9.8, 0.3])
-    prob["reference_area"] = np.array([2.21, 2.21, 2.21, 0.0, 0.0, 2.21, 0.0])
-    prob["nozzle_area"] = np.array([0.68, 0.0, 0.68, 0.0, 0.0, 0.1, 0.0])
-    prob["engine_on"] = np.array([1, 0, 1, 1, 0, 1, 1], dtype=np.int32)
-    prob["attitude_hold"] = np.array([1, 0, 0, 1, 1, 0, 0], dtype=np.int32)
+    multi-chunk phase (n = 100 > 64) with a ragged tail; positions all over the sphere (tests/states.py)."""
+    import states
+    prob, x = states.ragged_state()
     E, P = make_pair(prob)
-    N, M = E.N, E.M
-    # physically sensible random state: radius 1.0..1.02 Earth radii, speeds up to 7 km/s
-    pos = rng.standard_normal((M, 3))
-    pos = pos / np.linalg.norm(pos, axis=1, keepdims=True) * (1.0 + 0.02 * rng.random((M, 1)))
-    vel = rng.standard_normal((M, 3)) * 3.0
-    quat = rng.standard_normal((M, 4))
-    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
-    x = np.concatenate([0.2 + rng.random(M), pos.ravel(), vel.ravel(), quat.ravel(), rng.standard_normal(2 * N),
-                        np.sort(rng.random(S + 1))])
-    check_against_oracle(E, P, x, "ragged")
+    check_against_oracle(E, P, x, "ragged", prob=prob)
+
+
+def test_dense_air_at_high_latitude():
+    """55 .. 89.9 degrees, sea level .. 30 km, up to 2.5 km/s: the states rounds 1-2 kept out of the parity claim.  Against the
+    oracle with the reference's derived noise allowance; against exact quotients in tests/test_exact_fd.py."""
+    import states
+    prob, x = states.polar_dense_state()
+    E, P = make_pair(prob)
+    check_against_oracle(E, P, x, "polar-dense", prob=prob)
 
 
 def test_batch_matches_single_and_oracle():
@@ -965,41 +986,20 @@ def test_pipelined_host_batch_equals_resident_launch():
 def test_all_atmosphere_layers_and_both_hemispheres():
     """One aerodynamic phase whose 64 nodes climb from 300 m below the ellipsoid to 700 km: every US-1976 layer
     (lapse, isothermal, the 91-110 km ellipse, the exponential above 120 km), the geopotential switch at 86 km,
-    wind / CA clamps on both sides, southern and northern latitudes, Mach 0.03 ... 30, long flight times."""
-    prob, _, _ = named_problem("example")
-    rng = np.random.default_rng(23)
-    prob = dict(prob)
-    n = 64
-    prob["num_nodes"] = np.array([n], dtype=np.int32)
-    for k, v in [("thrust", 420000.0), ("massflow", 140.9), ("reference_area", 2.21), ("nozzle_area", 0.68)]:
-        prob[k] = np.array([v])
-    prob["engine_on"] = np.array([1], dtype=np.int32)
-    prob["attitude_hold"] = np.array([0], dtype=np.int32)
-    E, P = make_pair(prob)
-    up, uv, ut = prob["units"][1], prob["units"][2], prob["units"][4]
-    alt = np.concatenate([[-300.0, -50.0, 0.0, 10.0], np.linspace(2e3, 130e3, 53), [150e3, 200e3, 300e3, 400e3, 500e3, 600e3, 700e3, 700e3]])
-    assert len(alt) == n + 1
-    # -54 ... +83 degrees (geocentric): the dense-air nodes sit at moderate latitude on purpose.  The altitude
-    # p/cos(lat) - N amplifies the last-bit difference between ocml's and glibc's atan2/sincos by tan(lat)/cos(lat),
-    # and the sea-level pressure-thrust term turns that into FD noise ~ nozzle*P/H * d(alt)/dx: at 80 degrees and
-    # 0 m the reference's own entries are only good to 3e-6 relative (measured here: 8.7e-4 on an entry of 257).
-    lat = np.linspace(-0.95, 1.45, n + 1)
-    lon = np.linspace(-3.0, 3.0, n + 1)
-    a_e, b_e = 6378137.0, 6356752.314245
-    R = (a_e * b_e / np.sqrt((b_e * np.cos(lat)) ** 2 + (a_e * np.sin(lat)) ** 2) + alt) / up   # ellipsoid radius + altitude
-    pos = np.column_stack([R * np.cos(lat) * np.cos(lon), R * np.cos(lat) * np.sin(lon), R * np.sin(lat)])
-    speed = np.geomspace(10.0, 9000.0, n + 1) / uv
-    d = rng.standard_normal((n + 1, 3))
-    vel = d / np.linalg.norm(d, axis=1, keepdims=True) * speed[:, None]
-    quat = rng.standard_normal((n + 1, 4))
-    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
-    x = np.concatenate([np.linspace(1.0, 0.3, n + 1), pos.ravel(), vel.ravel(), quat.ravel(),
-                        2.0 * rng.standard_normal(2 * n), [100.0 / ut, 9000.0 / ut]])
-    check_against_oracle(E, P, x, "all-layers")
-    # the oracle's own altitudes really span the table (guards the construction above)
-    oracle = _setup()
-    h = np.array([oracle.ecef2geodetic(*(pos[i] * up))[2] for i in (1, n)])
-    assert h[0] < 0.0 and h[1] > 6.0e5
+    wind / CA clamps on both sides, southern and northern latitudes, Mach 0.03 ... 30, long flight times -- once with
+    the dense-air nodes at moderate latitude (-54 .. +83 degrees along the climb), once with the climb STARTING at 80 degrees
+    (sea-level air at 80 degrees: 3e-6 relative noise in the reference's own entries, covered by its derived allowance)."""
+    import states
+    for lo, hi in ((-0.95, 1.45), (1.40, -1.2)):
+        prob, x = states.all_layers_state(lo, hi)
+        E, P = make_pair(prob)
+        check_against_oracle(E, P, x, "all-layers %.2f..%.2f" % (lo, hi), prob=prob)
+        # the oracle's own altitudes really span the table (guards the construction)
+        oracle = _setup()
+        up = prob["units"][1]
+        pos = x[E.M:4 * E.M].reshape(-1, 3)
+        h = np.array([oracle.ecef2geodetic(*(pos[i] * up))[2] for i in (1, 64)])
+        assert h[0] < 0.0 and h[1] > 6.0e5
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -1025,7 +1025,7 @@ def test_random_problem_structures_values(seed):
     E, P = make_pair(prob)
     N, M = E.N, E.M
     up = prob["units"][1]
-    lat = rng.uniform(-1.0, 1.0, M)                            # |lat| <= 57 deg: see DESIGN.md on FD conditioning
+    lat = rng.uniform(-1.5, 1.5, M)                            # up to 86 deg: the reference's own FD noise is allowed for (fd_noise.py)
     lon = rng.uniform(-np.pi, np.pi, M)
     R = (6378137.0 - 21385.0 * np.sin(lat) ** 2 + rng.uniform(0.0, 150e3, M)) / up
     pos = np.column_stack([R * np.cos(lat) * np.cos(lon), R * np.cos(lat) * np.sin(lon), R * np.sin(lat)])
@@ -1034,7 +1034,7 @@ def test_random_problem_structures_values(seed):
     quat /= np.linalg.norm(quat, axis=1, keepdims=True)
     x = np.concatenate([0.2 + rng.random(M), pos.ravel(), vel.ravel(), quat.ravel(), rng.standard_normal(2 * N),
                         np.sort(rng.random(S + 1))])
-    res1, vals1 = check_against_oracle(E, P, x, "random-%d" % seed)
+    res1, vals1 = check_against_oracle(E, P, x, "random-%d" % seed, prob=prob)
     # the same vector inside a large batch goes through the throughput form of the kernel: same bits
     B = 200
     X = np.tile(x, (B, 1))
@@ -1046,30 +1046,10 @@ def test_random_problem_structures_values(seed):
 def test_long_phases_slab_staged_product(nn):
     """Phases of 68 nodes and more form D.X from double-buffered 44-row slabs of state rows: 2 .. 5 slabs, ragged last
     slabs and ragged last chunks, against the oracle and -- the same vector inside a batch -- against the split form."""
-    prob, _, _ = named_problem("example")
-    rng = np.random.default_rng(sum(nn))
-    S = len(nn)
-    prob = dict(prob)
-    prob["num_nodes"] = np.array(nn, dtype=np.int32)
-    prob["engine_on"] = np.ones(S, dtype=np.int32)
-    prob["thrust"] = rng.uniform(1e4, 5e5, S)
-    prob["massflow"] = rng.uniform(1.0, 150.0, S)
-    prob["reference_area"] = np.where(np.arange(S) % 2 == 0, 2.0, 0.0)
-    prob["nozzle_area"] = rng.uniform(0.0, 1.0, S)
-    prob["attitude_hold"] = np.zeros(S, dtype=np.int32)
+    import states
+    prob, x = states.long_state(nn)
     E, P = make_pair(prob)
-    N, M = E.N, E.M
-    up = prob["units"][1]
-    lat = rng.uniform(-1.0, 1.0, M)
-    lon = rng.uniform(-np.pi, np.pi, M)
-    R = (6378137.0 - 21385.0 * np.sin(lat) ** 2 + rng.uniform(0.0, 150e3, M)) / up
-    pos = np.column_stack([R * np.cos(lat) * np.cos(lon), R * np.cos(lat) * np.sin(lon), R * np.sin(lat)])
-    vel = rng.standard_normal((M, 3)) * rng.uniform(0.05, 4.0, (M, 1))
-    quat = rng.standard_normal((M, 4))
-    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
-    x = np.concatenate([0.2 + rng.random(M), pos.ravel(), vel.ravel(), quat.ravel(), rng.standard_normal(2 * N),
-                        np.sort(rng.random(S + 1))])
-    res1, vals1 = check_against_oracle(E, P, x, "long-%s" % (nn,))
+    res1, vals1 = check_against_oracle(E, P, x, "long-%s" % (nn,), prob=prob)
     for B in (300, 517):                                             # cooperative form (not the split latency form); ragged groups
         X = np.tile(x, (B, 1))
         X[B // 2] *= 1.0 + 1e-9
