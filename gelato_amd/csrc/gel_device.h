@@ -12,6 +12,7 @@ struct PhaseDev {
   int32_t air;        // reference_area != 0  -> dynamics_velocity, else _NoAir (lib/con_dynamics.py:257,346)
   int32_t air_fd;     // reference_area  > 0  -> velocity / t0 / tf sweeps are finite differences (:403,454)
   int32_t t_fd;       // air_fd and GEL_FLAG_FD_RECOMPUTE: the t0 / tf columns by two more sweeps (else in closed form, tf = -t0)
+  int32_t q_fd;       // free attitude and GEL_FLAG_FD_RECOMPUTE: quaternion-kinematics entries by finite differences (else closed form)
   int32_t engine_on;  // lib/con_dynamics.py:53,80
   int32_t hold;       // attitude in ("hold","vertical")  (lib/con_dynamics.py:521,559)
   int32_t K;          // compact Jacobian slots per node of this phase
@@ -34,7 +35,7 @@ __device__ __forceinline__ T load_const(const T* p) {
 __device__ __forceinline__ PhaseDev load_phase(const PhaseDev* g) {
   PhaseDev q;
   q.n = load_const(&g->n); q.ua = load_const(&g->ua); q.xa = load_const(&g->xa);
-  q.air = load_const(&g->air); q.air_fd = load_const(&g->air_fd); q.t_fd = load_const(&g->t_fd); q.engine_on = load_const(&g->engine_on);
+  q.air = load_const(&g->air); q.air_fd = load_const(&g->air_fd); q.t_fd = load_const(&g->t_fd); q.q_fd = load_const(&g->q_fd); q.engine_on = load_const(&g->engine_on);
   q.hold = load_const(&g->hold); q.K = load_const(&g->K);
   q.s_vv = load_const(&g->s_vv); q.s_vq = load_const(&g->s_vq); q.s_vt = load_const(&g->s_vt); q.s_qq = load_const(&g->s_qq);
   q.doff = load_const(&g->doff); q.toff = load_const(&g->toff); q.voff = load_const(&g->voff);

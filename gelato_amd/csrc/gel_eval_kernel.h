@@ -107,6 +107,13 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_PACK_A_PRELOAD 1  // two vectors per wavefront: all (<= 9) A slabs of D.X requested before the operand barrier
 #endif
 
+#ifndef GEL_PREFETCH_NEXT
+#define GEL_PREFETCH_NEXT 0  // 1024: touch the state rows of the workgroup dispatched one launch wave later (see the kernel)
+#endif
+#ifndef GEL_PRIO_PHASE_A
+#define GEL_PRIO_PHASE_A 0   // s_setprio level of a wavefront until its D.X rows are in registers
+#endif
+
 #ifndef GEL_COOP_XLDS
 #define GEL_COOP_XLDS 1  // cooperative D.X: state rows staged in LDS (1) or fetched per k-step from global memory (0)
 #endif
@@ -126,6 +133,18 @@ template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false>
 __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : GEL_MIN_WAVES_PER_SIMD) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   extern __shared__ double lds[];
+#ifdef GEL_STAMP  // diagnostic build only (tools/stamp_phases.py): where a wavefront's lifetime goes, in shader cycles
+#define GEL_STAMP_AT(i) do { if ((threadIdx.x & 63) == 0) gel_stamps[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) & ((1u << 18) - 1)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEL_STAMP_AT(i) do {} while (0)
+#endif
+  GEL_STAMP_AT(0);
+#if GEL_PREFETCH_NEXT
+  unsigned touch_reg = 0;   // destination of the prefetch loads: stays reserved until they have returned (end of the kernel)
+#endif
+#if GEL_PRIO_PHASE_A
+  if (MFMA && !SPLIT && JAC) __builtin_amdgcn_s_setprio(GEL_PRIO_PHASE_A);
+#endif
   const int park_off = P.park_off;
   // the cooperative forms meet at a barrier (operand image / hand-over) before any table lookup: no barrier of its own
   const Tables tb = stage_tables(P, lds, !(MFMA && !SPLIT));
@@ -227,6 +246,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   unsigned long long bad = 0;
 #define GEL_CHK(v) (bad |= __builtin_amdgcn_ballot_w64(!(fabs(v) <= 1.79769313486231570815e308)))
 
+  GEL_STAMP_AT(1);
   double* rb = (res && lead) ? res + (size_t)b * 11 * N : nullptr;
 #ifdef GEL_ABL_NOSTORE  // ablation (tools/variant.sh): everything computed, (almost) nothing stored
   double* jb = JAC ? jvar + (size_t)b * P.V + ph.voff + (size_t)j0 * ph.K + (j - j0) : nullptr;
@@ -366,6 +386,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         }
 #endif
         __syncthreads();
+        GEL_STAMP_AT(2);
 #if GEL_PACK_A_PRELOAD
         if (PACK) {
 #pragma unroll
@@ -402,6 +423,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
             }
           }
         }
+        GEL_STAMP_AT(3);
         {
           // the node's own state row comes from the same image (after the product: nothing of it is live across the loop)
           lds_double* src = wave_lds + (half * kPackRows + jc + 1) * 11;
@@ -428,6 +450,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
           }
         }
         __syncthreads();
+        GEL_STAMP_AT(4);
         if (ghost) return;
         lds_double* row = wave_lds + kHO + lane * 11;
         lm = row[0];
@@ -702,8 +725,9 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
           GEL_CHK(cq);                   // L2 merges; written non-temporally they cost 4 % more HBM writes (PMC)
         }
       }
-      if (JAC) {
+      if (JAC && ph.q_fd) {
         double f[4];
+        // GEL_FLAG_FD_RECOMPUTE: the reference's sweeps.
         // submat_quat[4j+c, 4(j+1)+k] = D[j][j+1]*(c==k) + rh_quat   (con_dynamics.py:575-589).  dq_c contains q_k only
         // for (c, k) in {0,1} x {2,3} and {2,3} x {0,1}: the other eight differences are exactly zero in the reference
         // too (the perturbed component never enters), so those entries are constants of the pattern.
@@ -725,6 +749,22 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 16 + c, fq[c] * ut / 2.0);  // t0 column; tf = its negative
+      } else if (JAC) {
+        // dq = q (x) (0, 0, omega_y, omega_z) / 2 is linear in q and in u (src/pybind_dynamics.cpp:94-106), so the reference's
+        // difference quotients ARE its partial derivatives up to the rounding of two evaluations (1e-8 of |dq|): the sixteen
+        // entries of quat / quaternion and quat / u are +- six numbers -- omega_y S / 2, omega_z S / 2 and
+        // unit_u (pi / 180) q_i S / 2 with S = (tf - to) unit_t / 2 -- which the gather map signs and places (gel_host.hip).
+        const double hS = (tf - to) * ut / 2.0;
+        const double d2r = 0.017453292519943295769;
+        EMIT(ph.s_qq + 0, 0.5 * ((u0 * P.uu) * d2r) * hS);
+        EMIT(ph.s_qq + 1, 0.5 * ((u1 * P.uu) * d2r) * hS);
+        const double kq = 0.5 * (P.uu * d2r) * hS;
+        EMIT(ph.s_qq + 2, -(kq * q[0]));
+        EMIT(ph.s_qq + 3, kq * q[1]);
+        EMIT(ph.s_qq + 4, kq * q[2]);
+        EMIT(ph.s_qq + 5, kq * q[3]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 6 + c, fq[c] * ut / 2.0);  // t0 column; tf = its negative
       }
     }
     if (rb) {
@@ -755,6 +795,50 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
       }
     }
   }
+  GEL_STAMP_AT(5);
+#if GEL_PRIO_PHASE_A
+  if (MFMA && !SPLIT && JAC) __builtin_amdgcn_s_setprio(0);
+#endif
+#if GEL_PREFETCH_NEXT
+  // The state rows a LATER workgroup will stage, touched now: workgroup p shares its XCD (and that XCD's L2) with workgroup
+  // p + 8k; about GEL_PREFETCH_NEXT workgroups are resident per launch wave, so p + GEL_PREFETCH_NEXT is dispatched onto this
+  // XCD roughly one workgroup lifetime from now and finds its rows in L2 instead of behind the store stream in HBM.  Pure
+  // prefetch of read-only input (one dword per 128-byte line, never waited for, result unused): placement-independent.
+  if (COOP && !PACK && JAC) {
+    const unsigned p2 = blockIdx.x + (unsigned)GEL_PREFETCH_NEXT;
+    if (p2 < gridDim.x) {
+      const unsigned nb = (unsigned)nb4;
+      const unsigned it2 = p2 / nb, r2 = p2 - it2 * nb;
+      const int4 c2 = P.chunks[P.chunk0 + it2];
+      const unsigned pos2 = (unsigned)c2.w >> 16, nc2 = (unsigned)c2.w & 0xffffu;
+      unsigned bg2 = r2;
+      if (nc2 > 1) {
+        const unsigned l = pos2 * nb + r2;
+        const unsigned blk = l / (8 * nc2), rem = l - blk * 8 * nc2;
+        const unsigned m = min(8u, nb - blk * 8);
+        bg2 = blk * 8 + (rem - (rem / m) * m);
+      }
+      const int sec2 = __builtin_amdgcn_readfirstlane(c2.x);
+      const int n2 = load_const(&P.phases[sec2].n), xa2 = load_const(&P.phases[sec2].xa);
+      const double* xn = x + (size_t)min((int)bg2 * 4 + wv, B - 1) * P.nvars;
+      // lines of the four state arrays of that vector's phase: lane l touches byte 128 l of each
+      const int rows8 = (n2 + 1) * 8;
+      const int o = lane * 128;
+#define GEL_TOUCH(ptr, bytes)                                                                         \
+  do {                                                                                                \
+    if (o < (bytes) + 128) {                                                                          \
+      const char* a_ = (const char*)(ptr) + min(o, (bytes) - 4);                                      \
+      asm volatile("global_load_dword %0, %1, off" : "+v"(touch_reg) : "v"(a_));                      \
+    }                                                                                                 \
+  } while (0)
+      GEL_TOUCH(xn + xa2, rows8);
+      GEL_TOUCH(xn + M + 3 * xa2, 3 * rows8);
+      GEL_TOUCH(xn + 4 * M + 3 * xa2, 3 * rows8);
+      GEL_TOUCH(xn + 7 * M + 4 * xa2, 4 * rows8);
+#undef GEL_TOUCH
+    }
+  }
+#endif
   // ======================= from here on: no global loads =======================
   // compiler barrier: parked values are re-read from LDS below, not forwarded through VGPRs
   asm volatile("" ::: "memory");
@@ -893,6 +977,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
 #undef GEL_TDC
 #undef GEL_T
       }
+      GEL_STAMP_AT(6);
       // position sweeps (lib/con_dynamics.py:381-400); SPLIT: this wavefront's one
 #ifndef GEL_ABL_NOPOS
       if (JAC && (!SPLIT || part)) {
@@ -1080,6 +1165,10 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
 #undef GEL_UNI
 #undef PARK_GET
 #undef PARK_SET
+  GEL_STAMP_AT(7);
+#if GEL_PREFETCH_NEXT
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch_reg));
+#endif
   if (bad) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 

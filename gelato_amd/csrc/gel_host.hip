@@ -112,7 +112,7 @@ int lgr_diffmat_ld(int n, std::vector<double>& D, std::vector<double>& tau_out) 
 // ---------------------------------------------------------------------------
 struct HostPhase {
   int n, ua, xa;
-  int air, air_fd, t_fd, engine_on, hold;
+  int air, air_fd, t_fd, q_fd, engine_on, hold;
   int K, s_vv, s_vq, s_vt, s_qq;
   int64_t voff;
   double thrust, massflow, area, nozzle;
@@ -278,16 +278,37 @@ void walk_pattern(const gel_problem& P, const Visitor& vis) {
               // on the block diagonal dq_c/dq_kk is a finite difference only where dq_c contains q_kk
               // (src/pybind_dynamics.cpp:94-106: rows {0,1} x columns {2,3} and rows {2,3} x columns {0,1});
               // elsewhere the reference's difference is exactly zero and the entry is D[j][j+1] or 0
-              if (cc == j + 1 && ((c < 2) != (kk < 2)))
-                vis(10, k[10]++, 4 * (ua + j) + c, 4 * (xa + cc) + kk, 1, 0, cs(h, h.s_qq + 2 * kk + (c & 1), j));
-              else
+              if (cc == j + 1 && ((c < 2) != (kk < 2))) {
+                if (h.q_fd)
+                  vis(10, k[10]++, 4 * (ua + j) + c, 4 * (xa + cc) + kk, 1, 0, cs(h, h.s_qq + 2 * kk + (c & 1), j));
+                else {
+                  // closed form (dq is linear in q): two values per node, A = omega_y S / 2 (slot s_qq) and B = omega_z S / 2
+                  // (s_qq + 1), S = (tf - to) unit_t / 2; entry (c, kk) = -d(dq_c)/d(q_kk) S  (src/pybind_dynamics.cpp:94-106)
+                  static const int which[4][4] = {{-1, -1, 0, 1}, {-1, -1, 1, 0}, {0, 1, -1, -1}, {1, 0, -1, -1}};   // [c][kk]
+                  static const int sign[4][4] = {{0, 0, +1, +1}, {0, 0, -1, +1}, {-1, +1, 0, 0}, {-1, -1, 0, 0}};
+                  vis(10, k[10]++, 4 * (ua + j) + c, 4 * (xa + cc) + kk, sign[c][kk] > 0 ? 1 : 2, 0, cs(h, h.s_qq + which[c][kk], j));
+                }
+              } else
                 vis(10, k[10]++, 4 * (ua + j) + c, 4 * (xa + cc) + kk, 0, (c == kk) ? Dji(j, cc) : 0.0, -1);
             }
       for (int kk = 0; kk < 2; kk++)
         for (int j = 0; j < n; j++)
-          for (int c = 0; c < 4; c++) vis(11, k[11]++, 4 * (ua + j) + c, 2 * (ua + j) + kk, 1, 0, cs(h, h.s_qq + 8 + 4 * kk + c, j));
-      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i, 1, 0, cs(h, h.s_qq + 16 + jj % 4, jj / 4));
-      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i + 1, 2, 0, cs(h, h.s_qq + 16 + jj % 4, jj / 4));
+          for (int c = 0; c < 4; c++) {
+            if (h.q_fd)
+              vis(11, k[11]++, 4 * (ua + j) + c, 2 * (ua + j) + kk, 1, 0, cs(h, h.s_qq + 8 + 4 * kk + c, j));
+            else {
+              // closed form (dq is linear in u): slots s_qq + 2 .. 5 hold C_0' = -C_0, C_1, C_2, C_3 with C_i = unit_u (pi/180) q_i S / 2
+              // (the first negated so that every slot has a positive use); entry (c, kk) = -d(dq_c)/d(u_kk) S
+              static const int which[2][4] = {{2, 3, 0, 1}, {3, 2, 1, 0}};          // [kk][c]: which C
+              static const int sign[2][4] = {{+1, +1, -1, -1}, {+1, -1, +1, -1}};
+              const int w = which[kk][c];
+              const int sg = (w == 0) ? -sign[kk][c] : sign[kk][c];                  // slot of C_0 stores -C_0
+              vis(11, k[11]++, 4 * (ua + j) + c, 2 * (ua + j) + kk, sg > 0 ? 1 : 2, 0, cs(h, h.s_qq + 2 + w, j));
+            }
+          }
+      const int s_qt = h.s_qq + (h.q_fd ? 16 : 6);
+      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i, 1, 0, cs(h, s_qt + jj % 4, jj / 4));
+      for (int jj = 0; jj < 4 * n; jj++) vis(12, k[12]++, 4 * ua + jj, i + 1, 2, 0, cs(h, s_qt + jj % 4, jj / 4));
     }
   }
 }
@@ -612,7 +633,8 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     h.t_fd = h.air_fd && p->fd_recompute;
     h.engine_on = d->engine_on[i] != 0; h.hold = d->attitude_hold[i] != 0;
     h.s_vv = 15; h.s_vq = h.air_fd ? 24 : 15; h.s_vt = h.s_vq + 12; h.s_qq = h.s_vt + (h.t_fd ? 6 : 3);
-    h.K = h.s_qq + (h.hold ? 0 : 20);
+    h.q_fd = !h.hold && p->fd_recompute;   // quaternion kinematics: finite differences (20 slots) or closed form (10)
+    h.K = h.s_qq + (h.hold ? 0 : (h.q_fd ? 20 : 10));
     h.voff = V; V += (int64_t)h.K * h.n + 1;  // node slots + the phase's pos/velocity diagonal scalar
     const size_t nd = (size_t)h.n * (h.n + 1);
     if (d->D && d->tau) {
@@ -710,7 +732,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
   for (int i = 0; i < S; i++) {
     const HostPhase& h = p->ph[i];
     gel::PhaseDev& q = dph[i];
-    q.n = h.n; q.ua = h.ua; q.xa = h.xa; q.air = h.air; q.air_fd = h.air_fd; q.t_fd = h.t_fd; q.engine_on = h.engine_on; q.hold = h.hold;
+    q.n = h.n; q.ua = h.ua; q.xa = h.xa; q.air = h.air; q.air_fd = h.air_fd; q.t_fd = h.t_fd; q.q_fd = h.q_fd; q.engine_on = h.engine_on; q.hold = h.hold;
     q.K = h.K; q.s_vv = h.s_vv; q.s_vq = h.s_vq; q.s_vt = h.s_vt; q.s_qq = h.s_qq;
     q.doff = (int32_t)Dt.size(); q.toff = (int32_t)tau.size(); q.voff = h.voff;
     q.thrust = h.thrust; q.massflow = h.massflow; q.area = h.area; q.nozzle = h.nozzle;

@@ -274,16 +274,28 @@ GEL_DEV void wind_eci_or_calm(const double r[3], const EarthAngle& e, double s_h
   wind_eci(r, e, s_hp, c_hp, inv_p, wn, we, w);
 }
 
-// aerodynamic force (ECI): src/pybind_dynamics.cpp:48-59 given the shared parts
+// aerodynamic force (ECI): src/pybind_dynamics.cpp:48-59 given the shared parts.
+// Air-relative velocity: the reference forms vel_eci2ecef(v, r, t) = Rz(-omega t) (v - omega x r) and then rotates it straight
+// back, ecef2eci(., t) = Rz(+omega t) (src/Coordinate.cpp:69-73, 41-49, src/pybind_dynamics.cpp:48,53).  The two rotations
+// cancel; they are not performed here (GEL_AERO_ROTATE=1 restores them): v - omega x r - w_eci differs from the round trip by
+// its rounding (<= 4 ulp of |v|, i.e. 1e-15 of the force), identically in the centre and in every perturbed evaluation.
+#ifndef GEL_AERO_ROTATE
+#define GEL_AERO_ROTATE 0
+#endif
 GEL_DEV void aero_force(const double r[3], const double v[3], double rho, double inv_a_sound, const EarthAngle& e,
                         const double w[3], double area, const Tables& tb, double F[3], Bracket* br = nullptr) {
-  // vel_eci2ecef: src/Coordinate.cpp:69-73 (omega x r = (-w y, w x, 0)), then ecef2eci (:41-49), minus wind
+  // omega x r = (-w y, w x, 0)
   const double d0 = v[0] + kOmega * r[1];
   const double d1 = v[1] - kOmega * r[0];
+#if GEL_AERO_ROTATE
   const double e0 = d0 * e.c + d1 * e.s;
   const double e1 = -d0 * e.s + d1 * e.c;
   const double a0 = (e0 * e.c - e1 * e.s) - w[0];
   const double a1 = (e0 * e.s + e1 * e.c) - w[1];
+#else
+  const double a0 = d0 - w[0];
+  const double a1 = d1 - w[1];
+#endif
   const double a2 = v[2] - w[2];
   // a vehicle at rest in the air (vn = 0) is a legitimate input: clamp below anything physical so that
   // fsqrt stays defined; the force is k * (-a) = 0 either way

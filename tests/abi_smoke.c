@@ -36,8 +36,9 @@ int main(int argc, char** argv) {
   CHECK(gel_problem_dims(p, &dm) == GEL_OK);
   CHECK(dm.S == 2 && dm.N == 75 && dm.M == 77 && dm.num_vars == 11 * 77 + 2 * 75 + 3);
   /* distinct x-dependent values: phase 0 air + hold = 39 per node (the tf column of vel / t is the negative of its t0 column:
-     closed form, gel_eval_kernel.h), phase 1 NoAir + free = 50 per node, + 1 scalar per phase */
-  CHECK(dm.num_var_entries == 39 * 5 + 1 + 50 * 70 + 1);
+     closed form, gel_eval_kernel.h), phase 1 NoAir + free = 30 + 10 per node (quaternion kinematics in closed form: six values
+     and the t0 column instead of twenty), + 1 scalar per phase */
+  CHECK(dm.num_var_entries == 39 * 5 + 1 + 40 * 70 + 1);
   CHECK(dm.stored_bytes == 8 * ((int64_t)11 * 75 + dm.num_var_entries));
   /* SURVEY.md 8(d) A_min: every x-dependent value the reference computes: 48 resp. 71 per node */
   CHECK(dm.algorithmic_bytes == 8 * ((int64_t)dm.num_vars + 11 * 75 + 48 * 5 + 71 * 70));
