@@ -26,6 +26,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_FLOP_PER_CYCLE = 256 * 4 * 16 * 2   # CUs x SIMDs x fp64 FMA lanes x 2 (half the fp32 vector rate of that guide: 157.3 TF at 2.4 GHz)
+FP64_SPEC_CLOCK_GHZ = 2.4
 
 
 def launcher_command(n_gpus, argv, port=None):
@@ -258,29 +260,28 @@ def main():
         barrier()
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) / K
 
-    # (1) COLD figure: W warm-up steps from an idle GPU, then K timed steps -- what a short burst sees.
+    # (1) `value`: exactly the contract -- W untimed warm-up steps, then K timed steps.  From an idle GPU these sit inside the
+    # chip's start-up power transient (tools/launch_series.py: first launch fast, a dip ~3 ms later, steady after ~40 ms).
     for _ in range(W):
         step()
     torch.cuda.synchronize()
-    elapsed_cold, kern_ms_cold = timed(K)
-    # (2) SETTLED figure (`value`): from idle the chip's power management overshoots -- tools/launch_series.py:
-    # 1.36 ms for the first launch, 1.70 ms 3 ms later, back to 1.30 ms after ~40 ms -- so the W + K launches
-    # above sit mostly inside that transient.  A batch workload lives in the steady state; ~0.25 s of untimed
-    # launches get there (same count on every rank), then W warm-up steps again, then exactly K timed steps.
-    n_settle = 0 if a.settle_ms <= 0 else min(5000, max(10, int(a.settle_ms / 1.3 * 16384 / B)))
+    elapsed, kern_ms = timed(K)
+    # (2) `value_settled`, informational: the same K steps after ~0.25 s of untimed launches (same count on every rank) and W
+    # warm-up steps again -- the steady state a batch workload lives in.
+    n_settle = 0 if a.settle_ms <= 0 else min(5000, max(10, int(a.settle_ms / 1.0 * 16384 / B)))
     for _ in range(n_settle):
         step()
     torch.cuda.synchronize()
     for _ in range(W):
         step()
     torch.cuda.synchronize()
-    elapsed, kern_ms = timed(K)
+    elapsed_settled, kern_ms_settled = timed(K)
     status = E.sync(stream)
 
-    tmax = torch.tensor([elapsed, elapsed_cold], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed, elapsed_settled], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    T, T_cold = float(tmax[0].item()), float(tmax[1].item())
+    T, T_settled = float(tmax[0].item()), float(tmax[1].item())
 
     if rank != 0:
         if use_dist:
@@ -313,12 +314,12 @@ def main():
         "world_size": world, "collective_backend": ("nccl (RCCL over xGMI)" if use_dist else None),
         "ms_per_step": 1e3 * T / K, "ms_per_eval": 1e3 * T / (B * K), "higher_is_better": True,
         "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        # the same K steps timed right after the W warm-up steps from an idle GPU, i.e. inside the chip's
-        # start-up power transient; `value` is the settled figure (config.settle_launches_before_warmup)
-        "value_cold": evals / T_cold, "ms_per_step_cold": 1e3 * T_cold / K,
+        # informational: the same K steps in the settled power state (config.settle_launches_before_second_timing untimed
+        # launches + W warm-ups before them); `value` is the contract's W warm-ups + K timed steps from an idle GPU
+        "value_settled": evals / T_settled, "ms_per_step_settled": 1e3 * T_settled / K,
         "config": {"workload": a.workload + (" (residual only)" if a.residual_only else ""), "phases": int(S),
                    "nodes_per_phase": [int(n) for n in prob["num_nodes"]],
-                   "batch_per_gpu": B, "settle_launches_before_warmup": n_settle, "decision_vars": E.nvars, "residual_rows": E.nres,
+                   "batch_per_gpu": B, "settle_launches_before_second_timing": n_settle, "decision_vars": E.nvars, "residual_rows": E.nres,
                    "jacobian_values_per_eval": 0 if a.residual_only else E.V, "coo_nnz": E.total_nnz,
                    "parallelism": ("phase+column shards x%d + all-gather" if shard else "replicas x%d") % world,
                    "output": ("4 defect residuals, in HBM" if a.residual_only else
@@ -327,23 +328,50 @@ def main():
     }
     if not shard:
         # one launch = B evals on this rank; HIP events on the launch stream over the K timed launches
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        stored = 8 * E.nres if a.residual_only else E.stored_bytes
+        fp64 = None
+        fpath = os.path.join(ROOT, "profiles", "fp64_%s_B%d.json" % (wl_tag, B))
+        if os.path.exists(fpath):   # fp64 instruction counters + datapath occupancy of this command (tools/gpu_record.sh)
+            try:
+                f = json.load(open(fpath))
+                peak_tf = FP64_FLOP_PER_CYCLE * FP64_SPEC_CLOCK_GHZ / 1e3
+                fp64 = {"flops_per_launch": f["fp64_flops_per_launch"], "achieved": f["fp64_flops_per_launch"] / (kern_ms * 1e-3) / 1e12,
+                        "peak": peak_tf, "unit": "TFLOP/s", "frac": f["fp64_flops_per_launch"] / (kern_ms * 1e-3) / 1e12 / peak_tf,
+                        "peak_note": "256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 at the 2.4 GHz spec clock; vector fp64 and "
+                                     "v_mfma_f64 share that datapath (DESIGN.md 3.1)",
+                        # the datapath's occupancy in TIME (profiled pass): fp64 adds / multiplies, conversions, integer and move
+                        # instructions occupy issue slots without counting two flops per lane, so this, not `frac`, says how close
+                        # the kernel is to the pipe
+                        "pipe_busy": f.get("fp64_pipe_busy"), "valu_busy": f.get("valu_busy"), "mfma_busy": f.get("mfma_busy"),
+                        "valu_instructions_per_wave": f.get("valu_instructions_per_wave"), "clock_ghz_profiled": f.get("clock_ghz"),
+                        "source": "static: profiles/%s (rocprofv3 --pmc passes of this command; not re-measured in this run)" % os.path.basename(fpath)}
+            except Exception:
+                fp64 = None
+        hbm_real = None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # which limit binds, from the data: the share of the HBM peak the bytes that REALLY moved reach, against the share of
+        # time the fp64 datapath was occupied
+        bound = "hbm"
+        if fp64 is not None and fp64.get("pipe_busy") is not None and hbm_real is not None and fp64["pipe_busy"] > hbm_real:
+            bound = "mfma"
+        out["roofline"] = {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": None if traffic is None else
                            "static: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                            "(2*FETCH_SIZE + WRITE_SIZE)*1024; not re-measured in this run)" % os.path.basename(tpath),
                            "kernel": kname, "kernel_ms": kern_ms,
-                           "frac_cold": abytes / (kern_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_cold": kern_ms_cold,
+                           "frac_settled": abytes / (kern_ms_settled * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_settled": kern_ms_settled,
                            "algorithmic_bytes_per_eval": a_min, "algorithmic_bytes_per_launch": abytes,
                            # what one eval actually writes (residual + the DISTINCT x-dependent values; the gather map
                            # restores negated / shared / structurally constant entries) -- `achieved` uses SURVEY 8(d)'s
                            # A_min as the contract prescribes, `traffic` shows the bytes that really moved
-                           "stored_bytes_per_eval": 8 * E.nres if a.residual_only else E.stored_bytes,
-                           "note": "bound by the fp64 pipe (VALU + MFMA share it; ~80 % busy) together with the store stream it "
-                                   "overlaps imperfectly (the launch moves its bytes at ~70 % of the pure-write rate of this "
-                                   "pattern), at the clock the chip holds under both; see DESIGN.md 3.1"}
+                           "stored_bytes_per_eval": stored, "hbm_frac_of_bytes_moved": hbm_real,
+                           "fp64": fp64,
+                           "bound_note": "`achieved` / `peak` / `frac` are the HBM figures of SURVEY 8(d) (algorithmic bytes); `bound` names "
+                                         "the limit the counters show nearer: 'mfma' = the fp64 datapath that v_mfma_f64 and vector fp64 "
+                                         "share (fp64.pipe_busy) is busier than HBM is with the bytes that really move "
+                                         "(hbm_frac_of_bytes_moved); see DESIGN.md 3.1"}
     else:
-        out["shard"] = {"step_ms": kern_ms, "step_ms_cold": kern_ms_cold,
+        out["shard"] = {"step_ms": kern_ms, "step_ms_settled": kern_ms_settled,
                         "units_per_rank": [c for _, c in shards.ranges],
                         "all_gather_bytes_received_per_rank_per_step": shards.bytes_received_per_vector() * B,
                         "note": "one step = this rank's unit range (split-form kernel) + one all-gather of the owned "
@@ -365,6 +393,9 @@ def main():
             ms = s.elapsed_time(e) / 5
             out["full_coo_expand"] = {"batch": Bf, "kernel_ms": ms,
                                       "write_GBps": Bf * E.total_nnz * 8 / (ms * 1e-3) / 1e9,
+                                      # expand_kernel: reads the compact values once, writes every COO value once
+                                      "algorithmic_bytes_per_launch": 8 * (E.V + E.total_nnz) * Bf,
+                                      "hbm_frac": 8 * (E.V + E.total_nnz) * Bf / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "evals_per_s_fused_plus_expand": Bf / ((kern_ms * Bf / B + ms) * 1e-3)}
             del dfull
         except Exception as ex:  # noqa: BLE001
@@ -431,7 +462,12 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 20
+            grads = sum(sum(d[1]) for d in dims)
             out["aero_constraints"] = {"rows": rows, "b1_ms_3_kinds": 1e3 * b1, "batch": Ba,
+                                       # aero_kernel: reads x once, writes the rows and their gradient values once (compute-bound:
+                                       # six runs of the atmosphere chain per constrained node; profiles/r03/others)
+                                       "algorithmic_bytes_per_launch": 8 * (E.nvars + rows + grads) * Ba,
+                                       "hbm_frac": 8 * (E.nvars + rows + grads) * Ba / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "host_buffers_vectors_per_s": Ba / dtb,
                                        "device_resident_vectors_per_s": Ba / (ms * 1e-3), "device_kernel_ms": ms}
             del dcon, djac

@@ -147,7 +147,9 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
 #endif
   const int park_off = P.park_off;
   // the cooperative forms meet at a barrier (operand image / hand-over) before any table lookup: no barrier of its own
-  const Tables tb = stage_tables(P, lds, !(MFMA && !SPLIT));
+  constexpr bool kSplitStage = MFMA && !SPLIT;   // cooperative forms: table entry requested now, written before their first barrier
+  const double tab_mine = kSplitStage ? stage_tables_issue(P) : 0.0;
+  const Tables tb = kSplitStage ? table_view(lds, P.Kw, P.Kc) : stage_tables(P, lds, true);
   const int lane = threadIdx.x & 63;
   // explicit LDS address space: ds_read/ds_write (lgkmcnt), never flat_* (which also ticks vmcnt)
   typedef __attribute__((address_space(3))) double lds_double;
@@ -385,6 +387,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
           for (int ks = 0; ks < 9; ks++) a_all[ks] = ap[min(ks, ksteps - 1) * 256];
         }
 #endif
+        stage_tables_commit(P, lds, tab_mine);
         __syncthreads();
         GEL_STAMP_AT(2);
 #if GEL_PACK_A_PRELOAD
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         GEL_PIPE_LOAD(0);
         double a = ap[0];
         GEL_PIPE_WRITE(0);
+        stage_tables_commit(P, lds, tab_mine);
         __syncthreads();
         for (int sl = 0; sl < nslab; sl++) {
           const int bo = (sl & 1) * kPipeBuf;
@@ -613,6 +617,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
           }
         }
 #undef GEL_DX_LOAD
+        stage_tables_commit(P, lds, tab_mine);
         // hand-over: the rows of vector vb go to wavefront vb's own region ([node][11] behind its early park slots)
         lds_double* wg_lds = (lds_double*)lds + park_off + kHO;
 #pragma unroll
@@ -850,11 +855,21 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
     const double inv_m = frcp(me * P.um);
 
     if (ph.air) {
-      EarthHalf eh;   // position sweeps do not change the Earth angle; only its half-angle pair is kept (full_angle())
-      {
-        const EarthAngle e0 = earth_angle(tn);
-        eh.ch = e0.ch; eh.sh = e0.sh;
-      }
+      // The Earth angle omega t enters the RHS only through the rotation of the wind into ECI (the air-relative velocity's two
+      // rotations cancel, aero_force()): a wavefront in calm air -- both wind components exactly zero in every lane, e.g. above
+      // and below the measured part of the wind table -- never needs it.  It is formed on first need (wave-uniform), its
+      // half-angle pair kept (full_angle()); position sweeps do not change it.
+      EarthHalf eh{1.0, 0.0};
+      bool have_eh = false;
+      // the node's time once more, for the rare late first need (a load behind the stores: it waits for them)
+#define GEL_NEED_EARTH_ANGLE(wn_, we_)                                                                                 \
+  do {                                                                                                                 \
+    if (!have_eh && __builtin_amdgcn_ballot_w64(!((wn_) == 0.0 && (we_) == 0.0)) != 0) {                                \
+      const double tau_ = P.tau[ph.toff + jc];                                                                         \
+      const EarthAngle e_ = earth_angle(tau_ * (tf - to) / 2 + (tf + to) / 2);                                         \
+      eh.ch = e_.ch; eh.sh = e_.sh; have_eh = true;                                                                    \
+    }                                                                                                                  \
+  } while (0)
       // Order of this branch (register and park discipline; the kernel runs 4 waves/SIMD on 128 VGPRs and a spilled value
       // would be reloaded through vmcnt, i.e. behind every Jacobian store in flight):
       // (1) the centre evaluation; the intermediates of its position part that the position sweeps will need (PosCentre) go to
@@ -883,10 +898,14 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
       {
         PosPart pp;
         double v[3], w[3], F[3], dir[3];
-        const EarthAngle ea = full_angle(eh);
         const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
         if (JAC) pp = pos_part<true, ParkSink>(r, tb, P.barC20, nullptr, ParkSink{park}, &pt);
         else pp = pos_part(r, tb, P.barC20);
+        if (__builtin_amdgcn_ballot_w64(!(pp.wn == 0.0 && pp.we == 0.0)) != 0) {   // tn is still in registers here
+          const EarthAngle e0 = earth_angle(tn);
+          eh.ch = e0.ch; eh.sh = e0.sh; have_eh = true;
+        }
+        const EarthAngle ea = full_angle(eh);
         wind_eci_or_calm(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] = PARK_GET(PK_V0 + c) * P.uv;
@@ -986,6 +1005,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
 #define GEL_POS_SWEEP_TAIL(kk, rp, pq)                                                                        \
   do {                                                                                                        \
     double wq_[3], Fp_[3], f_[3];                                                                             \
+    GEL_NEED_EARTH_ANGLE((pq).wn, (pq).we);                                                                   \
     const EarthAngle ea = full_angle(eh);                                                                     \
     wind_eci_or_calm(rp, ea, (pq).shp, (pq).chp, (pq).inv_p, (pq).wn, (pq).we, wq_);                          \
     const double vq_[3] = {PARK_GET(PK_V0) * P.uv, PARK_GET(PK_V1) * P.uv, PARK_GET(PK_V2) * P.uv};           \
@@ -1055,6 +1075,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
         }
 #endif
 #undef GEL_LOAD_POS_CENTRE
+#undef GEL_NEED_EARTH_ANGLE
 #undef GEL_POS_SWEEP_TAIL
       }
 #endif

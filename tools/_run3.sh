@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-SCAN_B=16384 timeout 900 tools/run_variants.sh "mixed-6x64 dense-6x64" main pf512 pf1024 pf2048 2>&1 | grep -v "jac=0" | tail -40
-GELATO_AMD_LIB=$GRAFT_REPO_ROOT/build/variants/libgel_stamp_pf.so timeout 300 python3 tools/stamp_phases.py mixed-6x64 16384 2>&1 | tail -9
+RES_ONLY=1 GELATO_AMD_LIB=$GRAFT_REPO_ROOT/build/variants/libgel_stamp.so timeout 300 python3 tools/stamp_phases.py 3x32 65536 2>&1 | tail -9
+RES_ONLY=1 GELATO_AMD_LIB=$GRAFT_REPO_ROOT/build/variants/libgel_stamp.so timeout 300 python3 tools/stamp_phases.py mixed-6x64 16384 2>&1 | tail -9
+GELATO_AMD_LIB=$GRAFT_REPO_ROOT/build/variants/libgel_stamp.so timeout 300 python3 tools/stamp_phases.py stress-12x128 4096 2>&1 | tail -9
+tools/pmc_kernels.sh "--workload 3x32 --residual-only --batch 65536" 2>&1 | grep -A30 "== eval_kernel" | head -34

@@ -14,5 +14,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-extras "$@" > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
 done
 python3 $R/tools/pmc_traffic.py $OUT "$@" > $OUT/traffic.json
-rm -rf $OUT/prof $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
-echo "== $TAG"; cat $OUT/bench.json; tail -1 $OUT/bench.err; head -4 $OUT/kernel_stats.csv; cat $OUT/traffic.json
+# fp64 work and datapath occupancy (the roofline that binds when the store stream does not): instruction counters; cycles + busy counters
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_F64 --output-format csv -d $OUT/pmc_fp64a -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-extras "$@" > /dev/null 2> $OUT/pmc_fp64a.err
+timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_fp64b -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-extras "$@" > /dev/null 2> $OUT/pmc_fp64b.err
+python3 $R/tools/pmc_fp64.py $OUT "$@" > $OUT/fp64.json
+rm -rf $OUT/prof $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_fp64a $OUT/pmc_fp64b
+echo "== $TAG"; cat $OUT/bench.json; tail -1 $OUT/bench.err; head -4 $OUT/kernel_stats.csv; cat $OUT/traffic.json $OUT/fp64.json
