@@ -61,6 +61,7 @@ class _State:
         self._pinned = None
         self._pinned_x = None
         self._pinned_cond = None
+        self._pinned_user = None
 
     def frame(self, xdict, need_jac):
         """All device outputs for `xdict`: the first function of a callback that asks evaluates the four defect groups,
@@ -124,6 +125,12 @@ def begin_callback(pdict, xdict):
     if st is not None:
         st.status = 0
         st._pinned, st._pinned_x, st._pinned_cond = xdict, None, None
+        st._pinned_user = None
+        # the user module's device rows are registered BEFORE the first function of the callback asks for the row table
+        # (equality_init comes before equality_user in objfunc): a table pinned without them would hand equality_user the
+        # rows of another group
+        from . import con_user
+        con_user._device_rows(pdict)
 
 
 def end_callback(pdict):
@@ -132,6 +139,7 @@ def end_callback(pdict):
     if st is None:
         return 0
     st._pinned, st._pinned_x, st._pinned_cond = None, None, None
+    st._pinned_user = None
     return st.status
 
 

@@ -153,6 +153,13 @@ class _Rows:
                 r = len(lin) - k0
                 lin.append((o["mass"] + ig, -1.0, o["mass"] + co, 1.0, d_mass / unitdict["mass"]))
                 rows += [r, r]; cols += [ig, co]; vals += [-1.0, 1.0]
+            else:
+                # the reference looks the two events up by name and raises IndexError when one is missing
+                # (lib/con_trajectory.py:40-49); the cut-down event lists of the synthetic bench meshes lack some on purpose,
+                # so the stage's row is left out here -- but never silently
+                import warnings
+                warnings.warn("inequality_mass: stage without its ignition_at / cutoff_at events (%r, %r) in the event list: "
+                              "no propellant limit row for it" % (stage.get("ignition_at"), stage.get("cutoff_at")), stacklevel=2)
         self.slices["imass"] = (k0, len(lin))
         self.jac["imass"] = {"mass": _coo(rows, cols, vals, (len(lin) - k0, M))}
         # inequality_kickturn (:106-125): the pitch rate of a kick-turn section is not positive; Jacobian :128-160
@@ -242,8 +249,11 @@ class _Rows:
 def rows_of(pdict, unitdict, condition):
     """The (cached) row table of this problem; rebuilt when the terminal targets or the user rows change."""
     st = con_dynamics._state(pdict, unitdict)
-    if st._pinned_cond is condition and st.__dict__.get("rows") is not None:
-        return st.rows[1]           # inside begin_callback() .. end_callback(): the key was checked once for this callback
+    if (st._pinned_cond is condition and st.__dict__.get("rows") is not None
+            and pdict.get("gelato_amd_user_rows") is st.__dict__.get("_pinned_user")):
+        # inside begin_callback() .. end_callback(): the key was checked once for this callback -- and the user rows are still
+        # the very tuple it was checked with (con_user._device_rows replaces the tuple object whenever the rows change)
+        return st.rows[1]
     user = tuple(tuple(r) for r in (pdict.get("gelato_amd_user_rows") or ()))
     key = (id(condition), condition["OptimizationMode"], tuple(condition.get(k) for k in (
         "altitude_perigee", "altitude_apogee", "inclination", "radius", "vel_tangential_geocentric",
@@ -254,6 +264,7 @@ def rows_of(pdict, unitdict, condition):
         st.rows = (key, _Rows(pdict, unitdict, condition, user))
     if st._pinned is not None:
         st._pinned_cond = condition
+        st._pinned_user = pdict.get("gelato_amd_user_rows")
     return st.rows[1]
 
 

@@ -1522,6 +1522,10 @@ int gel_initial_guess(const gel_problem* p, int32_t nref, const double* t_ref, c
     }
   }
   for (int i = 0; i <= S; i++) xt[i] = knot_times[i] / p->ut;
+  // a node time beyond a reference table that ends (or starts) with a repeated time extrapolates over a zero-width interval
+  // (scipy does the same and returns NaN / Inf silently): report it
+  for (int64_t i = 0; i < p->dims.num_vars; i++)
+    if (!std::isfinite(x[i])) return GEL_NONFINITE;
   return GEL_OK;
 }
 
@@ -1581,8 +1585,8 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
 }
 
 int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux, int32_t aux_rows, double* out) {
-  static const int nin[11] = {1, 3, 3, 6, 7, 1, 1, 2, 2, 8, 8}, nout[11] = {5, 3, 3, 3, 3, 3, 1, 4, 6, 8, 16};
-  if (kind < 0 || kind > 10 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
+  static const int nin[14] = {1, 3, 3, 6, 7, 1, 1, 2, 2, 8, 8, 8, 7, 4}, nout[14] = {5, 3, 3, 3, 3, 3, 1, 4, 6, 8, 16, 4, 3, 7};
+  if (kind < 0 || kind > 13 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
   if (n == 0) return GEL_OK;
   int rc = need_device();
   if (rc) return rc;

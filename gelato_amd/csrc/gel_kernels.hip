@@ -218,10 +218,11 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       out[5 * i] = h; out[5 * i + 1] = a.T; out[5 * i + 2] = a.P; out[5 * i + 3] = a.rho; out[5 * i + 4] = a.a;
     } break;
     case 1: {
-      // latitude and altitude exactly as pos_part forms them; angles reported in degrees
+      // latitude / longitude in degrees (atan2, as the reference reports them); the altitude exactly as pos_part forms it
+      // (from the algebraic sine / cosine pair of the latitude)
       double lat, sl, cl, p, ip;
       geodetic_lat_p(in[3 * i], in[3 * i + 1], in[3 * i + 2], lat, p, ip);
-      fsincos(lat, &sl, &cl);
+      geodetic_sincos_p(in[3 * i], in[3 * i + 1], in[3 * i + 2], sl, cl, p, ip);
       const double lon = atan2(in[3 * i + 1], in[3 * i]);
       out[3 * i] = lat * 180.0 / kPi; out[3 * i + 1] = lon * 180.0 / kPi;
       out[3 * i + 2] = geodetic_alt_from(p, sl, cl);
@@ -236,9 +237,8 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       // wind vector NED -> ECI exactly as the hot path does it: in = pos[3], t, wn, we
       const double* a = in + 6 * i;
       const double r[3] = {a[0], a[1], a[2]};
-      double lat, sl, cl, p, ip, w[3];
-      geodetic_lat_p(r[0], r[1], r[2], lat, p, ip);
-      fsincos(lat, &sl, &cl);
+      double sl, cl, p, ip, w[3];
+      geodetic_sincos_p(r[0], r[1], r[2], sl, cl, p, ip);
       const EarthAngle ea = earth_angle(a[3]);
       double chp, irt;
       fsqrt_rsqrt(0.5 * (1.0 + cl), chp, irt);
@@ -282,6 +282,23 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
         wind_ned2_cached(in[8 * i + k], lds, lds + 3 * aux_rows, aux_rows, wn, we, br);
         out[16 * i + 2 * k] = wn; out[16 * i + 2 * k + 1] = we;
       }
+    } break;
+    case 11: {  // quatmult (src/wrapper_coordinate.hpp:50-57): in = q[4], p[4]
+      double o[4];
+      quatmult(in + 8 * i, in + 8 * i + 4, o);
+      for (int c = 0; c < 4; c++) out[4 * i + c] = o[c];
+    } break;
+    case 12: {  // quatrot (:70-78) = vec(conj(q) (0, v) q): in = q[4], v[3]
+      double o[3];
+      quatrot(in + 7 * i, in + 7 * i + 4, o);
+      for (int c = 0; c < 3; c++) out[3 * i + c] = o[c];
+    } break;
+    case 13: {  // conj (:59-61) and the thrust direction quatrot(conj(q), (1, 0, 0)) the hot path forms without the zero terms: in = q[4]
+      const double* q = in + 4 * i;
+      out[7 * i] = q[0]; out[7 * i + 1] = -q[1]; out[7 * i + 2] = -q[2]; out[7 * i + 3] = -q[3];
+      double d[3];
+      thrust_dir(q, d);
+      for (int c = 0; c < 3; c++) out[7 * i + 4 + c] = d[c];
     } break;
     default: break;
   }

@@ -70,6 +70,13 @@ def make_callbacks(pdict, unitdict, condition):
 
     def objfunc(xdict):
         con_dynamics.begin_callback(pdict, xdict)    # sticky status over ALL device evaluations of this callback; xdict pinned
+        try:
+            return _objfunc(xdict)
+        except BaseException:
+            con_dynamics.end_callback(pdict)         # never leave the dict pinned: a later direct con_* call must see a fresh x
+            raise
+
+    def _objfunc(xdict):
         funcs = {"obj": cost_6DoF(xdict, condition)}
         if rows:  # Trajectory_Optimization.py:197-198,212-216,220,233,241
             funcs["eqcon_init"] = con_a.equality_init(xdict, pdict, unitdict, condition)
@@ -99,6 +106,13 @@ def make_callbacks(pdict, unitdict, condition):
 
     def sens(xdict, funcs):
         con_dynamics.begin_callback(pdict, xdict)
+        try:
+            return _sens(xdict, funcs)
+        except BaseException:
+            con_dynamics.end_callback(pdict)
+            raise
+
+    def _sens(xdict, funcs):
         fs = {"obj": cost_jac(xdict, condition)}
         if rows:  # Trajectory_Optimization.py:248-249,264-269,279-281,297-299,309-311
             fs["eqcon_init"] = con_a.equality_jac_init(xdict, pdict, unitdict, condition)

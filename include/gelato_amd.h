@@ -306,6 +306,10 @@ int gel_dynamics_quaternion(int32_t n, const double* quat_eci2body, const double
  *  kind 9: 8 abscissae     -> kind 6 of each, looked up one after the other through the table interval kept from the
  *                           previous lookup (what the fused kernel does across a node's sweeps)   in [n][8]  out [n][8]
  *  kind 10: 8 altitudes    -> kind 5 (wn, we) of each, likewise                                    in [n][8]  out [n][16]
+ *  kind 11: (q, p)       -> quatmult(q, p)                      in [n][8]   out [n][4]  (src/wrapper_coordinate.hpp:50-57)
+ *  kind 12: (q, v)       -> quatrot(q, v) = vec(conj(q) (0, v) q)  in [n][7]  out [n][3]  (:70-78)
+ *  kind 13: q            -> [conj(q), thrust direction quatrot(conj(q), (1, 0, 0))]  in [n][4]  out [n][7]  (:59-61,
+ *           src/pybind_dynamics.cpp:62-63)
  */
 int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux, int32_t aux_rows, double* out);
 

@@ -193,6 +193,45 @@ def test_callbacks_carry_every_row_group_and_a_sticky_status():
         con_user.set_user_module(None)
 
 
+def test_user_rows_registered_after_the_state_exists():
+    """The state (engine, row table) of a pdict created BEFORE the user module is known -- a direct con_* call or engine_of()
+    ahead of make_callbacks -- must not make the first pinned callback hand equality_user the rows of another group: the user
+    rows are registered before the callback's first look at the row table, and a table pinned for one tuple of user rows is not
+    handed out for another."""
+    from gelato_amd import con_dynamics, con_user, driver
+    from gelato_amd import con_init_terminal_knot as ck
+    from gelato_amd.examples import user_constraints as uc
+    pdict, unitdict, condition, xdict = example()
+    con_user.set_user_module(None)
+    try:
+        con_dynamics.engine_of(pdict, unitdict)                       # the state exists ...
+        ck.equality_init(xdict, pdict, unitdict, condition)           # ... and so does a row table WITHOUT user rows
+        assert ck.rows_of(pdict, unitdict, condition).user_rows == []
+        con_user.set_user_module(uc)                                  # only now the user module is set
+        objfunc, sens = driver.make_callbacks(pdict, unitdict, condition)
+        funcs, fail = objfunc(xdict)
+        assert not fail
+        # the reference value of the shipped user constraint (periapsis radius at IIP_END), from a fresh problem
+        p2, u2, c2, x2 = example()
+        want = con_user.equality_user(x2, p2, u2, c2)
+        assert np.array_equal(np.asarray(funcs["eqcon_user"]), np.asarray(want))
+        assert len(ck.rows_of(pdict, unitdict, condition).user_rows) == 1
+        fs, fail = sens(xdict, funcs)
+        assert not fail and fs["eqcon_user"]["position"].shape[0] == 1
+        # switching the module between runs on the same pdict
+        con_user.set_user_module(None)
+        funcs, _ = objfunc(xdict)
+        assert funcs["eqcon_user"] is None
+        # an exception inside a callback does not leave xdict pinned
+        bad = dict(xdict)
+        del bad["u"]
+        with pytest.raises(KeyError):
+            objfunc(bad)
+        assert pdict["_gelato_amd"]._pinned is None
+    finally:
+        con_user.set_user_module(None)
+
+
 def test_one_round_trip_callback_equals_the_separate_calls():
     """gel_eval_callback: defect groups + row table + aero kinds of one decision vector, launched back to back, one
     synchronise -- every output bit for bit what the separate entry points return; configuring a kind or the row
