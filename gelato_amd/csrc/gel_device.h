@@ -74,6 +74,7 @@ struct ProblemDev {
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
   int32_t unit0, nunits;     // split form only: first unit and number of units (unit = 4 * work item + part)
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)
+  int32_t vmajor;            // cooperative launches in vector-group major, XCD-aware order (every phase one chunk)
   int32_t fd_recompute;      // GEL_FLAG_FD_RECOMPUTE: every finite-difference sweep re-runs the reference's chain
   const int4* chunks;        // [nchunks] {phase, first node of the chunk, offset of its MFMA-ordered D in Dsw / 4,
                              //  (position in the run of this phase's chunks) << 16 | chunks of the phase in the list}:

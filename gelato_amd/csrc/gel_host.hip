@@ -844,6 +844,12 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     dv.pack = (nmax <= 32) && !(d->flags & GEL_FLAG_NO_PACK);
   }
   dv.fd_recompute = p->fd_recompute ? 1 : 0;
+  {
+    int nmax = 0;
+    for (int i = 0; i < S; i++) nmax = std::max(nmax, p->ph[i].n);
+    // measured (same box): 3 x 32 +4 % (fused and residual-only), 6 x 64 -1..2 %: only the small-phase meshes, whose rows share most lines
+    dv.vmajor = (nmax <= 32 && !(d->flags & GEL_FLAG_ITEM_MAJOR)) ? 1 : 0;
+  }
   dv.um = p->um; dv.up = p->up; dv.uv = p->uv; dv.uu = p->uu; dv.ut = p->ut; dv.dx = p->dx; dv.barC20 = p->barC20;
   *out = p;
   return GEL_OK;

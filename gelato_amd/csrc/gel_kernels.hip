@@ -880,7 +880,9 @@ EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
 
 template <bool JAC, bool PACK>
 static void launch_coop(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
-  const unsigned grid = (unsigned)P.nchunks * (unsigned)((B + (PACK ? 7 : 3)) / (PACK ? 8 : 4));
+  const unsigned nb = (unsigned)((B + (PACK ? 7 : 3)) / (PACK ? 8 : 4));
+  // vector-group major order deals the groups to the eight XCDs in blocks of eight (short last block: idle workgroups leave at once)
+  const unsigned grid = P.vmajor ? (unsigned)P.nchunks * 8u * ((nb + 7u) / 8u) : (unsigned)P.nchunks * nb;
   const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(JAC, true, PACK) * (kBlock / 64));
   hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
 }

@@ -60,6 +60,8 @@ extern "C" {
 #define GEL_FLAG_DX_VALU 2 /* force wavefront dot-products (VALU FMAs) */
 #define GEL_FLAG_NO_PACK 4 /* matrix-pipe form of a problem whose phases all have <= 32 nodes: one decision vector per
                               wavefront (32 idle lanes) instead of two -- for A/B measurements and parity tests */
+#define GEL_FLAG_ITEM_MAJOR 16 /* cooperative launches in work-item major order also when every phase has at most 32 nodes (the default there is
+                              vector-group major, XCD-aware: see gel_eval_kernel.h) -- for A/B measurements */
 #define GEL_FLAG_FD_RECOMPUTE 8 /* every finite-difference sweep re-runs the reference's chain on the perturbed input
                               (lib/con_dynamics.py:381-400,452-480), as rounds 1-2 did.  Default (flag clear): the three position
                               sweeps form the CHANGE of altitude / atmosphere / wind from algebraic difference identities of the
