@@ -56,9 +56,10 @@ static_assert(kWaveLds - kCoopStageOff >= 64 * 11, "the cooperative hand-over ar
 // then, once the wavefront has taken its rows, the park over that -- 6 KB instead of 9.5 KB per wavefront.
 constexpr int kSlabRowsMax = 68, kPackRows = 36, kParkRes = (PK_LV2 + 1) * 64;
 constexpr int kPipeSlabK = 11;   // k-steps per double-buffered slab of the long-phase form (44 state rows)
-constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack) {
-  return jac ? kWaveLds : (!mfma ? kParkRes : (pack ? 2 * kPackRows * 11 : (GEL_XLDS_PIPE ? 2 * 4 * kPipeSlabK * 11 : kSlabRowsMax * 11)));
+constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack, bool split = false) {
+  return jac ? kWaveLds : (!mfma ? kParkRes : (split ? 64 * kStageLd /* one wavefront's own result tile */ : (pack ? 2 * kPackRows * 11 : (GEL_XLDS_PIPE ? 2 * 4 * kPipeSlabK * 11 : kSlabRowsMax * 11))));
 }
+static_assert(wave_lds_doubles(false, true, false, true) >= kParkRes, "residual-only split form: park over the result tile");
 static_assert(wave_lds_doubles(false, true, true) >= 64 * 11 && wave_lds_doubles(false, true, false) >= 64 * 11, "hand-over area");
 static_assert(wave_lds_doubles(false, true, true) >= kParkRes && wave_lds_doubles(false, true, false) >= kParkRes, "residual-only park");
 
@@ -126,12 +127,15 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 // the atmosphere/geodesy chain instead of four plus the light sweeps.  Same expressions, same bits.
 // PACK (cooperative form, every phase of the problem at most 32 nodes): a wavefront carries TWO decision vectors, one
 // per 32-lane half, and a workgroup eight -- otherwise half of the lanes (and two of the four D.X row tiles) idle.
+// The body is a device function of a (virtual) workgroup index: eval_kernel runs it for every workgroup of a launch,
+// callback_kernel (gel_kernels.hip) for the first workgroups of the one launch that serves a whole callback.  In the forms
+// that are not cooperative a workgroup may have any number of wavefronts (each its own work item).
 template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false>
-__global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : GEL_MIN_WAVES_PER_SIMD) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
-                                                      double* __restrict__ res, double* __restrict__ jvar) {
+__device__ __forceinline__ void eval_body(const ProblemDev& P, int B, const double* __restrict__ x, double* __restrict__ res,
+                                          double* __restrict__ jvar, const unsigned vblk) {
   extern __shared__ double lds[];
 #ifdef GEL_STAMP  // diagnostic build only (tools/stamp_phases.py): where a wavefront's lifetime goes, in shader cycles
-#define GEL_STAMP_AT(i) do { if ((threadIdx.x & 63) == 0) gel_stamps[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) & ((1u << 18) - 1)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GEL_STAMP_AT(i) do { if ((threadIdx.x & 63) == 0) gel_stamps[(((size_t)vblk * 4 + (threadIdx.x >> 6)) & ((1u << 18) - 1)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define GEL_STAMP_AT(i) do {} while (0)
 #endif
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   const int lane = threadIdx.x & 63;
   // explicit LDS address space: ds_read/ds_write (lgkmcnt), never flat_* (which also ticks vmcnt)
   typedef __attribute__((address_space(3))) double lds_double;
-  constexpr int kWL = wave_lds_doubles(JAC, MFMA, PACK);   // this instantiation's region per wavefront
+  constexpr int kWL = wave_lds_doubles(JAC, MFMA, PACK, SPLIT);   // this instantiation's region per wavefront
   constexpr int kHO = JAC ? kCoopStageOff : 0;             // where the cooperative hand-over area starts in it
   static_assert(!(MFMA && !SPLIT) || kWL - kHO >= 64 * 11, "the cooperative hand-over area must fit the region");
   lds_double* wave_lds = (lds_double*)lds + park_off + (threadIdx.x >> 6) * kWL;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int half = PACK ? (lane >> 5) : 0;
   const int nb4 = (B + kVecWg - 1) / kVecWg;  // COOP: workgroups per work item
-  const long long item = COOP ? 0 : __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * kBlock + threadIdx.x) >> 6));
+  const long long item = COOP ? 0 : __builtin_amdgcn_readfirstlane((int)(((long long)vblk * blockDim.x + threadIdx.x) >> 6));
   if (!COOP && item >= (long long)B * (SPLIT ? P.nunits : P.nchunks)) return;
   // work-item major: all B vectors of one (phase, chunk) are neighbours, so the four wavefronts of a
   // workgroup cost the same (its LDS is only released when the slowest ends), and the list is ordered
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   // adjacent in dispatch order; phases of at most 64 nodes have one chunk and keep plain work-item major order.
   int q, b0;
   if (COOP) {
-    const unsigned p = blockIdx.x, nb = (unsigned)nb4;
+    const unsigned p = vblk, nb = (unsigned)nb4;
     unsigned it = p / nb, r = p - it * nb;
     if (P.vmajor) {
       // Vector-group major, XCD aware (meshes whose phases all have at most 32 nodes): the work items of ONE group of vectors run
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
   const int dsw = __builtin_amdgcn_readfirstlane(ck.z);  // first gel_double4 of this work item in Dsw
   const int j = PACK ? (lane & 31) : j0 + lane;  // node inside the phase (PACK: one chunk per phase, j0 = 0)
   const PhaseDev ph = load_phase(P.phases + sec);  // by value, in SGPRs, before any store
-  if (SPLIT && part && !ph.air) return;  // only aerodynamic phases have the long position sweeps
+  if (SPLIT && part && (!ph.air || !JAC)) return;  // only aerodynamic phases have the long position sweeps (and only with derivatives)
   const bool lead = !(SPLIT && part);     // the wavefront that owns everything but the split-off sweeps
   const int n = ph.n;
   // the matrix pipe reads all 64 lanes: lanes past the end of a ragged phase stay alive (with zero
@@ -1153,6 +1157,12 @@ __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES
 #undef PARK_SET
   GEL_STAMP_AT(7);
   if (bad) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
+}
+
+template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false>
+__global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : GEL_MIN_WAVES_PER_SIMD) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
+                                                      double* __restrict__ res, double* __restrict__ jvar) {
+  eval_body<JAC, MFMA, SPLIT, PACK>(P, B, x, res, jvar, blockIdx.x);
 }
 
 }  // namespace gel

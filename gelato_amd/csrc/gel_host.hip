@@ -370,6 +370,14 @@ int ensure_capacity(gel_problem* p, int B) {
   return GEL_OK;
 }
 
+// Wait for a short launch by polling: hipStreamSynchronize() sleeps on an interrupt and returns ~5 us after the kernel has
+// ended; on the one-vector latency path (tens of microseconds in all) the host spins instead.
+static hipError_t spin_wait(hipStream_t s) {
+  hipError_t q;
+  while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+  return q;
+}
+
 // run B evals from host x; leaves results in the pinned staging buffers
 int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_jac) {
   int rc = ensure_capacity(p, B);
@@ -385,7 +393,7 @@ int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_ja
     gel::ProblemDev dv = p->dev;
     dv.flag = p->h_flag;
     HIPCHK(gel::launch_eval(dv, B, p->h_x, want_res ? p->h_res : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(spin_wait(p->stream));
     if (*p->h_flag) { *p->h_flag = 0; return GEL_NONFINITE; }
     return GEL_OK;
   }
@@ -1555,26 +1563,34 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
   if (rows && (rc = grow(&p->h_rows, &p->h_rows_cap, R + 7 * nfn + 1, true))) return rc;
   if (aero && (rc = grow(&p->h_aero, &p->h_aero_cap, atotal, true))) return rc;
   std::memcpy(p->h_x, x, (size_t)p->dims.num_vars * 8);
-  // everything reads x from and writes to pinned host memory; launches go back to back on the handle's stream
+  // everything reads x from and writes to pinned host memory: no copy commands
   gel::ProblemDev dv = p->dev;
   dv.flag = p->h_flag;
   const bool want_jac = io->vals_full != nullptr;
-  if (io->res || want_jac)
-    HIPCHK(gel::launch_eval(dv, 1, p->h_x, (io->res || want_jac) ? p->h_res : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
-  if (rows)
-    HIPCHK(gel::launch_rows(dv, (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, 1, p->h_x, p->h_rows,
-                            io->rows_jfn ? p->h_rows + R : nullptr, p->stream));
+  const bool fused = io->res || want_jac;
   gel::AeroLaunchOut out;
-  if (aero) {
+  if (aero)
     for (int k = 0; k < 3; k++) {
       const size_t n = p->aero_rows[k].size();
       out.nrows[k] = (int32_t)n;
       out.con[k] = (io->aero_con[k] && n) ? p->h_aero + off_c[k] : nullptr;
       out.jac[k] = (out.con[k] && io->aero_jac[k]) ? p->h_aero + off_j[k] : nullptr;
     }
-    HIPCHK(gel::launch_aero(dv, (int)p->aero_nodes.size(), p->d_aero_nodes, 1, p->h_x, out, p->stream));
+  // GEL_CB_MODE=3 (measurement switch): the three launches of rounds 1-2, back to back on the handle's stream
+  static const int cb_mode = [] { const char* e = getenv("GEL_CB_MODE"); return e ? atoi(e) : 0; }();
+  if (cb_mode == 3 || !fused) {
+    if (fused) HIPCHK(gel::launch_eval(dv, 1, p->h_x, p->h_res, want_jac ? p->h_jv : nullptr, p->stream));
+    if (rows) HIPCHK(gel::launch_rows(dv, (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, 1, p->h_x, p->h_rows,
+                                      io->rows_jfn ? p->h_rows + R : nullptr, p->stream));
+    if (aero) HIPCHK(gel::launch_aero(dv, (int)p->aero_nodes.size(), p->d_aero_nodes, 1, p->h_x, out, p->stream));
+  } else {
+    // ONE launch: defect groups, aero kinds and row table as workgroup ranges of one grid (gel_kernels.hip callback_kernel)
+    HIPCHK(gel::launch_callback(dv, want_jac, p->h_x, p->h_res, want_jac ? p->h_jv : nullptr,
+                                aero ? (int)p->aero_nodes.size() : 0, p->d_aero_nodes, aero ? &out : nullptr,
+                                (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, rows ? p->h_rows : nullptr,
+                                (rows && io->rows_jfn) ? p->h_rows + R : nullptr, p->stream));
   }
-  HIPCHK(hipStreamSynchronize(p->stream));   // the ONE synchronise of the callback
+  HIPCHK(hipStreamSynchronize(p->stream));   // the ONE wait of the callback (a sleeping wait: polling hipStreamQuery measured slower)
   if (io->res) std::memcpy(io->res, p->h_res, (size_t)11 * p->dims.N * 8);
   if (want_jac) scatter_full(p, p->h_jv, io->vals_full, io->fill_constants);
   if (rows) {

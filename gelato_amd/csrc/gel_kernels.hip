@@ -369,14 +369,14 @@ struct AeroOut {
 // so every store of a gradient block is one contiguous segment (which is what lets the B = 1 callback write straight into
 // pinned host memory).
 constexpr int kAeroRoles = 6;
-__global__ __launch_bounds__(64 * kAeroRoles) void aero_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
-                                                                 int tiles, const double* __restrict__ x, AeroOut O) {
+__device__ __forceinline__ void aero_body(const ProblemDev& P, int nnodes, const AeroNodeDev* __restrict__ nodes, int tiles,
+                                          const double* __restrict__ x, const AeroOut& O, const unsigned vblk) {
   extern __shared__ double lds[];
   const Tables tb = stage_tables(P, lds);
   double* centre = lds + ((table_doubles(P.Kw, P.Kc) + 1) & ~1);   // [2][64]: alpha, q of the centre evaluation
   const int sw = (int)(threadIdx.x >> 6);              // 0 centre + light sweeps, 1..3 position, 4 t0, 5 tf
   const int lane = (int)(threadIdx.x & 63);
-  const int b = (int)(blockIdx.x / (unsigned)tiles), tile = (int)(blockIdx.x - (unsigned)b * (unsigned)tiles);
+  const int b = (int)(vblk / (unsigned)tiles), tile = (int)(vblk - (unsigned)b * (unsigned)tiles);
   const int ni_raw = tile * 64 + lane;
   const bool live = ni_raw < nnodes;
   const int ni = live ? ni_raw : nnodes - 1;
@@ -473,6 +473,11 @@ __global__ __launch_bounds__(64 * kAeroRoles) void aero_kernel(ProblemDev P, int
 #undef GEL_AERO_F
   }
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
+}
+
+__global__ __launch_bounds__(64 * kAeroRoles) void aero_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
+                                                                 int tiles, const double* __restrict__ x, AeroOut O) {
+  aero_body(P, nnodes, nodes, tiles, x, O, blockIdx.x);
 }
 
 hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
@@ -590,13 +595,13 @@ GEL_DEV double node_fn(int fn, const double r[3], const double v[3], double t, c
   return (fn == 5) ? a * (1.0 - e) : a * (1.0 + e);
 }
 
-__global__ void rows_kernel(ProblemDev P, int nlin, const LinRowDev* __restrict__ lin, int nfn,
-                            const FnRowDev* __restrict__ fr, int B, int lin_blocks, const double* __restrict__ x,
-                            double* __restrict__ con, double* __restrict__ jfn) {
+__device__ __forceinline__ void rows_body(const ProblemDev& P, int nlin, const LinRowDev* __restrict__ lin, int nfn,
+                                          const FnRowDev* __restrict__ fr, int B, int lin_blocks, const double* __restrict__ x,
+                                          double* __restrict__ con, double* __restrict__ jfn, const unsigned vblk) {
   const int R = nlin + nfn;
   double chk = 0.0;
-  if ((int)blockIdx.x < lin_blocks) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((int)vblk < lin_blocks) {
+    const long long t = (long long)vblk * blockDim.x + threadIdx.x;
     if (t >= (long long)B * nlin) return;
     const int b = (int)(t / nlin), r = (int)(t - (long long)b * nlin);
     const LinRowDev L = lin[r];
@@ -605,7 +610,7 @@ __global__ void rows_kernel(ProblemDev P, int nlin, const LinRowDev* __restrict_
     if (L.idx1 >= 0) s += L.coef1 * xb[L.idx1];
     chk = con[(size_t)b * R + r] = s + L.c0;
   } else {
-    const long long t = (long long)(blockIdx.x - lin_blocks) * blockDim.x + threadIdx.x;
+    const long long t = (long long)(vblk - lin_blocks) * blockDim.x + threadIdx.x;
     const long long grp = t >> 3;
     const int sw = (int)(t & 7);                       // 0 centre, 1..3 position xyz + dx, 4..6 velocity xyz + dx, 7 knot time + dx
     const bool live = grp < (long long)B * nfn;
@@ -642,6 +647,73 @@ __global__ void rows_kernel(ProblemDev P, int nlin, const LinRowDev* __restrict_
     }
   }
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
+}
+
+__global__ void rows_kernel(ProblemDev P, int nlin, const LinRowDev* __restrict__ lin, int nfn,
+                            const FnRowDev* __restrict__ fr, int B, int lin_blocks, const double* __restrict__ x,
+                            double* __restrict__ con, double* __restrict__ jfn) {
+  rows_body(P, nlin, lin, nfn, fr, B, lin_blocks, x, con, jfn, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// ONE launch for one callback of the optimiser (Trajectory_Optimization.py:194-312 at B = 1): the four defect groups in the
+// split latency form (its own wavefronts, one unit each), the aero path constraints and the row table, as workgroup
+// ranges of the same grid -- nothing waits for anything, so the three run side by side instead of one launch after the
+// other (three launches on one stream: 30 us of kernels back to back + two more launch latencies; three streams cost
+// more than they saved: 94 us against 65).  Same device functions, same bits as the separate launches.
+// 384 threads: what the aero workgroup needs (one wavefront per sweep role).
+// ---------------------------------------------------------------------------
+struct CallbackArgs {
+  int32_t nb_eval, nb_aero;
+  int32_t nnodes, tiles;
+  const AeroNodeDev* nodes;
+  AeroOut O;
+  int32_t nlin, nfn, lin_blocks;
+  const LinRowDev* lin;
+  const FnRowDev* fr;
+  double* con;
+  double* jfn;
+};
+static_assert(64 * kAeroRoles == 384, "callback_kernel's workgroup is the aero workgroup");
+template <bool JAC, bool MFMA>
+__global__ __launch_bounds__(384) void callback_kernel(ProblemDev P, const double* __restrict__ x, double* __restrict__ res,
+                                                       double* __restrict__ jvar, CallbackArgs A) {
+  const unsigned b = blockIdx.x;
+  if (b < (unsigned)A.nb_eval) eval_body<JAC, MFMA, true, false>(P, 1, x, res, jvar, b);
+  else if (b < (unsigned)(A.nb_eval + A.nb_aero)) aero_body(P, A.nnodes, A.nodes, A.tiles, x, A.O, b - (unsigned)A.nb_eval);
+  else rows_body(P, A.nlin, A.lin, A.nfn, A.fr, 1, A.lin_blocks, x, A.con, A.jfn, b - (unsigned)(A.nb_eval + A.nb_aero));
+}
+
+hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_x, double* d_res, double* d_jvar,
+                           int nnodes, const AeroNodeDev* nodes, const AeroLaunchOut* aero,
+                           int nlin, const LinRowDev* lin, int nfn, const FnRowDev* fr, double* d_con, double* d_jfn, hipStream_t s) {
+  ProblemDev P = P0;
+  P.unit0 = 4 * P0.chunk0;
+  P.nunits = 4 * P0.nchunks;                       // every unit of the problem, split form
+  CallbackArgs A{};
+  A.nb_eval = (P.nunits + 5) / 6;                  // six wavefronts = six units per workgroup
+  if (aero && nnodes > 0) {
+    for (int k = 0; k < 3; k++) { A.O.con[k] = aero->con[k]; A.O.jac[k] = aero->jac[k]; A.O.nrows[k] = aero->nrows[k]; }
+    A.nnodes = nnodes; A.nodes = nodes; A.tiles = (nnodes + 63) / 64; A.nb_aero = A.tiles;
+  }
+  int rows_blocks = 0;
+  if (d_con && nlin + nfn > 0) {
+    A.nlin = nlin; A.nfn = nfn; A.lin = lin; A.fr = fr; A.con = d_con; A.jfn = d_jfn;
+    A.lin_blocks = (nlin + 383) / 384;
+    rows_blocks = A.lin_blocks + (nfn * 8 + 383) / 384;
+  }
+  const size_t lds_eval = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(want_jac, P.use_mfma != 0, false, true) * 6);
+  const size_t lds_aero = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + 128);
+  const size_t lds = lds_eval > lds_aero ? lds_eval : lds_aero;
+  const dim3 grid((unsigned)(A.nb_eval + A.nb_aero + rows_blocks));
+  if (want_jac) {
+    if (P.use_mfma) hipLaunchKernelGGL((callback_kernel<true, true>), grid, dim3(384), lds, s, P, d_x, d_res, d_jvar, A);
+    else hipLaunchKernelGGL((callback_kernel<true, false>), grid, dim3(384), lds, s, P, d_x, d_res, d_jvar, A);
+  } else {
+    if (P.use_mfma) hipLaunchKernelGGL((callback_kernel<false, true>), grid, dim3(384), lds, s, P, d_x, d_res, d_jvar, A);
+    else hipLaunchKernelGGL((callback_kernel<false, false>), grid, dim3(384), lds, s, P, d_x, d_res, d_jvar, A);
+  }
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

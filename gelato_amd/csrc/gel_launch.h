@@ -31,6 +31,11 @@ struct AeroLaunchOut { double* con[3]; double* jac[3]; int32_t nrows[3]; };
 hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
                        const AeroLaunchOut& out, hipStream_t s);
 
+// one callback = one launch: defect groups (split form) + aero kinds + row table as workgroup ranges of one grid; aero / d_con
+// may be null (that part is left out)
+hipError_t launch_callback(const ProblemDev& P, bool want_jac, const double* d_x, double* d_res, double* d_jvar,
+                           int nnodes, const AeroNodeDev* nodes, const AeroLaunchOut* aero,
+                           int nlin, const LinRowDev* lin, int nfn, const FnRowDev* fr, double* d_con, double* d_jfn, hipStream_t s);
 hipError_t launch_rows(const ProblemDev& P, int nlin, const LinRowDev* lin, int nfn, const FnRowDev* fr, int B,
                        const double* d_x, double* d_con, double* d_jfn, hipStream_t s);
 
