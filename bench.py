@@ -159,8 +159,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16384, help="decision vectors per GPU per step (16384 x 6 = 24 rounds of "
-                    "the 4096 wavefronts the chip holds: at 4096 vectors the ramp and tail of a launch cost a quarter)")
+    ap.add_argument("--batch", type=int, default=65536, help="decision vectors per GPU per step.  65536 vectors = 96 rounds of the 4096 "
+                    "wavefronts the chip holds (at 4096 vectors the ramp and tail of a launch cost a quarter) and, at 6 x 64, "
+                    "13.8 GB of inputs and outputs resident in HBM: sized for the 288 GB of the part, and a step (3.4 ms) long "
+                    "enough that W = 5 warm-up steps reach the chip's steady power state (at 16384 vectors the K timed steps of "
+                    "a short run sit inside the start-up transient: 17.1 M evals/s against 18.8 M settled)")
     ap.add_argument("--settle-ms", type=float, default=250.0, dest="settle_ms",
                     help="untimed launches before the warm-up steps until the power state has settled (0 = none)")
     ap.add_argument("--workload", default="mixed-6x64", help="mixed-6x64 | dense-6x64 | 3x32 | stress-12x128 | example")
@@ -268,7 +271,7 @@ def main():
     elapsed, kern_ms = timed(K)
     # (2) `value_settled`, informational: the same K steps after ~0.25 s of untimed launches (same count on every rank) and W
     # warm-up steps again -- the steady state a batch workload lives in.
-    n_settle = 0 if a.settle_ms <= 0 else min(5000, max(10, int(a.settle_ms / 1.0 * 16384 / B)))
+    n_settle = 0 if a.settle_ms <= 0 else min(5000, max(4, int(a.settle_ms / 1.0 * 16384 / B)))
     for _ in range(n_settle):
         step()
     torch.cuda.synchronize()

@@ -37,7 +37,7 @@ def means(sub):
 
 a, kname, dur_a, na = means("pmc_fp64a")
 b, _, dur_b, nb = means("pmc_fp64b")
-out = {"workload": opt("--workload", "mixed-6x64") + ("_resonly" if "--residual-only" in args else ""), "batch": int(opt("--batch", "16384")),
+out = {"workload": opt("--workload", "mixed-6x64") + ("_resonly" if "--residual-only" in args else ""), "batch": int(opt("--batch", "65536")),
        "kernel": kname, "launches_averaged": [na, nb]}
 if a and b:
     valu_flops = 64.0 * (a.get("SQ_INSTS_VALU_ADD_F64", 0) + a.get("SQ_INSTS_VALU_MUL_F64", 0) + 2 * a.get("SQ_INSTS_VALU_FMA_F64", 0)

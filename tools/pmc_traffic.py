@@ -32,7 +32,7 @@ def mean_per_launch(counter):
 fs, nf, kname = mean_per_launch("FETCH_SIZE")
 ws, nw, _ = mean_per_launch("WRITE_SIZE")
 out = {"workload": opt("--workload", "mixed-6x64") + ("_resonly" if "--residual-only" in args else ""),
-       "batch": int(opt("--batch", "16384")), "kernel": kname, "launches": [nf, nw],
+       "batch": int(opt("--batch", "65536")), "kernel": kname, "launches": [nf, nw],
        "FETCH_SIZE_KiB_per_launch": fs, "WRITE_SIZE_KiB_per_launch": ws}
 if fs is not None and ws is not None:
     out["hbm_bytes_per_launch_raw"] = (fs + ws) * 1024
