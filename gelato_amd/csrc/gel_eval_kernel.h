@@ -131,7 +131,7 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 // callback_kernel (gel_kernels.hip) for the first workgroups of the one launch that serves a whole callback.  In the forms
 // that are not cooperative a workgroup may have any number of wavefronts (each its own work item).
 template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false>
-__device__ __forceinline__ void eval_body(const ProblemDev& P, int B, const double* __restrict__ x, double* __restrict__ res,
+__device__ __forceinline__ void eval_body(const ProblemDev P, int B, const double* __restrict__ x, double* __restrict__ res,
                                           double* __restrict__ jvar, const unsigned vblk) {
   extern __shared__ double lds[];
 #ifdef GEL_STAMP  // diagnostic build only (tools/stamp_phases.py): where a wavefront's lifetime goes, in shader cycles

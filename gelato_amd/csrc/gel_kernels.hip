@@ -369,8 +369,8 @@ struct AeroOut {
 // so every store of a gradient block is one contiguous segment (which is what lets the B = 1 callback write straight into
 // pinned host memory).
 constexpr int kAeroRoles = 6;
-__device__ __forceinline__ void aero_body(const ProblemDev& P, int nnodes, const AeroNodeDev* __restrict__ nodes, int tiles,
-                                          const double* __restrict__ x, const AeroOut& O, const unsigned vblk) {
+__device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes, int tiles,
+                                          const double* __restrict__ x, const AeroOut O, const unsigned vblk) {
   extern __shared__ double lds[];
   const Tables tb = stage_tables(P, lds);
   double* centre = lds + ((table_doubles(P.Kw, P.Kc) + 1) & ~1);   // [2][64]: alpha, q of the centre evaluation
@@ -595,7 +595,7 @@ GEL_DEV double node_fn(int fn, const double r[3], const double v[3], double t, c
   return (fn == 5) ? a * (1.0 - e) : a * (1.0 + e);
 }
 
-__device__ __forceinline__ void rows_body(const ProblemDev& P, int nlin, const LinRowDev* __restrict__ lin, int nfn,
+__device__ __forceinline__ void rows_body(const ProblemDev P, int nlin, const LinRowDev* __restrict__ lin, int nfn,
                                           const FnRowDev* __restrict__ fr, int B, int lin_blocks, const double* __restrict__ x,
                                           double* __restrict__ con, double* __restrict__ jfn, const unsigned vblk) {
   const int R = nlin + nfn;

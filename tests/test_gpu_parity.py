@@ -527,7 +527,7 @@ def test_lookups_through_a_kept_interval_equal_fresh_lookups():
 
 
 @pytest.mark.parametrize("name,B,jac", [("mixed-6x64", 65536, True), ("dense-6x64", 65536, True), ("stress-12x128", 16384, True),
-                                        ("3x32", 262144, False)])    # the batch sizes bench.py / tools/record_all.sh run
+                                        ("3x32", 65536, False)])     # the batch sizes bench.py / tools/record_all.sh run
 def test_full_size_batches_size_independent_properties(name, B, jac):
     """The bench's own launches (BASELINE.json configs at their full batch sizes), checked through properties that do not
     need a reference of that size: equal decision vectors give equal output rows wherever they sit in the batch (the batch

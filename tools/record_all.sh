@@ -5,4 +5,4 @@ cd $GRAFT_REPO_ROOT
 tools/gpu_record.sh $TAG/mixed
 tools/gpu_record.sh $TAG/dense --workload dense-6x64
 tools/gpu_record.sh $TAG/stress --workload stress-12x128 --batch 16384
-tools/gpu_record.sh $TAG/3x32res --workload 3x32 --residual-only --batch 262144
+tools/gpu_record.sh $TAG/3x32res --workload 3x32 --residual-only --batch 65536
