@@ -362,19 +362,22 @@ struct AeroOut {
   int32_t nrows[3];
 };
 
-// Workgroup = 64 consecutive constrained nodes of one decision vector x 6 roles, one wavefront per role (wave-uniform: no
+// Workgroup = 64 consecutive constrained nodes of one decision vector x 4 roles, one wavefront per role (wave-uniform: no
 // divergence): role 0 the centre value + the light sweeps (velocity 3: only the air-relative velocity changes;
-// quaternion 4: only the thrust direction), roles 1..3 one position sweep each (the whole chain), roles 4..5 the t0 / tf
-// sweeps.  The centre values reach the other wavefronts through LDS.  Consecutive lanes are consecutive nodes of a spec,
+// quaternion 4: only the thrust direction), roles 1..3 one position sweep each (the whole chain).  The t0 / tf columns are
+// written as zeros: their sweeps (con_aero.py:452-463 and twins) move only the Earth angle, which the air-relative velocity
+// does not depend on -- the rotation by omega t is applied and undone, and the NED axes at an inertial position do not move with
+// t -- so the reference's quotients are rounding noise around zero (its own values on the example: <= 9e-5 beside position
+// entries of 3e3).  GEL_FLAG_FD_RECOMPUTE: role 0 also runs the two sweeps.  The centre values reach the other wavefronts through LDS.  Consecutive lanes are consecutive nodes of a spec,
 // so every store of a gradient block is one contiguous segment (which is what lets the B = 1 callback write straight into
 // pinned host memory).
-constexpr int kAeroRoles = 6;
+constexpr int kAeroRoles = 4;
 __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes, int tiles,
                                           const double* __restrict__ x, const AeroOut O, const unsigned vblk) {
   extern __shared__ double lds[];
   const Tables tb = stage_tables(P, lds);
   double* centre = lds + ((table_doubles(P.Kw, P.Kc) + 1) & ~1);   // [2][64]: alpha, q of the centre evaluation
-  const int sw = (int)(threadIdx.x >> 6);              // 0 centre + light sweeps, 1..3 position, 4 t0, 5 tf
+  const int sw = (int)(threadIdx.x >> 6);              // 0 centre + light sweeps, 1..3 position
   const int lane = (int)(threadIdx.x & 63);
   const int b = (int)(vblk / (unsigned)tiles), tile = (int)(vblk - (unsigned)b * (unsigned)tiles);
   const int ni_raw = tile * 64 + lane;
@@ -390,10 +393,8 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   for (int c = 0; c < 3; c++) { re[c] = xb[M + 3 * xi + c]; ve[c] = xb[4 * M + 3 * xi + c]; }
 #pragma unroll
   for (int c = 0; c < 4; c++) q[c] = xb[7 * M + 4 * xi + c];
-  double to = xb[11 * M + 2 * N + Nd.phase], tf = xb[11 * M + 2 * N + Nd.phase + 1];
+  const double to = xb[11 * M + 2 * N + Nd.phase], tf = xb[11 * M + 2 * N + Nd.phase + 1];
   const double tau = (Nd.k == 0) ? 0.0 : P.tau[ph.toff + Nd.k - 1];
-  if (sw == 4) to += dx;
-  if (sw == 5) tf += dx;
   // PSparams.time_nodes (SectionParameters.py:77-81): node 0 is t0 itself; t in seconds here (con_aero.py:45)
   const double t = ((Nd.k == 0) ? to : (tau * (tf - to) / 2 + (tf + to) / 2)) * P.ut;
   // con_aero.py:39-87: scale, evaluate
@@ -434,6 +435,21 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       al_q[c] = aero_alpha(a0, nv0, qp);
     }
   }
+  // t0 / tf columns: zero (see above) unless the problem asks for the reference's sweeps
+  double al_t[2] = {alpha_c, alpha_c}, qd_t[2] = {qdyn_c, qdyn_c};
+  if (sw == 0 && want_jac && P.fd_recompute) {
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {
+      const double to_p = (c == 0) ? to + dx : to, tf_p = (c == 1) ? tf + dx : tf;
+      const double tp = ((Nd.k == 0) ? to_p : (tau * (tf_p - to_p) / 2 + (tf_p + to_p) / 2)) * P.ut;
+      const EarthAngle eq = earth_angle(tp);
+      double wq[3], aq[3];
+      wind_eci(r, eq, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, wq);
+      const double nvq = aero_vair(r, v, eq, wq, aq);
+      al_t[c] = aero_alpha(aq, nvq, q);
+      qd_t[c] = 0.5 * rho * nvq * nvq;
+    }
+  }
 #pragma unroll
   for (int kind = 0; kind < 3; kind++) {
     const int row = Nd.row[kind];
@@ -463,11 +479,16 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
             chk += gv;
           }
         }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {                                        // t block: t0 column then tf column
+          const double gv = P.fd_recompute ? -((GEL_AERO_F(al_t[c], qd_t[c]) - fc) / dx) : 0.0;
+          jb[(6 + nq) * R + 2 * row0 + c * nk + Nd.k] = gv;
+          chk += gv;
+        }
       }
     } else if (jb) {
       const double gv = -((GEL_AERO_F(alpha, qdyn) - fc) / dx);
-      if (sw <= 3) jb[3 * row0 + (sw - 1) * nk + Nd.k] = gv;                  // position block, [component][node] per spec
-      else jb[(6 + nq) * R + 2 * row0 + (sw - 4) * nk + Nd.k] = gv;            // t block: t0 column then tf column
+      jb[3 * row0 + (sw - 1) * nk + Nd.k] = gv;                               // position block, [component][node] per spec
       chk += gv;
     }
 #undef GEL_AERO_F
@@ -661,7 +682,7 @@ __global__ void rows_kernel(ProblemDev P, int nlin, const LinRowDev* __restrict_
 // ranges of the same grid -- nothing waits for anything, so the three run side by side instead of one launch after the
 // other (three launches on one stream: 30 us of kernels back to back + two more launch latencies; three streams cost
 // more than they saved: 94 us against 65).  Same device functions, same bits as the separate launches.
-// 384 threads: what the aero workgroup needs (one wavefront per sweep role).
+// 256 threads: the aero workgroup (one wavefront per sweep role) and four units of the split form.
 // ---------------------------------------------------------------------------
 struct CallbackArgs {
   int32_t nb_eval, nb_aero;
@@ -674,9 +695,9 @@ struct CallbackArgs {
   double* con;
   double* jfn;
 };
-static_assert(64 * kAeroRoles == 384, "callback_kernel's workgroup is the aero workgroup");
+static_assert(64 * kAeroRoles == 256, "callback_kernel's workgroup is the aero workgroup");
 template <bool JAC, bool MFMA>
-__global__ __launch_bounds__(384) void callback_kernel(ProblemDev P, const double* __restrict__ x, double* __restrict__ res,
+__global__ __launch_bounds__(256) void callback_kernel(ProblemDev P, const double* __restrict__ x, double* __restrict__ res,
                                                        double* __restrict__ jvar, CallbackArgs A) {
   const unsigned b = blockIdx.x;
   if (b < (unsigned)A.nb_eval) eval_body<JAC, MFMA, true, false>(P, 1, x, res, jvar, b);
@@ -691,7 +712,7 @@ hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_
   P.unit0 = 4 * P0.chunk0;
   P.nunits = 4 * P0.nchunks;                       // every unit of the problem, split form
   CallbackArgs A{};
-  A.nb_eval = (P.nunits + 5) / 6;                  // six wavefronts = six units per workgroup
+  A.nb_eval = (P.nunits + 3) / 4;                  // four wavefronts = four units per workgroup
   if (aero && nnodes > 0) {
     for (int k = 0; k < 3; k++) { A.O.con[k] = aero->con[k]; A.O.jac[k] = aero->jac[k]; A.O.nrows[k] = aero->nrows[k]; }
     A.nnodes = nnodes; A.nodes = nodes; A.tiles = (nnodes + 63) / 64; A.nb_aero = A.tiles;
@@ -699,19 +720,19 @@ hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_
   int rows_blocks = 0;
   if (d_con && nlin + nfn > 0) {
     A.nlin = nlin; A.nfn = nfn; A.lin = lin; A.fr = fr; A.con = d_con; A.jfn = d_jfn;
-    A.lin_blocks = (nlin + 383) / 384;
-    rows_blocks = A.lin_blocks + (nfn * 8 + 383) / 384;
+    A.lin_blocks = (nlin + 255) / 256;
+    rows_blocks = A.lin_blocks + (nfn * 8 + 255) / 256;
   }
-  const size_t lds_eval = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(want_jac, P.use_mfma != 0, false, true) * 6);
+  const size_t lds_eval = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(want_jac, P.use_mfma != 0, false, true) * 4);
   const size_t lds_aero = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + 128);
   const size_t lds = lds_eval > lds_aero ? lds_eval : lds_aero;
   const dim3 grid((unsigned)(A.nb_eval + A.nb_aero + rows_blocks));
   if (want_jac) {
-    if (P.use_mfma) hipLaunchKernelGGL((callback_kernel<true, true>), grid, dim3(384), lds, s, P, d_x, d_res, d_jvar, A);
-    else hipLaunchKernelGGL((callback_kernel<true, false>), grid, dim3(384), lds, s, P, d_x, d_res, d_jvar, A);
+    if (P.use_mfma) hipLaunchKernelGGL((callback_kernel<true, true>), grid, dim3(256), lds, s, P, d_x, d_res, d_jvar, A);
+    else hipLaunchKernelGGL((callback_kernel<true, false>), grid, dim3(256), lds, s, P, d_x, d_res, d_jvar, A);
   } else {
-    if (P.use_mfma) hipLaunchKernelGGL((callback_kernel<false, true>), grid, dim3(384), lds, s, P, d_x, d_res, d_jvar, A);
-    else hipLaunchKernelGGL((callback_kernel<false, false>), grid, dim3(384), lds, s, P, d_x, d_res, d_jvar, A);
+    if (P.use_mfma) hipLaunchKernelGGL((callback_kernel<false, true>), grid, dim3(256), lds, s, P, d_x, d_res, d_jvar, A);
+    else hipLaunchKernelGGL((callback_kernel<false, false>), grid, dim3(256), lds, s, P, d_x, d_res, d_jvar, A);
   }
   return hipGetLastError();
 }
