@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-tools/pmc_kernels.sh "" 2>&1 | grep -A40 "== eval_kernel" | head -60
+timeout 900 python -m pytest tests -m gpu -q -k "callback or aero or rows or driver or gn or shim" 2>&1 | grep -E "^FAILED|^ERROR|passed|failed|Error|assert" | head -20
+for m in 1 0 1 0; do echo "poll=$m"; GEL_CB_POLL=$m python3 tools/cb_abi.py 2>&1 | tail -2 | cut -c1-700; done
