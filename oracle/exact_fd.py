@@ -114,18 +114,12 @@ def gravity(r, barC20):
     return [g_ir * irx, g_ir * iry, g_ir * irz + g_iz]
 
 
-def rhs_air(m_e, r_e, v_e, q, t, thrust, area, nozzle, wind, ca, units, barC20, alt_shift=0):
-    """src/pybind_dynamics.cpp:30-71 on fp64 inputs given as exact mpf; returns acc / unit_vel (3 mpf).  alt_shift (m) is added
-    to the altitude before the atmosphere and wind look-ups: only used to form d(acc)/d(altitude) for the noise bound."""
-    um, up, uv = units
-    # :33-35 -- the scaling is an fp64 product in the reference (Eigen array * double): the chain starts from those ROUNDED values
-    m = f64(float(m_e) * float(um))
-    r = [f64(float(c) * float(up)) for c in r_e]
-    v = [f64(float(c) * float(uv)) for c in v_e]
-    _, _, alt = geodetic(*r)                                   # :43 (the ECI position as if ECEF)
+def air_velocity(r, v, t, wind, alt_shift=0):
+    """the velocity relative to the air in ECI axes and the geopotential altitude of the look-ups: src/pybind_dynamics.cpp:43-53 and
+    src/wrapper_utils.hpp:93-100,165-172 (the same calls) on exact mpf inputs -> ([3], h)"""
+    _, _, alt = geodetic(*r)                                   # the ECI position as if ECEF
     alt = alt + alt_shift
     h = R0 * alt / (R0 + alt) if alt < 86000 else alt          # src/Air.cpp:47-54
-    T, P, rho, a = atmosphere(h)
     c, s = cos(OMEGA * t), sin(OMEGA * t)
     vg = [v[0] + OMEGA * r[1], v[1] - OMEGA * r[0], v[2]]     # src/Coordinate.cpp:69-73
     vecef = [vg[0] * c + vg[1] * s, -vg[0] * s + vg[1] * c, vg[2]]
@@ -137,7 +131,20 @@ def rhs_air(m_e, r_e, v_e, q, t, thrust, area, nozzle, wind, ca, units, barC20, 
     q_i2e = [cos(OMEGA * t / 2), mpf(0), mpf(0), sin(OMEGA * t / 2)]
     q_n2i = conj(quatmult(q_i2e, q_e2n))                       # :104-110
     weci = quatrot(q_n2i, wned)
-    va = [vecef[0] * c - vecef[1] * s - weci[0], vecef[0] * s + vecef[1] * c - weci[1], vecef[2] - weci[2]]   # :53
+    va = [vecef[0] * c - vecef[1] * s - weci[0], vecef[0] * s + vecef[1] * c - weci[1], vecef[2] - weci[2]]
+    return va, h
+
+
+def rhs_air(m_e, r_e, v_e, q, t, thrust, area, nozzle, wind, ca, units, barC20, alt_shift=0):
+    """src/pybind_dynamics.cpp:30-71 on fp64 inputs given as exact mpf; returns acc / unit_vel (3 mpf).  alt_shift (m) is added
+    to the altitude before the atmosphere and wind look-ups: only used to form d(acc)/d(altitude) for the noise bound."""
+    um, up, uv = units
+    # :33-35 -- the scaling is an fp64 product in the reference (Eigen array * double): the chain starts from those ROUNDED values
+    m = f64(float(m_e) * float(um))
+    r = [f64(float(c) * float(up)) for c in r_e]
+    v = [f64(float(c) * float(uv)) for c in v_e]
+    va, h = air_velocity(r, v, t, wind, alt_shift)            # :43-53
+    T, P, rho, a = atmosphere(h)
     vn = sqrt(va[0] ** 2 + va[1] ** 2 + va[2] ** 2)
     cav = interp(vn / a, ca[0], ca[1])
     F = [mpf("0.5") * rho * area * cav * vn * -x for x in va]  # :58-59
@@ -205,3 +212,77 @@ def velocity_fd_truth(prob, x, phase, barC20, with_alt_sensitivity=True):
         lat, _, alt = geodetic(*[f64(float(v) * float(up)) for v in base["r"]])
         out["lat"][j], out["alt"][j] = float(lat), float(alt)
     return out
+
+
+# ---- aero path constraints ----
+def aero_point(r_e, v_e, q, t_e, wind, up, uv, ut, alt_shift=0):
+    """lib/con_aero.py:39-87 (scale in fp64) + src/wrapper_utils.hpp:89-111,163-175 -> (angle of attack [rad], dynamic pressure [Pa])
+    as exact mpf of fp64 inputs"""
+    r = [f64(float(c) * float(up)) for c in r_e]
+    v = [f64(float(c) * float(uv)) for c in v_e]
+    t = f64(float(t_e) * float(ut))
+    va, h = air_velocity(r, v, t, wind, alt_shift)
+    nv = sqrt(va[0] ** 2 + va[1] ** 2 + va[2] ** 2)
+    d = quatrot(conj(q), [mpf(1), mpf(0), mpf(0)])             # :91-92
+    nd = sqrt(d[0] ** 2 + d[1] ** 2 + d[2] ** 2)
+    rho = atmosphere(h)[2]
+    qdyn = mpf("0.5") * rho * nv * nv
+    if nv < mpf("1e-6"):
+        return mpf(0), qdyn
+    c = sum((va[i] / nv) * (d[i] / nd) for i in range(3))
+    from mpmath import acos
+    return (mpf(0) if c > 1 else acos(c)), qdyn
+
+
+def aero_fd_truth(prob, x, spec):
+    """Exact values of what lib/con_aero.py:311-471 differences, for the nodes of `spec` (rows of (phase, range_all)): per node
+    alpha, q and the quotients (f_p - f_c)/dx of BOTH (f = alpha [rad], q [Pa]: the caller forms a kind's gradient from them, the
+    product rule being exact for the quotient of q * alpha: see tests/fd_noise.py) for the position (3), velocity (3) and
+    quaternion (4) sweeps from the UNMODIFIED node (no `+= dx, -= dx` drift); the t0 / tf quotients are exactly zero (the
+    air-relative velocity does not depend on the Earth angle) and are returned as computed, to show it.
+    -> dict: alpha [R], q [R], d_alpha [R, 12], d_q [R, 12] (columns: position xyz, velocity xyz, quaternion wxyz, t0, tf),
+    dalpha_dalt, dq_dalt [R] per metre, lat, alt [R]"""
+    nn = [int(v) for v in prob["num_nodes"]]
+    S, N = len(nn), sum(nn)
+    M = N + S
+    up, uv, ut = [f64(prob["units"][k]) for k in (1, 2, 4)]
+    dx = float(prob["dx"])
+    xr, xv, xq = x[M:4 * M].reshape(-1, 3), x[4 * M:7 * M].reshape(-1, 3), x[7 * M:11 * M].reshape(-1, 4)
+    xt = x[11 * M + 2 * N:]
+    wt = np.asarray(prob["wind_table"])
+    wind = [[f64(v) for v in wt[:, c]] for c in range(3)]
+    rows = []
+    for ph, all_nodes in spec:
+        ph = int(ph)
+        xa = sum(nn[:ph]) + ph
+        to, tf = float(xt[ph]), float(xt[ph + 1])
+        tau = np.asarray(prob["tau"][ph], dtype=np.float64)
+
+        def tnode(k, a, b):                                    # lib/SectionParameters.py:77-81 in fp64
+            return a if k == 0 else float(tau[k - 1] * (b - a) / 2 + (b + a) / 2)
+
+        for k in range(nn[ph] + 1 if all_nodes else 1):
+            r0 = [float(v) for v in xr[xa + k]]; v0 = [float(v) for v in xv[xa + k]]; q0 = [float(v) for v in xq[xa + k]]
+
+            def f(r=r0, v=v0, q=q0, t=tnode(k, to, tf), alt_shift=0):
+                return aero_point(r, v, [f64(c) for c in q], t, wind, up, uv, ut, alt_shift)
+
+            ac, qc = f()
+            cols = []
+            for c in range(3):
+                rp = list(r0); rp[c] = rp[c] + dx
+                cols.append(f(r=rp))
+            for c in range(3):
+                vp = list(v0); vp[c] = vp[c] + dx
+                cols.append(f(v=vp))
+            for c in range(4):
+                qp = list(q0); qp[c] = qp[c] + dx
+                cols.append(f(q=qp))
+            cols.append(f(t=tnode(k, to + dx, tf)))
+            cols.append(f(t=tnode(k, to, tf + dx)))
+            ash, qsh = f(alt_shift=mpf("1e-3"))
+            lat, _, alt = geodetic(*[f64(float(c) * float(up)) for c in r0])
+            rows.append((float(ac), float(qc), [float((a - ac) / f64(dx)) for a, _ in cols], [float((b - qc) / f64(dx)) for _, b in cols],
+                         float((ash - ac) / mpf("1e-3")), float((qsh - qc) / mpf("1e-3")), float(lat), float(alt)))
+    keys = ("alpha", "q", "d_alpha", "d_q", "dalpha_dalt", "dq_dalt", "lat", "alt")
+    return {k: np.array([row[i] for row in rows]) for i, k in enumerate(keys)}

@@ -92,3 +92,124 @@ def engine_bound(terms):
     """per node: what the engine's exact-difference entries may be off the exact quotient (no altitude term) -- except at nodes
     within a step of a break of the atmosphere / wind tables, where the engine recomputes like the reference"""
     return np.where(terms["near_break"], reference_bound(terms), C_CHAIN_ENGINE * EPS * terms["chain"] * np.abs(terms["scale"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Aero path constraints (lib/con_aero.py:311-471): f = alpha / limit, q / limit or q alpha / limit, gradient = -(f_p - f_c)/dx.
+#
+# One evaluation of the chain (src/wrapper_utils.hpp:89-111,163-175) is off the exact value by
+#   angle of attack   e_alpha = eps (C_ACOS / sin(alpha) + C_DIR A)
+#       alpha = acos(c), c = v_air . dir / (|v_air| |dir|) ~ 1: the few roundings of c (absolute C_ACOS eps) move alpha by
+#       eps / sin(alpha); the direction of v_air = R(theta) R(-theta)(v - omega x r) - w_eci carries the roundings of its terms,
+#       whose magnitudes exceed |v_air| by A = (|v| + omega |r| + |w|) / |v_air|;
+#   dynamic pressure  e_q = eps q (C_Q (1 + A) [+ C_RHO])    (|v_air|^2; the density's pow / exp chain: position sweeps only --
+#       the other sweeps look the atmosphere up at the same altitude bits in both evaluations and its rounding cancels);
+#   position sweeps   + |d alpha / d alt| d_alt, |d q / d alt| d_alt with the altitude's rounding d_alt of the velocity bound above.
+# An entry differences two evaluations: bound = 2 e_f / dx.  The REFERENCE adds a drift: it perturbs in place (`+= dx`, `-= dx`,
+# con_aero.py:335-360), which can leave a component one ulp off for every later sweep: |g_i| ulp(x_i) / dx per earlier component.
+# ---------------------------------------------------------------------------------------------------------------------------
+C_ACOS = 8.0
+C_DIR = 8.0
+C_Q = 4.0
+C_RHO = 64.0
+OMEGA_E = 7.2921151467e-5
+
+
+def aero_noise_terms(orc, prob, x, spec):
+    """spec: rows of (phase, range_all, ...) -> per constrained node (rows in the constraint's order): alpha, q, sin(alpha), the
+    cancellation factor A, d_alt, |d alpha / d alt|, |d q / d alt|, and the node's normalised values (for the drift term)"""
+    import ctypes as C
+    L = orc.lib()
+    dp = C.POINTER(C.c_double)
+    L.orc_dynamic_pressure_pa.restype = C.c_double
+    L.orc_angle_of_attack_all_rad.restype = C.c_double
+    nn = [int(v) for v in prob["num_nodes"]]
+    S, N = len(nn), sum(nn)
+    M = N + S
+    up, uv, ut = (float(prob["units"][k]) for k in (1, 2, 4))
+    xr, xv, xq = x[M:4 * M].reshape(-1, 3), x[4 * M:7 * M].reshape(-1, 3), x[7 * M:11 * M].reshape(-1, 4)
+    xt = x[11 * M + 2 * N:]
+    wind = np.ascontiguousarray(prob["wind_table"], dtype=np.float64)
+    Kw = len(wind)
+    wmax = float(np.abs(wind[:, 1:]).max())
+
+    def point(pos, vel, quat, t):
+        a = L.orc_angle_of_attack_all_rad(pos.ctypes.data_as(dp), vel.ctypes.data_as(dp), quat.ctypes.data_as(dp), C.c_double(t),
+                                          wind.ctypes.data_as(dp), C.c_int(Kw))
+        q = L.orc_dynamic_pressure_pa(pos.ctypes.data_as(dp), vel.ctypes.data_as(dp), C.c_double(t), wind.ctypes.data_as(dp), C.c_int(Kw))
+        return a, q
+
+    rows = []
+    for sp in spec:
+        ph, all_nodes = int(sp[0]), int(sp[1])
+        xa = sum(nn[:ph]) + ph
+        to, tf = float(xt[ph]), float(xt[ph + 1])
+        tau = np.asarray(prob["tau"][ph], dtype=np.float64)
+        for k in range(nn[ph] + 1 if all_nodes else 1):
+            t = (to if k == 0 else tau[k - 1] * (tf - to) / 2 + (tf + to) / 2) * ut
+            pos, vel, quat = xr[xa + k] * up, xv[xa + k] * uv, np.ascontiguousarray(xq[xa + k])
+            a, q = point(pos, vel, quat, t)
+            rn = np.linalg.norm(pos)
+            a2, q2 = point(pos * (1.0 + 10.0 / rn), vel, quat, t)
+            lat_deg, _, alt = orc.ecef2geodetic(*pos)
+            lat = np.deg2rad(lat_deg)
+            nv = np.linalg.norm(vel - np.cross([0.0, 0.0, OMEGA_E], pos)) - wmax      # a lower bound of |v_air|
+            A = (np.linalg.norm(vel) + OMEGA_E * rn + wmax) / nv if nv > 0.0 else np.inf
+            qq = np.hypot(pos[0], pos[1]) / max(abs(np.cos(lat)), 1e-300)
+            dalt = EPS * (qq * (1.0 + C_LAT * abs(lat * np.tan(lat))) + 6.4e6)
+            rows.append((a, q, np.sin(a), A, dalt, abs(a2 - a) / 10.0, abs(q2 - q) / 10.0,
+                         np.concatenate([np.abs(xr[xa + k]), np.abs(xv[xa + k]), np.abs(xq[xa + k])])))
+    keys = ("alpha", "q", "sin", "A", "dalt", "dalpha_dalt", "dq_dalt", "xabs")
+    return {k: np.array([r[i] for r in rows]) for i, k in enumerate(keys)}
+
+
+def aero_bound(terms, kind, limit, dx, position):
+    """per row: how far one fp64 implementation's gradient entry of `kind` (position columns / the other columns) may be from the
+    exact quotient.  limit: per row (units[3] of con_aero.py)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        e_alpha = EPS * (C_ACOS / terms["sin"] + C_DIR * terms["A"])
+        e_q = EPS * terms["q"] * (C_Q * (1.0 + terms["A"]) + (C_RHO if position else 0.0))
+        e_alpha = np.where(terms["alpha"] > 0.0, e_alpha, np.inf)     # c_alpha > 1 is clamped to 0: not differentiable there
+        e_q = np.where(np.isfinite(e_q), e_q, 0.0)                    # no air: q = 0 in every evaluation
+    if position:
+        e_alpha = e_alpha + terms["dalpha_dalt"] * terms["dalt"]
+        e_q = e_q + terms["dq_dalt"] * terms["dalt"]
+    e_f = {"alpha": e_alpha, "q": e_q, "qalpha": terms["q"] * e_alpha + terms["alpha"] * e_q}[kind]
+    return 2.0 * e_f / dx / limit
+
+
+def aero_drift(terms, grad_abs, dx):
+    """per row: the reference's in-place drift.  grad_abs [R, 10]: magnitudes of the row's position, velocity and quaternion entries"""
+    return (grad_abs * EPS * (terms["xabs"] + dx)).sum(axis=1) / dx
+
+
+def aero_coo_bounds(orc, prob, x, kind, spec, drift_of=None):
+    """{var: bound of every gradient entry, in the reference's emission order (per spec row, component-major: con_aero.py:437-463)}
+    for ONE implementation against the exact quotient.  drift_of: {var: values in the same order} of a reference-style
+    implementation -- adds the drift of its in-place perturbations, estimated from its own entries."""
+    terms = aero_noise_terms(orc, prob, x, spec)
+    nn = [int(v) for v in prob["num_nodes"]]
+    blocks, lim, r0 = [], [], 0
+    for sp in spec:
+        nk = nn[int(sp[0])] + 1 if int(sp[1]) else 1
+        blocks.append((r0, nk))
+        lim += [float(sp[2])] * nk
+        r0 += nk
+    lim = np.array(lim)
+    dx = float(prob["dx"])
+    width = {"position": 3, "velocity": 3, "quaternion": 0 if kind == "q" else 4, "t": 2}
+    drift = 0.0
+    if drift_of is not None:
+        g = np.zeros((r0, 10))
+        for var, c0 in (("position", 0), ("velocity", 3), ("quaternion", 6)):
+            w, off = width[var], 0
+            for b0, nk in blocks:
+                if w:
+                    g[b0:b0 + nk, c0:c0 + w] = np.abs(np.asarray(drift_of[var])[off:off + w * nk]).reshape(w, nk).T
+                off += w * nk
+        drift = aero_drift(terms, g, dx)
+    out = {}
+    for var, w in width.items():
+        b = aero_bound(terms, kind, lim, dx, position=(var == "position")) + drift
+        out[var] = np.concatenate([np.repeat(b[b0:b0 + nk][None, :], w, axis=0).ravel() for b0, nk in blocks]) if w and blocks else np.zeros(0)
+    return out

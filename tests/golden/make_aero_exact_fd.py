@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Exact-arithmetic known answers for the gradients of the aero path constraints (tests/golden/g18_aero_exact_fd.npz).
+
+Runs in the build container (needs mpmath; NOT the reference checkout): oracle/exact_fd.py evaluates the reference's angle of
+attack and dynamic pressure (src/wrapper_utils.hpp:89-111,163-175 and what they call, lib/con_aero.py:39-87 for the scaling) in
+40-digit arithmetic on exactly the fp64 inputs the reference's sweeps form and differences them (lib/con_aero.py:311-371): the
+finite-difference quotients without their rounding noise.  Cases: the two constraint sets of G9 (the shipped example's own and
+the synthetic one) on the example's decision vector, and every aerodynamic phase but the last of the extreme states of
+tests/states.py (all latitudes up to 89.9 degrees in dense air, every atmosphere layer, hypersonic speeds in thick air).
+
+Per case and constrained node: alpha, q, d_alpha [12], d_q [12] = (f_p - f_c)/dx for position xyz, velocity xyz, quaternion wxyz,
+t0, tf.  The t quotients are zero to the working precision: the air-relative velocity does not depend on the Earth angle.
+
+Usage:  python tests/golden/make_aero_exact_fd.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import oracle  # noqa: E402
+import states  # noqa: E402
+from oracle import exact_fd  # noqa: E402
+
+KEYS = ("alpha", "q", "d_alpha", "d_q")
+LIMITS = {"alpha": 0.2, "q": 4.0e4, "qalpha": 5.0e3}     # units[3] of con_aero.py for the synthetic states
+
+
+def g9_cases():
+    from conftest import D_tau_from_golden, load_golden, problem_from_golden
+    from test_aero_oracle_golden import KINDS, spec_from_golden
+    g = load_golden("g9_aero_example.npz")
+    prob = dict(problem_from_golden(g))
+    D, tau = D_tau_from_golden(g, prob)
+    prob["tau"] = tau
+    for cname in ("example", "synthetic"):
+        nodes = sorted({(int(s[0]), int(s[1])) for kind in KINDS for s in spec_from_golden(g, cname, kind)})
+        # a phase constrained at its first node by one kind and at every node by another: the full range covers both
+        nodes = [(p, a) for p, a in nodes if a == 1 or (p, 1) not in nodes]
+        yield "g9_" + cname, prob, g["x"], nodes
+
+
+def state_cases():
+    for name, build in (("ragged", states.ragged_state), ("polar", lambda: states.with_coast_tail(states.polar_dense_state)),
+                        ("layers", lambda: states.with_coast_tail(states.all_layers_state))):
+        prob, x = build()
+        P = oracle.Problem(prob)
+        prob = dict(prob)
+        prob["tau"] = [P.tau(i) for i in range(P.S)]
+        nodes = [(i, 1) for i in range(P.S - 1) if prob["reference_area"][i] != 0.0]
+        yield name, prob, x, nodes
+
+
+def main():
+    out = {}
+    for name, prob, x, nodes in list(g9_cases()) + list(state_cases()):
+        t0 = time.time()
+        T = exact_fd.aero_fd_truth(prob, x, nodes)
+        out[name + "_x"] = x
+        out[name + "_nodes"] = np.array(nodes, dtype=np.int32)
+        for k in KEYS:
+            out["%s_%s" % (name, k)] = T[k]
+        print("%s: %d nodes of phases %s, %.1f s; max |t quotient| %.1e (alpha), %.1e (q)" % (
+            name, len(T["alpha"]), [p for p, _ in nodes], time.time() - t0, np.abs(T["d_alpha"][:, 10:]).max(), np.abs(T["d_q"][:, 10:]).max()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "g18_aero_exact_fd.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -121,3 +121,21 @@ def polar_dense_state():
     x = np.concatenate([np.linspace(1.0, 0.5, n + 1), pos.ravel(), vel.ravel(), quat.ravel(),
                         2.0 * rng.standard_normal(2 * n), [10.0 / ut, 160.0 / ut]])
     return prob, x
+
+
+def with_coast_tail(build, n_tail=2):
+    """(prob, x) of `build` with one short engine-off phase without aerodynamics appended: the aero path constraints never apply to
+    the LAST phase (lib/con_aero.py:108 walks range(num_sections - 1)), so a one-phase state needs a successor to be constrained."""
+    prob, x = build()
+    prob = dict(prob)
+    nn = [int(v) for v in prob["num_nodes"]]
+    S, N = len(nn), sum(nn)
+    M = N + S
+    for key, v in [("num_nodes", n_tail), ("thrust", 0.0), ("massflow", 0.0), ("reference_area", 0.0), ("nozzle_area", 0.0),
+                   ("engine_on", 0), ("attitude_hold", 0)]:
+        prob[key] = np.concatenate([prob[key], np.array([v], dtype=np.asarray(prob[key]).dtype)])
+    o = np.cumsum([0, M, 3 * M, 3 * M, 4 * M, 2 * N, S + 1])
+    mass, pos, vel, quat, u, t = (x[o[i]:o[i + 1]] for i in range(6))
+    rep = n_tail + 1
+    return prob, np.concatenate([mass, np.repeat(mass[-1:], rep), pos, np.tile(pos[-3:], rep), vel, np.tile(vel[-3:], rep),
+                                 quat, np.tile(quat[-4:], rep), u, np.zeros(2 * n_tail), t, [t[-1] + 0.01]])
