@@ -47,10 +47,15 @@ def _configured(pdict, unitdict, condition, kind):
 
 def _configure_all(pdict, unitdict, condition):
     """every kind configured for this condition dict -> (state, {kind: number of specs})"""
-    st = None
+    st = con_dynamics._state(pdict, unitdict)
+    # inside begin_callback() .. end_callback() the condition dict is read once (the caller vouches it is not modified, like xdict)
+    if st._pinned is not None and st._pinned_aero is not None and st._pinned_aero[0] is condition:
+        return st, st._pinned_aero[1]
     n = {}
     for kind in _KINDS:
         st, n[kind] = _configured(pdict, unitdict, condition, kind)
+    if st._pinned is not None:
+        st._pinned_aero = (condition, n)
     return st, n
 
 

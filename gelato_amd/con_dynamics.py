@@ -62,6 +62,8 @@ class _State:
         self._pinned_x = None
         self._pinned_cond = None
         self._pinned_user = None
+        self._pinned_aero = None
+        self._jd = None
 
     def frame(self, xdict, need_jac):
         """All device outputs for `xdict`: the first function of a callback that asks evaluates the four defect groups,
@@ -88,7 +90,11 @@ class _State:
         return self.engine.split_res(self.frame(xdict, False)["res"])
 
     def jacobians(self, xdict):
-        return self.engine.jac_dicts(self.frame(xdict, True)["vals"])
+        vals = self.frame(xdict, True)["vals"]
+        # the block dicts hold VIEWS of the engine's value array, which every evaluation rewrites in place: built once per array
+        if self._jd is None or self._jd[0] is not vals:
+            self._jd = (vals, self.engine.jac_dicts(vals))
+        return self._jd[1]
 
 
 def _state(pdict, unitdict):
@@ -125,7 +131,7 @@ def begin_callback(pdict, xdict):
     if st is not None:
         st.status = 0
         st._pinned, st._pinned_x, st._pinned_cond = xdict, None, None
-        st._pinned_user = None
+        st._pinned_user = st._pinned_aero = None
         # the user module's device rows are registered BEFORE the first function of the callback asks for the row table
         # (equality_init comes before equality_user in objfunc): a table pinned without them would hand equality_user the
         # rows of another group
@@ -139,7 +145,7 @@ def end_callback(pdict):
     if st is None:
         return 0
     st._pinned, st._pinned_x, st._pinned_cond = None, None, None
-    st._pinned_user = None
+    st._pinned_user = st._pinned_aero = None
     return st.status
 
 

@@ -277,6 +277,8 @@ def _values(xdict, pdict, unitdict, condition, group):
 
 def _const_jac(pdict, unitdict, condition, group):
     j = rows_of(pdict, unitdict, condition).jac[group]
+    if pdict.get("gelato_amd_share_values"):   # constants: the cached arrays themselves (con_dynamics._copy_jac)
+        return {var: {"coo": list(b["coo"]), "shape": b["shape"]} for var, b in j.items()}
     return {var: {"coo": [b["coo"][0], b["coo"][1], b["coo"][2].copy()], "shape": b["shape"]} for var, b in j.items()}
 
 

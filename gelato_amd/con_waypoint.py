@@ -116,13 +116,18 @@ def _jac(xdict, pdict, unitdict, condition, group, with_velocity):
     if jfn is None:
         return None
     n, M, S = len(meta), pdict["M"], pdict["num_sections"]
-    rows3 = np.repeat(np.arange(n, dtype=np.int32), 3)
-    cols3 = np.array([3 * node + c for (_, _, node, _) in meta for c in range(3)], dtype=np.int32)
-    jac = {"position": {"coo": [rows3, cols3, jfn[:, 0:3].ravel().copy()], "shape": (n, 3 * M)}}
+    # the index arrays depend on the row table only: formed once per table and group (the values are fresh arrays per call)
+    R = _ck.rows_of(pdict, unitdict, condition)
+    pat = R.__dict__.setdefault("waypoint_pattern", {}).get(group)
+    if pat is None:
+        pat = R.waypoint_pattern[group] = (
+            np.repeat(np.arange(n, dtype=np.int32), 3), np.array([3 * node + c for (_, _, node, _) in meta for c in range(3)], dtype=np.int32),
+            np.arange(n, dtype=np.int32), np.array([sec for (_, sec, _, _) in meta], dtype=np.int32))
+    rows3, cols3, rows1, secs = pat
+    jac = {"position": {"coo": [rows3, cols3, jfn[:, 0:3].ravel()], "shape": (n, 3 * M)}}     # ravel of a column slice: a copy
     if with_velocity:
-        jac["velocity"] = {"coo": [rows3.copy(), cols3.copy(), jfn[:, 3:6].ravel().copy()], "shape": (n, 3 * M)}
-    jac["t"] = {"coo": [np.arange(n, dtype=np.int32), np.array([sec for (_, sec, _, _) in meta], dtype=np.int32),
-                        jfn[:, 6].copy()], "shape": (n, S + 1)}
+        jac["velocity"] = {"coo": [rows3, cols3, jfn[:, 3:6].ravel()], "shape": (n, 3 * M)}
+    jac["t"] = {"coo": [rows1, secs, jfn[:, 6].copy()], "shape": (n, S + 1)}
     return jac
 
 
