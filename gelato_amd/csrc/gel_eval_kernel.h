@@ -294,7 +294,24 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     GEL_CHK(_v);                                                                          \
   } while (0)
 #endif
+#ifdef GEL_ABL_PAIR   // timing experiment (wrong values): even slots write 16 B per lane over their own and the next slot's bytes, odd slots nothing
+typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
+#define EMIT(slot, val)                                                                                      \
+  do {                                                                                                       \
+    const double _v = (val);                                                                                 \
+    if (((slot) & 1) == 0 && (int)(slot) + 1 >= (int)ph.K) {                                                 \
+      EMIT_AT((int)(slot) * cw8, _v);                                                                        \
+    } else if (((slot) & 1) == 0) {                                                                          \
+      const double _p[2] = {_v, _v};                                                                         \
+      gel_u4 _d;                                                                                             \
+      __builtin_memcpy(&_d, _p, 16);                                                                         \
+      __builtin_amdgcn_raw_buffer_store_b128(_d, jrs, 2 * jvo, (int)(slot) * cw8, GEL_STORE_AUX);            \
+    }                                                                                                        \
+    GEL_CHK(_v);                                                                                             \
+  } while (0)
+#else
 #define EMIT(slot, val) EMIT_AT((int)(slot) * cw8, val)
+#endif
 #ifdef GEL_ABL_NORES  // ablation: residual rows computed, not stored
 #define RSTORE(idx, val) do { if ((val) == 1.2345e300) rb[idx] = (val); } while (0)
 #else
@@ -823,6 +840,33 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     const double tn = tau * (tf - to) / 2 + (tf + to) / 2;  // PSparams.time_nodes, SectionParameters.py:77-81
     const double inv_m = frcp(me * P.um);
 
+    // Exact-difference forms of the two sweeps of the velocity group whose perturbed variable enters the RHS algebraically
+    // (the reference differences two runs, lib/con_dynamics.py:402-450; GEL_FLAG_FD_RECOMPUTE keeps that):
+    //  * quaternion component k: the thrust direction is a quadratic form of q (thrust_dir()), so with the step the
+    //    reference's `+= dx` really takes, dl = (q_k + dx) - q_k (exact), its change is dl * (d dir / d q_k) plus dl^2 in the first
+    //    component -- f_p - f_c = T / m / unit_v * that, exactly; 11 operations per sweep instead of a thrust direction, an
+    //    acceleration and three differences;
+    //  * mass: f_c - f_p = (T d + F) (1/m - 1/m') / unit_v = tm * e / (1 + e) / unit_v with e = (m' - m) / m from the two
+    //    rounded products the reference forms (their difference is exact); e <= 1e-6, so e (1 - e (1 - e)) is exact to 1e-18.
+#define GEL_QUAT_CLOSED(Tval)                                                                                          \
+  do {                                                                                                                 \
+    const double kq_ = ((Tval) * inv_m) * (inv_uv * fds);                                                              \
+    const double q_[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};                         \
+    _Pragma("unroll") for (int k = 0; k < 4; k++) {                                                                    \
+      const double dl_ = (q_[k] + dx) - q_[k];                                                                         \
+      const double a_ = (k < 2) ? -(dl_ * kq_) : dl_ * kq_;   /* entry = -(f_p - f_c) fds; d dir_x / d q_k = +-2 q_k */ \
+      const double b_ = -2.0 * (dl_ * kq_);                                                                            \
+      EMIT(ph.s_vq + 3 * k + 0, (2.0 * q_[k] + dl_) * a_);                                                             \
+      EMIT(ph.s_vq + 3 * k + 1, q_[3 - k] * b_);              /* d dir_y / d q = 2 (q3, q2, q1, q0) */                  \
+      EMIT(ph.s_vq + 3 * k + 2, ((k & 1) ? q_[k ^ 2] : -q_[k ^ 2]) * b_);   /* d dir_z / d q = 2 (-q2, q3, -q0, q1) */  \
+    }                                                                                                                  \
+  } while (0)
+#define GEL_MASS_CLOSED(tm_)                                                                                           \
+  do {                                                                                                                 \
+    const double e_ = ((me + dx) * P.um - me * P.um) * inv_m;                                                          \
+    const double k_ = (e_ * (1.0 - e_ * (1.0 - e_))) * (inv_uv * fds);                                                 \
+    _Pragma("unroll") for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, (tm_)[c] * k_);                                    \
+  } while (0)
     if (ph.air) {
       // The Earth angle omega t enters the RHS only through the rotation of the wind into ECI (the air-relative velocity's two
       // rotations cancel, aero_force()): a wavefront in calm air -- both wind components exactly zero in every lane, e.g. above
@@ -886,9 +930,10 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
           const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
           thrust_dir(q, dir);
         }
+        double tm[3];   // (thrust + aerodynamic force) / m: what the mass sweep scales
         {
           GEL_TDC(Tdc);
-          accel(Tdc, F, inv_m, pp.g, inv_uv, fc);
+          accel_parts(Tdc, F, inv_m, pp.g, inv_uv, tm, fc);
         }
         if (rb) {  // velocity defect (:216-289)
 #pragma unroll
@@ -905,8 +950,15 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         }
         if (JAC && lead) {
           double f[3];
+#ifndef GEL_ABL_NOQM
+          if (!P.fd_recompute) GEL_MASS_CLOSED(tm);   // first: (T d + F) / m dies here
+#endif
           // velocity sweeps: only the aerodynamic force changes
+#ifdef GEL_ABL_NOVEL   // ablation (tools/build_variants.sh): the velocity sweeps left out
+          if (ph.air_fd && dx == 1.2345e300) {
+#else
           if (ph.air_fd) {
+#endif
             const double djj = PARK_GET(PK_DJJ);
 #pragma unroll 1
             for (int k = 0; k < 3; k++) {
@@ -922,8 +974,14 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
               for (int c = 0; c < 3; c++) EMIT(ph.s_vv + 3 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fc[c]));
             }
           }
-          // quaternion sweeps: only the thrust direction changes
-          {
+          // quaternion sweeps: only the thrust direction changes; mass sweep: only the division by mass
+#ifdef GEL_ABL_NOQM
+          if (dx == 1.2345e300) {
+#else
+          if (!P.fd_recompute) {
+#endif
+            GEL_QUAT_CLOSED(GEL_T);
+          } else if (P.fd_recompute) {
             const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
 #pragma unroll 1
             for (int k = 0; k < 4; k++) {
@@ -937,14 +995,11 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #pragma unroll
               for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
             }
-          }
-          // mass sweep: only the division by mass changes
-          {
             GEL_TDC(Tdc);
             accel(Tdc, F, frcp((me + dx) * P.um), pp.g, inv_uv, f);
-          }
 #pragma unroll
-          for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
+            for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
+          }
           // t0 / tf columns (con_dynamics.py:452-480): their two sweeps move only the Earth angle -- and the RHS does not depend on
           // it: the rotation by omega t is applied and undone (src/Coordinate.cpp:41-59), and the NED axes at an inertial position
           // do not move with t, so f_p = f_c up to rounding and the reference's quotient -(f_p (tf_p - to_p) - f_c (tf - to))/dx ut/2
@@ -1102,7 +1157,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         const double r[3] = {re[0] * P.up, re[1] * P.up, re[2] * P.up};
         gravity_eci(r, P.barC20, gc);
       }
-      accel_noair(Td, inv_m, gc, inv_uv, fc);
+      double tm[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) { tm[c] = Td[c] * inv_m; fc[c] = (tm[c] + gc[c]) * inv_uv; }   // accel_noair(), keeping T d / m
       if (rb) {  // velocity defect (:216-289)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -1114,9 +1171,13 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
       }
       if (JAC) {
         double f[3];
-        accel_noair(Td, frcp((me + dx) * P.um), gc, inv_uv, f);
+        if (!P.fd_recompute) {
+          GEL_MASS_CLOSED(tm);
+        } else {
+          accel_noair(Td, frcp((me + dx) * P.um), gc, inv_uv, f);
 #pragma unroll
-        for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
+          for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
+        }
 #pragma unroll 1
         for (int k = 0; k < 3; k++) {
           double r[3], gp[3];
@@ -1127,18 +1188,22 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #pragma unroll
           for (int c = 0; c < 3; c++) EMIT(kSlotVP + 3 * k + c, FDQ(f[c], fc[c]));
         }
-        const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
+        if (!P.fd_recompute) {
+          GEL_QUAT_CLOSED(T);
+        } else {
+          const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-          double qp[4];
+          for (int k = 0; k < 4; k++) {
+            double qp[4];
 #pragma unroll
-          for (int c = 0; c < 4; c++) qp[c] = (k == c) ? (q[c] + dx) : q[c];
-          double dp[3];
-          thrust_dir(qp, dp);
-          const double Tp[3] = {T * dp[0], T * dp[1], T * dp[2]};
-          accel_noair(Tp, inv_m, gc, inv_uv, f);
+            for (int c = 0; c < 4; c++) qp[c] = (k == c) ? (q[c] + dx) : q[c];
+            double dp[3];
+            thrust_dir(qp, dp);
+            const double Tp[3] = {T * dp[0], T * dp[1], T * dp[2]};
+            accel_noair(Tp, inv_m, gc, inv_uv, f);
 #pragma unroll
-          for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
+            for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
+          }
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * ut / 2.0);  // t0 column; tf = its negative
@@ -1148,6 +1213,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #undef EMIT
 #undef GEL_CA_BRACKET
 #undef GEL_WIND_BRACKET
+#undef GEL_QUAT_CLOSED
+#undef GEL_MASS_CLOSED
 #undef EMIT_AT
 #undef RSTORE
 #undef FDQ

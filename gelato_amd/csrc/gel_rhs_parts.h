@@ -313,6 +313,12 @@ GEL_DEV void accel(const double Td[3], const double F[3], double inv_m, const do
 #pragma unroll
   for (int c = 0; c < 3; c++) out[c] = ((Td[c] + F[c]) * inv_m + g[c]) * inv_uv;
 }
+// the same, also returning (thrust_eci + aero)/m (what the mass sweep's closed form scales); same operations, same bits
+GEL_DEV void accel_parts(const double Td[3], const double F[3], double inv_m, const double g[3], double inv_uv, double tm[3],
+                         double out[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) { tm[c] = (Td[c] + F[c]) * inv_m; out[c] = (tm[c] + g[c]) * inv_uv; }
+}
 // NoAir: (thrust_eci/m + g)/uv                          src/pybind_dynamics.cpp:85-91
 GEL_DEV void accel_noair(const double Td[3], double inv_m, const double g[3], double inv_uv, double out[3]) {
 #pragma unroll
