@@ -76,6 +76,9 @@ constexpr int kSlotPT = 0, kSlotVM = 3, kSlotVP = 6;
 #ifndef GEL_MIN_WAVES_PER_SIMD
 #define GEL_MIN_WAVES_PER_SIMD 4  // 121-128 VGPRs: 4 waves/SIMD (16 per CU, matching the LDS budget); 5 spills heavily
 #endif
+#ifndef GEL_MIN_WAVES_PER_SIMD_PACKJAC
+#define GEL_MIN_WAVES_PER_SIMD_PACKJAC 4  // two vectors per wavefront with derivatives (the per-half scalars are vector values there)
+#endif
 #ifndef GEL_MIN_WAVES_PER_SIMD_RES
 #define GEL_MIN_WAVES_PER_SIMD_RES 5  // residual-only, two vectors per wavefront: 94 VGPRs, 25 KB of LDS per workgroup
 #endif
@@ -322,7 +325,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
   const double inv_dx = 1.0 / dx;
   const double fds = GEL_UNI(inv_dx * (tf - to) * ut / 2.0);
   const double fdt = GEL_UNI(inv_dx * ut / 2.0);
-  const double inv_uv = GEL_UNI(1.0 / P.uv);
+  const double inv_uv = wave_uniform(1.0 / P.uv);   // the same for both halves of a two-vector wavefront
 #define FDQ(fp, fc) (((fc) - (fp)) * fds)
 
   // ======================= phase A: every global load =======================
@@ -863,7 +866,8 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
   } while (0)
 #define GEL_MASS_CLOSED(tm_)                                                                                           \
   do {                                                                                                                 \
-    const double e_ = ((me + dx) * P.um - me * P.um) * inv_m;                                                          \
+    /* two ROUNDED products, as the reference forms them (a contracted fma would difference an unrounded one) */      \
+    const double e_ = (fresh_product(me + dx, P.um) - fresh_product(me, P.um)) * inv_m;                                \
     const double k_ = (e_ * (1.0 - e_ * (1.0 - e_))) * (inv_uv * fds);                                                 \
     _Pragma("unroll") for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, (tm_)[c] * k_);                                    \
   } while (0)
@@ -1227,7 +1231,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 }
 
 template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false>
-__global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : GEL_MIN_WAVES_PER_SIMD) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
+__global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : ((JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_PACKJAC : GEL_MIN_WAVES_PER_SIMD)) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   eval_body<JAC, MFMA, SPLIT, PACK>(P, B, x, res, jvar, blockIdx.x);
 }

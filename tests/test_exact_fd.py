@@ -121,6 +121,15 @@ def test_engine_exact_difference_form_within_its_bound_of_the_exact_quotients(na
     assert rc == 0
     J = E.jac_dicts(vals)["vel"]
     compare(J, G, name, prob, P, terms, fd_noise.engine_bound, fd_noise.engine_bound, "engine (exact-difference form)")
+    # the quaternion and mass sweeps are closed forms of the exact quotient (the thrust direction is a quadratic form of q; 1/m
+    # differenced as e/(1+e)): no finite-difference noise at all -- 1e-12 of the node's largest entry, five orders inside the bound
+    for ph in G[name + "_phases"]:
+        ph = int(ph)
+        for var in ("quaternion", "mass"):
+            got = block_entries(J, prob, ph, var)
+            exact = G["%s_p%d_%s" % (name, ph, var)].reshape(got.shape)
+            scale = np.abs(exact).reshape(len(exact), -1).max(axis=1)[:, None, None]
+            assert np.all(np.abs(got - exact) <= 1e-12 * scale + 1e-300), (name, ph, var, (np.abs(got - exact) / (scale + 1e-300)).max())
     # t columns of aerodynamic phases: closed form +-f_c unit_t / 2 (the RHS does not depend on t)
     r, c, v = J["t"]["coo"]
     nn = [int(v_) for v_ in prob["num_nodes"]]
