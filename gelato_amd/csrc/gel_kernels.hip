@@ -362,24 +362,48 @@ struct AeroOut {
   int32_t nrows[3];
 };
 
-// Workgroup = 64 consecutive constrained nodes of one decision vector x 4 roles, one wavefront per role (wave-uniform: no
-// divergence): role 0 the centre value + the light sweeps (velocity 3: only the air-relative velocity changes;
-// quaternion 4: only the thrust direction), roles 1..3 one position sweep each (the whole chain).  The t0 / tf columns are
-// written as zeros: their sweeps (con_aero.py:452-463 and twins) move only the Earth angle, which the air-relative velocity
-// does not depend on -- the rotation by omega t is applied and undone, and the NED axes at an inertial position do not move with
-// t -- so the reference's quotients are rounding noise around zero (its own values on the example: <= 9e-5 beside position
-// entries of 3e3).  GEL_FLAG_FD_RECOMPUTE: role 0 also runs the two sweeps.  The centre values reach the other wavefronts through LDS.  Consecutive lanes are consecutive nodes of a spec,
-// so every store of a gradient block is one contiguous segment (which is what lets the B = 1 callback write straight into
-// pinned host memory).
-constexpr int kAeroRoles = 4;
-__device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes, int tiles,
+// One WAVEFRONT = 64 consecutive constrained nodes of one decision vector, every sweep of the node in the same lane (round 2 ran
+// one wavefront per sweep role and the whole chain in each: six, then four runs of the atmosphere chain per node):
+//   centre      pos_part<CENTRE> (the fused kernel's position part without gravity), wind into ECI, air-relative velocity
+//               (the rotation by omega t and back is not performed: gel_rhs_parts.h aero_force), alpha, q;
+//   position    EXACT-DIFFERENCE form (pos_delta(), gel_rhs_parts.h): the change of latitude pair, altitude, density and wind
+//               from algebraic identities of the reference's formulas, ~130 operations instead of a second run of the chain,
+//               then wind -> air velocity -> alpha, q at the perturbed point; a wavefront with a lane the form does not
+//               cover (another atmosphere layer / table piece, next to the polar axis) recomputes that sweep in full;
+//   velocity    only the air-relative velocity changes;   quaternion: only the body axis;
+//   t0 / tf     zeros: their sweeps (con_aero.py:452-463 and twins) move only the Earth angle, which the air-relative velocity
+//               does not depend on -- the rotation is applied and undone, and the NED axes at an inertial position do not move
+//               with t -- so the reference's quotients are rounding noise around zero (<= 9e-5 beside position entries of 3e3).
+// GEL_FLAG_FD_RECOMPUTE: every position sweep and the two t sweeps re-run the chain like the reference.  alpha is only
+// evaluated by wavefronts that have an alpha or q-alpha row.  Consecutive lanes are consecutive nodes of a spec, so every
+// store of a gradient block is one contiguous segment (which is what lets the B = 1 callback write straight into pinned
+// host memory).  Four wavefronts (four tiles) per workgroup.
+constexpr int kAeroWaves = 4;
+GEL_DEV double aero_vair_eci(const double r[3], const double v[3], const double w[3], double a[3]) {
+  a[0] = (v[0] + kOmega * r[1]) - w[0]; a[1] = (v[1] - kOmega * r[0]) - w[1]; a[2] = v[2] - w[2];
+  return fsqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+}
+// angle of attack (wrapper_utils.hpp:89-111) from the body axis d (thrust_dir(q)): the cosine as one dot product times the two
+// reciprocal norms (the reference divides component by component: <= 3 ulp of the cosine apart)
+GEL_DEV double aero_alpha_dir(const double a[3], double nv, const double d[3]) {
+  const double ind = frsqrt(fmax(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1.0e-300));
+  const double c_alpha = ((a[0] * d[0] + a[1] * d[1] + a[2] * d[2]) * frcp(fmax(nv, 1.0e-300))) * ind;
+  return (c_alpha > 1.0) ? 0.0 : ((nv < 1e-6) ? 0.0 : acos(c_alpha));
+}
+
+// ROLES (the B = 1 callback launch, where the length of one wavefront's chain is what counts): the four wavefronts of a
+// workgroup share ONE tile -- wavefront 0 the centre values and the light sweeps, wavefronts 1..3 the centre and one position
+// sweep each.  Same operations on the same operands per entry: bit-identical to the one-wavefront form.
+template <bool ROLES>
+__device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes, int tiles, int B,
                                           const double* __restrict__ x, const AeroOut O, const unsigned vblk) {
   extern __shared__ double lds[];
   const Tables tb = stage_tables(P, lds);
-  double* centre = lds + ((table_doubles(P.Kw, P.Kc) + 1) & ~1);   // [2][64]: alpha, q of the centre evaluation
-  const int sw = (int)(threadIdx.x >> 6);              // 0 centre + light sweeps, 1..3 position
   const int lane = (int)(threadIdx.x & 63);
-  const int b = (int)(vblk / (unsigned)tiles), tile = (int)(vblk - (unsigned)b * (unsigned)tiles);
+  const int sw = ROLES ? (int)(threadIdx.x >> 6) : -1;   // ROLES: 0 centre + light sweeps, 1..3 position sweep sw - 1
+  const long long wid = ROLES ? (long long)vblk : (long long)vblk * kAeroWaves + (threadIdx.x >> 6);
+  if (wid >= (long long)B * tiles) return;             // after the tables' barrier
+  const int b = (int)(wid / tiles), tile = (int)(wid - (long long)b * tiles);
   const int ni_raw = tile * 64 + lane;
   const bool live = ni_raw < nnodes;
   const int ni = live ? ni_raw : nnodes - 1;
@@ -397,108 +421,149 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   const double tau = (Nd.k == 0) ? 0.0 : P.tau[ph.toff + Nd.k - 1];
   // PSparams.time_nodes (SectionParameters.py:77-81): node 0 is t0 itself; t in seconds here (con_aero.py:45)
   const double t = ((Nd.k == 0) ? to : (tau * (tf - to) / 2 + (tf + to) / 2)) * P.ut;
-  // con_aero.py:39-87: scale, evaluate
+  const bool want_jac = O.jac[0] || O.jac[1] || O.jac[2];
+  // does any lane of this wavefront have an alpha or q-alpha row?  (wave-uniform)
+  const bool need_alpha = __builtin_amdgcn_ballot_w64(live && ((O.con[0] && Nd.row[0] >= 0) || (O.con[2] && Nd.row[2] >= 0))) != 0;
+  // ---- centre (con_aero.py:39-87: scale, evaluate)
   double r[3], v[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) { r[c] = ((sw == 1 + c) ? re[c] + dx : re[c]) * P.up; v[c] = ve[c] * P.uv; }
-  const AeroPos pp = aero_pos_part(r, tb);
+  for (int c = 0; c < 3; c++) { r[c] = re[c] * P.up; v[c] = ve[c] * P.uv; }
+  PosCentre pc;
+  PosCentreTail pt;
+  PosPart pp = pos_part<true, PosCentreSink, false>(r, tb, 0.0, nullptr, PosCentreSink{&pc}, &pt);
+  pos_centre_tail(pt, pp.rho, pp.P, tb, pc, pp.wn, pp.we);
   const EarthAngle ea = earth_angle(t);
-  double w[3], a0[3];
+  double w[3], a0[3], dir[3];
   wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
-  const double nv0 = aero_vair(r, v, ea, w, a0);
-  const double alpha = aero_alpha(a0, nv0, q);
-  const double rho = pp.rho;
-  const double qdyn = 0.5 * rho * nv0 * nv0;
-  if (sw == 0) { centre[lane] = alpha; centre[64 + lane] = qdyn; }
-  __syncthreads();
-  if (!live) return;
-  const double alpha_c = centre[lane], qdyn_c = centre[64 + lane];
+  const double nv0 = aero_vair_eci(r, v, w, a0);
+  thrust_dir(q, dir);
+  const double alpha_c = need_alpha ? aero_alpha_dir(a0, nv0, dir) : 0.0;
+  const double qdyn_c = 0.5 * pp.rho * nv0 * nv0;
   double chk = 0.0;
-  // role 0: the light sweeps, once for all kinds
-  double al_v[3] = {0, 0, 0}, qd_v[3] = {0, 0, 0}, al_q[4] = {0, 0, 0, 0};
-  const bool want_jac = O.jac[0] || O.jac[1] || O.jac[2];
-  if (sw == 0 && want_jac) {
+  // f / units[3] (con_aero.py:85-87) as f * (1 / units[3]) (one rounding apart from the division); con = 1 - f (:127-139);
+  // jac = -(f_p - f_c)/dx (:437-463)
+  const double inv_dx = 1.0 / dx;
+  double ilim[3], fcen[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      double vp[3], a[3];
+  for (int kind = 0; kind < 3; kind++) ilim[kind] = frcp(Nd.limit[kind]);
+#define GEL_AERO_F(kind, al, qd) ((((kind) == 0) ? (al) : ((kind) == 1) ? (qd) : (qd) * (al)) * ilim[kind])
 #pragma unroll
-      for (int d = 0; d < 3; d++) vp[d] = ((d == c) ? ve[d] + dx : ve[d]) * P.uv;
-      const double nv = aero_vair(r, vp, ea, w, a);
-      al_v[c] = aero_alpha(a, nv, q);
-      qd_v[c] = 0.5 * rho * nv * nv;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      double qp[4];
-#pragma unroll
-      for (int d = 0; d < 4; d++) qp[d] = (d == c) ? q[d] + dx : q[d];
-      al_q[c] = aero_alpha(a0, nv0, qp);
-    }
-  }
-  // t0 / tf columns: zero (see above) unless the problem asks for the reference's sweeps
-  double al_t[2] = {alpha_c, alpha_c}, qd_t[2] = {qdyn_c, qdyn_c};
-  if (sw == 0 && want_jac && P.fd_recompute) {
-#pragma unroll 1
-    for (int c = 0; c < 2; c++) {
-      const double to_p = (c == 0) ? to + dx : to, tf_p = (c == 1) ? tf + dx : tf;
-      const double tp = ((Nd.k == 0) ? to_p : (tau * (tf_p - to_p) / 2 + (tf_p + to_p) / 2)) * P.ut;
-      const EarthAngle eq = earth_angle(tp);
-      double wq[3], aq[3];
-      wind_eci(r, eq, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, wq);
-      const double nvq = aero_vair(r, v, eq, wq, aq);
-      al_t[c] = aero_alpha(aq, nvq, q);
-      qd_t[c] = 0.5 * rho * nvq * nvq;
-    }
-  }
+  for (int kind = 0; kind < 3; kind++) fcen[kind] = GEL_AERO_F(kind, alpha_c, qdyn_c);
+  // one gradient entry of every kind that has this node, from the perturbed pair (alpha, q): block offset `boff` (in units of R
+  // rows: 0 position, 3 velocity, 6 quaternion, -1 = t: 6 + nq), `width` columns per row in the block, column `col`
+#define GEL_AERO_EMIT(boff, width, col, al, qd, skip_q, zero)                                                   \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int kind = 0; kind < 3; kind++) {                                                      \
+      if ((skip_q) && kind == 1) continue;                 /* dynamic pressure has no quaternion block */        \
+      const int row = Nd.row[kind];                                                                               \
+      if (!live || row < 0 || !O.jac[kind]) continue;                                                             \
+      const int R = O.nrows[kind], nq = (kind == 1) ? 0 : 4;                                                      \
+      const int bo = ((boff) < 0) ? (6 + nq) : (boff);                                                            \
+      double* jb = O.jac[kind] + (size_t)b * R * (8 + nq);                                                        \
+      const double gv = (zero) ? 0.0 : (fcen[kind] - GEL_AERO_F(kind, al, qd)) * inv_dx;                          \
+      jb[(size_t)bo * R + (width) * Nd.row0[kind] + (col) * Nd.nk[kind] + Nd.k] = gv;                             \
+      chk += gv;                                                                                                  \
+    }                                                                                                             \
+  } while (0)
 #pragma unroll
   for (int kind = 0; kind < 3; kind++) {
     const int row = Nd.row[kind];
-    if (row < 0 || !O.con[kind]) continue;
-    const int R = O.nrows[kind], nk = Nd.nk[kind], row0 = Nd.row0[kind], nq = (kind == 1) ? 0 : 4;
-    const double lim = Nd.limit[kind];
-    // f / units[3] (con_aero.py:85-87); con = 1 - f (:127-139); jac = -(f_p - f_c)/dx (:437-463)
-#define GEL_AERO_F(al, qd) (((kind == 0) ? (al) : (kind == 1) ? (qd) : (qd) * (al)) / lim)
-    const double fc = GEL_AERO_F(alpha_c, qdyn_c);
-    double* jb = O.jac[kind] ? O.jac[kind] + (size_t)b * R * (8 + nq) : nullptr;
-    if (sw == 0) {
-      const double cv = 1.0 - fc;
-      O.con[kind][(size_t)b * R + row] = cv;
-      chk += cv;
-      if (jb) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const double gv = -((GEL_AERO_F(al_v[c], qd_v[c]) - fc) / dx);
-          jb[3 * R + 3 * row0 + c * nk + Nd.k] = gv;                         // velocity block
-          chk += gv;
-        }
-        if (kind != 1) {                                                     // dynamic pressure has no quaternion block
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const double gv = -((GEL_AERO_F(al_q[c], qdyn_c) - fc) / dx);
-            jb[6 * R + 4 * row0 + c * nk + Nd.k] = gv;
-            chk += gv;
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 2; c++) {                                        // t block: t0 column then tf column
-          const double gv = P.fd_recompute ? -((GEL_AERO_F(al_t[c], qd_t[c]) - fc) / dx) : 0.0;
-          jb[(6 + nq) * R + 2 * row0 + c * nk + Nd.k] = gv;
-          chk += gv;
-        }
-      }
-    } else if (jb) {
-      const double gv = -((GEL_AERO_F(alpha, qdyn) - fc) / dx);
-      jb[3 * row0 + (sw - 1) * nk + Nd.k] = gv;                               // position block, [component][node] per spec
-      chk += gv;
-    }
-#undef GEL_AERO_F
+    if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
+    const double cv = 1.0 - fcen[kind];
+    O.con[kind][(size_t)b * O.nrows[kind] + row] = cv;
+    chk += cv;
   }
+  if (want_jac) {
+    // ---- t0 / tf columns
+#pragma unroll 1
+    for (int c = (ROLES && sw != 0) ? 2 : 0; c < 2; c++) {
+      double al = alpha_c, qd = qdyn_c;
+      if (P.fd_recompute) {
+        const double to_p = (c == 0) ? to + dx : to, tf_p = (c == 1) ? tf + dx : tf;
+        const double tp = ((Nd.k == 0) ? to_p : (tau * (tf_p - to_p) / 2 + (tf_p + to_p) / 2)) * P.ut;
+        const EarthAngle eq = earth_angle(tp);
+        double wq[3], aq[3];
+        wind_eci(r, eq, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, wq);
+        const double nvq = aero_vair_eci(r, v, wq, aq);
+        al = need_alpha ? aero_alpha_dir(aq, nvq, dir) : 0.0;
+        qd = 0.5 * pp.rho * nvq * nvq;
+      }
+      GEL_AERO_EMIT(-1, 2, c, al, qd, false, !P.fd_recompute);
+    }
+    // ---- position sweeps
+#define GEL_AERO_POS_TAIL(c, rp, pq)                                                                 \
+  do {                                                                                               \
+    double wq_[3], a_[3];                                                                            \
+    wind_eci(rp, ea, (pq).shp, (pq).chp, (pq).inv_p, (pq).wn, (pq).we, wq_);                         \
+    const double nv_ = aero_vair_eci(rp, v, wq_, a_);                                                \
+    const double al_ = need_alpha ? aero_alpha_dir(a_, nv_, dir) : 0.0;                              \
+    GEL_AERO_EMIT(0, 3, c, al_, 0.5 * (pq).rho * nv_ * nv_, false, false);                           \
+  } while (0)
+    const unsigned mine = ROLES ? ((sw == 0) ? 0u : (1u << (sw - 1))) : 7u;   // this wavefront's position sweeps
+    unsigned todo = P.fd_recompute ? mine : 0u;   // sweeps with a lane the difference form does not cover (wave-uniform)
+    if (!P.fd_recompute) {
+#pragma unroll 1
+      for (int c = 0; c < 3; c++) {
+        if (!((mine >> c) & 1u)) continue;
+        double rp[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) rp[d] = (d == c) ? (re[d] + dx) * P.up : r[d];
+        const double dlt = (c == 0) ? rp[0] - r[0] : ((c == 1) ? rp[1] - r[1] : rp[2] - r[2]);   // exact
+        PosPart pq;
+        if (__builtin_amdgcn_ballot_w64(!pos_delta(r, c, dlt, pp, pc, tb, pq)) != 0) { todo |= 1u << c; continue; }
+        GEL_AERO_POS_TAIL(c, rp, pq);
+      }
+    }
+    if (todo) {   // the chain once more on the perturbed position, for the whole wavefront (like the reference)
+      asm volatile("" ::: "memory");
+#pragma unroll 1
+      for (int c = 0; c < 3; c++) {
+        if (!((todo >> c) & 1u)) continue;
+        double rp[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) rp[d] = ((d == c) ? xb[M + 3 * xi + d] + dx : xb[M + 3 * xi + d]) * P.up;
+        const PosPart pf = pos_part<false, NoSink, false>(rp, tb, 0.0);
+        GEL_AERO_POS_TAIL(c, rp, pf);
+      }
+    }
+#undef GEL_AERO_POS_TAIL
+    asm volatile("" ::: "memory");   // the light sweeps read their inputs again
+    // ---- velocity sweeps: [component][node] per spec
+#pragma unroll 1
+    for (int c = (ROLES && sw != 0) ? 3 : 0; c < 3; c++) {
+      double vp[3], a[3];
+      const double r[3] = {xb[M + 3 * xi] * P.up, xb[M + 3 * xi + 1] * P.up, xb[M + 3 * xi + 2] * P.up};
+      const double ve[3] = {xb[4 * M + 3 * xi], xb[4 * M + 3 * xi + 1], xb[4 * M + 3 * xi + 2]};
+#pragma unroll
+      for (int d = 0; d < 3; d++) vp[d] = ((d == c) ? ve[d] + dx : ve[d]) * P.uv;
+      const double nv = aero_vair_eci(r, vp, w, a);
+      const double al = need_alpha ? aero_alpha_dir(a, nv, dir) : 0.0;
+      GEL_AERO_EMIT(3, 3, c, al, 0.5 * pp.rho * nv * nv, false, false);
+    }
+    // ---- quaternion sweeps
+    if (need_alpha && !(ROLES && sw != 0)) {
+#pragma unroll 1
+      for (int c = 0; c < 4; c++) {
+        double qp[4], dp[3];
+        const double q[4] = {xb[7 * M + 4 * xi], xb[7 * M + 4 * xi + 1], xb[7 * M + 4 * xi + 2], xb[7 * M + 4 * xi + 3]};
+#pragma unroll
+        for (int d = 0; d < 4; d++) qp[d] = (d == c) ? q[d] + dx : q[d];
+        thrust_dir(qp, dp);
+        GEL_AERO_EMIT(6, 4, c, aero_alpha_dir(a0, nv0, dp), qdyn_c, true, false);
+      }
+    }
+  }
+#undef GEL_AERO_EMIT
+#undef GEL_AERO_F
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 
-__global__ __launch_bounds__(64 * kAeroRoles) void aero_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
-                                                                 int tiles, const double* __restrict__ x, AeroOut O) {
-  aero_body(P, nnodes, nodes, tiles, x, O, blockIdx.x);
+#ifndef GEL_AERO_MIN_WAVES
+#define GEL_AERO_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(64 * kAeroWaves, GEL_AERO_MIN_WAVES) void aero_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
+                                                                int tiles, int B, const double* __restrict__ x, AeroOut O) {
+  aero_body<false>(P, nnodes, nodes, tiles, B, x, O, blockIdx.x);
 }
 
 hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
@@ -507,8 +572,9 @@ hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes
   AeroOut O;
   for (int k = 0; k < 3; k++) { O.con[k] = out.con[k]; O.jac[k] = out.jac[k]; O.nrows[k] = out.nrows[k]; }
   const int tiles = (nnodes + 63) / 64;
-  const size_t lds = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + 128);
-  hipLaunchKernelGGL(aero_kernel, dim3((unsigned)B * (unsigned)tiles), dim3(64 * kAeroRoles), lds, s, P, nnodes, nodes, tiles, d_x, O);
+  const size_t lds = sizeof(double) * ((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1);
+  const unsigned grid = (unsigned)(((long long)B * tiles + kAeroWaves - 1) / kAeroWaves);
+  hipLaunchKernelGGL(aero_kernel, dim3(grid), dim3(64 * kAeroWaves), lds, s, P, nnodes, nodes, tiles, B, d_x, O);
   return hipGetLastError();
 }
 
@@ -695,13 +761,13 @@ struct CallbackArgs {
   double* con;
   double* jfn;
 };
-static_assert(64 * kAeroRoles == 256, "callback_kernel's workgroup is the aero workgroup");
+static_assert(64 * kAeroWaves == 256, "callback_kernel's workgroup is the aero workgroup (four roles of one tile)");
 template <bool JAC, bool MFMA>
 __global__ __launch_bounds__(256) void callback_kernel(ProblemDev P, const double* __restrict__ x, double* __restrict__ res,
                                                        double* __restrict__ jvar, CallbackArgs A) {
   const unsigned b = blockIdx.x;
   if (b < (unsigned)A.nb_eval) eval_body<JAC, MFMA, true, false>(P, 1, x, res, jvar, b);
-  else if (b < (unsigned)(A.nb_eval + A.nb_aero)) aero_body(P, A.nnodes, A.nodes, A.tiles, x, A.O, b - (unsigned)A.nb_eval);
+  else if (b < (unsigned)(A.nb_eval + A.nb_aero)) aero_body<true>(P, A.nnodes, A.nodes, A.tiles, 1, x, A.O, b - (unsigned)A.nb_eval);
   else rows_body(P, A.nlin, A.lin, A.nfn, A.fr, 1, A.lin_blocks, x, A.con, A.jfn, b - (unsigned)(A.nb_eval + A.nb_aero));
 }
 
@@ -715,7 +781,7 @@ hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_
   A.nb_eval = (P.nunits + 3) / 4;                  // four wavefronts = four units per workgroup
   if (aero && nnodes > 0) {
     for (int k = 0; k < 3; k++) { A.O.con[k] = aero->con[k]; A.O.jac[k] = aero->jac[k]; A.O.nrows[k] = aero->nrows[k]; }
-    A.nnodes = nnodes; A.nodes = nodes; A.tiles = (nnodes + 63) / 64; A.nb_aero = A.tiles;
+    A.nnodes = nnodes; A.nodes = nodes; A.tiles = (nnodes + 63) / 64; A.nb_aero = A.tiles;   // ROLES form: one workgroup per tile
   }
   int rows_blocks = 0;
   if (d_con && nlin + nfn > 0) {
@@ -724,7 +790,7 @@ hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_
     rows_blocks = A.lin_blocks + (nfn * 8 + 255) / 256;
   }
   const size_t lds_eval = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(want_jac, P.use_mfma != 0, false, true) * 4);
-  const size_t lds_aero = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + 128);
+  const size_t lds_aero = sizeof(double) * ((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1);
   const size_t lds = lds_eval > lds_aero ? lds_eval : lds_aero;
   const dim3 grid((unsigned)(A.nb_eval + A.nb_aero + rows_blocks));
   if (want_jac) {

@@ -71,7 +71,8 @@ struct PosCentreSink {   // collects into a PosCentre (hooks, aero kernel)
   }
 };
 
-template <bool CENTRE = false, class Sink = NoSink>
+// GRAV = false (aero path constraints): no gravity.
+template <bool CENTRE = false, class Sink = NoSink, bool GRAV = true>
 GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20, Bracket2* wbr = nullptr, Sink sink = Sink(),
                          PosCentreTail* tail = nullptr) {
   PosPart o;
@@ -116,7 +117,8 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20, Bra
     tail->h = h; tail->k = us76_layer(h);
   } else if (wbr) wind_ned2_cached(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we, *wbr);
   else wind_ned2(h, tb.wind, tb.winds, tb.Kw, o.wn, o.we);
-  gravity_eci(r, barC20, o.g);
+  if (GRAV) gravity_eci(r, barC20, o.g);
+  else o.g[0] = o.g[1] = o.g[2] = 0.0;
   return o;
 }
 

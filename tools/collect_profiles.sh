@@ -7,7 +7,7 @@ mkdir -p profiles/$TAG/others
 for w in mixed dense stress 3x32res; do
   for f in bench.json bench_profiled.json kernel_stats.csv traffic.json fp64.json; do cp gpurun_out/$TAG/$w/$f profiles/$TAG/${w}_$f; done
 done
-cp gpurun_out/$TAG/others/{others.json,kernel_stats.csv,pmc_FETCH_SIZE.csv,pmc_WRITE_SIZE.csv} profiles/$TAG/others/
+cp gpurun_out/$TAG/others/{others.json,kernel_stats.csv,pmc_FETCH_SIZE.csv,pmc_WRITE_SIZE.csv,pmc_busy.csv} profiles/$TAG/others/
 python3 - $TAG <<'PY'
 import json, shutil, sys
 tag = sys.argv[1]

@@ -28,5 +28,27 @@ for (name, grid), vs in sorted(agg.items()):
     print('"%s",%s,%d,%.1f' % (name, grid, len(vs), sum(vs) / len(vs)))
 PY
 done
-rm -rf $OUT/prof $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
-echo "== others"; cat $OUT/others.json; head -12 $OUT/kernel_stats.csv; cat $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv
+# datapath occupancy per kernel (what binds the ones that are far from the HBM roofline)
+OK_REPS=4 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_busy -o pmc -- python3 $R/tools/other_kernels.py $WL > /dev/null 2> $OUT/pmc_busy.err
+python3 - $OUT/pmc_busy > $OUT/pmc_busy.csv <<'PY'
+import csv, glob, os, sys
+per = {}
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = (row["Kernel_Name"].split("(")[0], row.get("Grid_Size", ""), row["Dispatch_Id"])
+        per.setdefault(k, {}).setdefault(row["Counter_Name"], 0.0)
+        per[k][row["Counter_Name"]] += float(row["Counter_Value"])
+agg = {}
+for (name, grid, _), c in per.items():
+    a = agg.setdefault((name, grid), {"n": 0})
+    a["n"] += 1
+    for k, v in c.items(): a[k] = a.get(k, 0.0) + v
+print("kernel,grid_size,dispatches,valu_insts_per_wave,valu_busy,wait_inst_share")
+for (name, grid), a in sorted(agg.items()):
+    if not a.get("SQ_WAVES") or not a.get("GRBM_GUI_ACTIVE"): continue
+    cyc = a["GRBM_GUI_ACTIVE"] / 8.0
+    print('"%s",%s,%d,%.1f,%.3f,%.3f' % (name, grid, a["n"], a["SQ_INSTS_VALU"] / a["SQ_WAVES"], a["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc,
+                                       a["SQ_WAIT_INST_ANY"] / max(a["SQ_WAVE_CYCLES"], 1.0)))
+PY
+rm -rf $OUT/prof $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_busy
+echo "== others"; cat $OUT/others.json; head -12 $OUT/kernel_stats.csv; cat $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_busy.csv
