@@ -391,6 +391,10 @@ GEL_DEV double aero_alpha_dir(const double a[3], double nv, const double d[3]) {
   return (c_alpha > 1.0) ? 0.0 : ((nv < 1e-6) ? 0.0 : acos(c_alpha));
 }
 
+// park slots of one wavefront (doubles; the last five hold 10 ints per lane)
+enum { AP_ILIM = 0, AP_FCEN = 3, AP_W = 6, AP_A0 = 9, AP_DIR = 12, AP_NV0 = 15, AP_RHO = 16, AP_INTS = 17, kAeroParkSlots = 22 };
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) double lds_f64;
 // ROLES (the B = 1 callback launch, where the length of one wavefront's chain is what counts): the four wavefronts of a
 // workgroup share ONE tile -- wavefront 0 the centre values and the light sweeps, wavefronts 1..3 the centre and one position
 // sweep each.  Same operations on the same operands per entry: bit-identical to the one-wavefront form.
@@ -443,49 +447,70 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   // f / units[3] (con_aero.py:85-87) as f * (1 / units[3]) (one rounding apart from the division); con = 1 - f (:127-139);
   // jac = -(f_p - f_c)/dx (:437-463)
   const double inv_dx = 1.0 / dx;
-  double ilim[3], fcen[3];
+  // The park: this wavefront's [slot][lane] region of LDS behind the tables.  What every store needs (1/limit, the centre's f,
+  // the node's rows) and what only the light sweeps need (centre wind, air velocity, body axis) wait there instead of in
+  // registers across the position sweeps: 234 -> fewer VGPRs, one more wavefront per SIMD.
+  lds_f64* park = (lds_f64*)lds + ((table_doubles(P.Kw, P.Kc) + 1) & ~1) + (size_t)(threadIdx.x >> 6) * (kAeroParkSlots * 64) + lane;
+  lds_int* ipark = (lds_int*)(park - lane + AP_INTS * 64) + lane;      // [10][64] ints: k, row0[3], nk[3], row[3]
+#define AP_GET(i) (park[(i) * 64])
+#define AP_SET(i, v) (park[(i) * 64] = (v))
+  {
+    double fc_[3];
 #pragma unroll
-  for (int kind = 0; kind < 3; kind++) ilim[kind] = frcp(Nd.limit[kind]);
-#define GEL_AERO_F(kind, al, qd) ((((kind) == 0) ? (al) : ((kind) == 1) ? (qd) : (qd) * (al)) * ilim[kind])
+    for (int kind = 0; kind < 3; kind++) {
+      const double il = frcp(Nd.limit[kind]);
+      fc_[kind] = ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
+      AP_SET(AP_ILIM + kind, il); AP_SET(AP_FCEN + kind, fc_[kind]);
+      ipark[(1 + kind) * 64] = Nd.row0[kind]; ipark[(4 + kind) * 64] = Nd.nk[kind];
+      ipark[(7 + kind) * 64] = (live && O.jac[kind]) ? Nd.row[kind] : -1;
+    }
+    ipark[0] = Nd.k;
 #pragma unroll
-  for (int kind = 0; kind < 3; kind++) fcen[kind] = GEL_AERO_F(kind, alpha_c, qdyn_c);
+    for (int kind = 0; kind < 3; kind++) {     // the constraint values (con_aero.py:127-139)
+      const int row = Nd.row[kind];
+      if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
+      const double cv = 1.0 - fc_[kind];
+      O.con[kind][(size_t)b * O.nrows[kind] + row] = cv;
+      chk += cv;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) { AP_SET(AP_W + c, w[c]); AP_SET(AP_A0 + c, a0[c]); AP_SET(AP_DIR + c, dir[c]); }
+  AP_SET(AP_NV0, nv0); AP_SET(AP_RHO, pp.rho);
+#define GEL_AERO_F(kind, al, qd) ((((kind) == 0) ? (al) : ((kind) == 1) ? (qd) : (qd) * (al)) * AP_GET(AP_ILIM + (kind)))
   // one gradient entry of every kind that has this node, from the perturbed pair (alpha, q): block offset `boff` (in units of R
   // rows: 0 position, 3 velocity, 6 quaternion, -1 = t: 6 + nq), `width` columns per row in the block, column `col`
 #define GEL_AERO_EMIT(boff, width, col, al, qd, skip_q, zero)                                                   \
   do {                                                                                                            \
+    const int k_ = ipark[0];                                                                                      \
     _Pragma("unroll") for (int kind = 0; kind < 3; kind++) {                                                      \
       if ((skip_q) && kind == 1) continue;                 /* dynamic pressure has no quaternion block */        \
-      const int row = Nd.row[kind];                                                                               \
-      if (!live || row < 0 || !O.jac[kind]) continue;                                                             \
+      if (ipark[(7 + kind) * 64] < 0) continue;                                                                   \
       const int R = O.nrows[kind], nq = (kind == 1) ? 0 : 4;                                                      \
       const int bo = ((boff) < 0) ? (6 + nq) : (boff);                                                            \
       double* jb = O.jac[kind] + (size_t)b * R * (8 + nq);                                                        \
-      const double gv = (zero) ? 0.0 : (fcen[kind] - GEL_AERO_F(kind, al, qd)) * inv_dx;                          \
-      jb[(size_t)bo * R + (width) * Nd.row0[kind] + (col) * Nd.nk[kind] + Nd.k] = gv;                             \
+      const double gv = (zero) ? 0.0 : (AP_GET(AP_FCEN + kind) - GEL_AERO_F(kind, al, qd)) * inv_dx;              \
+      jb[(size_t)bo * R + (width) * ipark[(1 + kind) * 64] + (col) * ipark[(4 + kind) * 64] + k_] = gv;           \
       chk += gv;                                                                                                  \
     }                                                                                                             \
   } while (0)
-#pragma unroll
-  for (int kind = 0; kind < 3; kind++) {
-    const int row = Nd.row[kind];
-    if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
-    const double cv = 1.0 - fcen[kind];
-    O.con[kind][(size_t)b * O.nrows[kind] + row] = cv;
-    chk += cv;
-  }
   if (want_jac) {
     // ---- t0 / tf columns
 #pragma unroll 1
     for (int c = (ROLES && sw != 0) ? 2 : 0; c < 2; c++) {
-      double al = alpha_c, qd = qdyn_c;
-      if (P.fd_recompute) {
-        const double to_p = (c == 0) ? to + dx : to, tf_p = (c == 1) ? tf + dx : tf;
-        const double tp = ((Nd.k == 0) ? to_p : (tau * (tf_p - to_p) / 2 + (tf_p + to_p) / 2)) * P.ut;
+      double al = 0.0, qd = 0.0;
+      if (P.fd_recompute) {   // audit form: the knot times and the node's abscissa are read again (not carried in registers)
+        const int kn = ipark[0], phn = nodes[ni].phase;
+        const double to2 = xb[11 * M + 2 * N + phn], tf2 = xb[11 * M + 2 * N + phn + 1];
+        const double tau2 = (kn == 0) ? 0.0 : P.tau[P.phases[phn].toff + kn - 1];
+        const double to_p = (c == 0) ? to2 + dx : to2, tf_p = (c == 1) ? tf2 + dx : tf2;
+        const double tp = ((kn == 0) ? to_p : (tau2 * (tf_p - to_p) / 2 + (tf_p + to_p) / 2)) * P.ut;
         const EarthAngle eq = earth_angle(tp);
         double wq[3], aq[3];
         wind_eci(r, eq, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, wq);
         const double nvq = aero_vair_eci(r, v, wq, aq);
-        al = need_alpha ? aero_alpha_dir(aq, nvq, dir) : 0.0;
+        const double dq_[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};
+        al = need_alpha ? aero_alpha_dir(aq, nvq, dq_) : 0.0;
         qd = 0.5 * pp.rho * nvq * nvq;
       }
       GEL_AERO_EMIT(-1, 2, c, al, qd, false, !P.fd_recompute);
@@ -495,8 +520,10 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   do {                                                                                               \
     double wq_[3], a_[3];                                                                            \
     wind_eci(rp, ea, (pq).shp, (pq).chp, (pq).inv_p, (pq).wn, (pq).we, wq_);                         \
-    const double nv_ = aero_vair_eci(rp, v, wq_, a_);                                                \
-    const double al_ = need_alpha ? aero_alpha_dir(a_, nv_, dir) : 0.0;                              \
+    const double vq_[3] = {xb[4 * M + 3 * xi] * P.uv, xb[4 * M + 3 * xi + 1] * P.uv, xb[4 * M + 3 * xi + 2] * P.uv}; \
+    const double nv_ = aero_vair_eci(rp, vq_, wq_, a_);                                              \
+    const double dq_[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};                  \
+    const double al_ = need_alpha ? aero_alpha_dir(a_, nv_, dq_) : 0.0;                              \
     GEL_AERO_EMIT(0, 3, c, al_, 0.5 * (pq).rho * nv_ * nv_, false, false);                           \
   } while (0)
     const unsigned mine = ROLES ? ((sw == 0) ? 0u : (1u << (sw - 1))) : 7u;   // this wavefront's position sweeps
@@ -505,6 +532,9 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
 #pragma unroll 1
       for (int c = 0; c < 3; c++) {
         if (!((mine >> c) & 1u)) continue;
+        asm volatile("" ::: "memory");
+        // the scaled position is formed where it is used (fresh_product: not carried across the trips), the velocity read again
+        const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
         double rp[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) rp[d] = (d == c) ? (re[d] + dx) * P.up : r[d];
@@ -536,9 +566,11 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       const double ve[3] = {xb[4 * M + 3 * xi], xb[4 * M + 3 * xi + 1], xb[4 * M + 3 * xi + 2]};
 #pragma unroll
       for (int d = 0; d < 3; d++) vp[d] = ((d == c) ? ve[d] + dx : ve[d]) * P.uv;
-      const double nv = aero_vair_eci(r, vp, w, a);
-      const double al = need_alpha ? aero_alpha_dir(a, nv, dir) : 0.0;
-      GEL_AERO_EMIT(3, 3, c, al, 0.5 * pp.rho * nv * nv, false, false);
+      const double wc[3] = {AP_GET(AP_W), AP_GET(AP_W + 1), AP_GET(AP_W + 2)};
+      const double dc[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};
+      const double nv = aero_vair_eci(r, vp, wc, a);
+      const double al = need_alpha ? aero_alpha_dir(a, nv, dc) : 0.0;
+      GEL_AERO_EMIT(3, 3, c, al, 0.5 * AP_GET(AP_RHO) * nv * nv, false, false);
     }
     // ---- quaternion sweeps
     if (need_alpha && !(ROLES && sw != 0)) {
@@ -549,17 +581,21 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
 #pragma unroll
         for (int d = 0; d < 4; d++) qp[d] = (d == c) ? q[d] + dx : q[d];
         thrust_dir(qp, dp);
-        GEL_AERO_EMIT(6, 4, c, aero_alpha_dir(a0, nv0, dp), qdyn_c, true, false);
+        const double ac[3] = {AP_GET(AP_A0), AP_GET(AP_A0 + 1), AP_GET(AP_A0 + 2)};
+        const double nvc = AP_GET(AP_NV0);
+        GEL_AERO_EMIT(6, 4, c, aero_alpha_dir(ac, nvc, dp), 0.5 * AP_GET(AP_RHO) * nvc * nvc, true, false);
       }
     }
   }
 #undef GEL_AERO_EMIT
 #undef GEL_AERO_F
+#undef AP_GET
+#undef AP_SET
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 
 #ifndef GEL_AERO_MIN_WAVES
-#define GEL_AERO_MIN_WAVES 2
+#define GEL_AERO_MIN_WAVES 3
 #endif
 __global__ __launch_bounds__(64 * kAeroWaves, GEL_AERO_MIN_WAVES) void aero_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
                                                                 int tiles, int B, const double* __restrict__ x, AeroOut O) {
@@ -572,7 +608,7 @@ hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes
   AeroOut O;
   for (int k = 0; k < 3; k++) { O.con[k] = out.con[k]; O.jac[k] = out.jac[k]; O.nrows[k] = out.nrows[k]; }
   const int tiles = (nnodes + 63) / 64;
-  const size_t lds = sizeof(double) * ((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1);
+  const size_t lds = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + (size_t)kAeroWaves * kAeroParkSlots * 64);
   const unsigned grid = (unsigned)(((long long)B * tiles + kAeroWaves - 1) / kAeroWaves);
   hipLaunchKernelGGL(aero_kernel, dim3(grid), dim3(64 * kAeroWaves), lds, s, P, nnodes, nodes, tiles, B, d_x, O);
   return hipGetLastError();
@@ -790,7 +826,7 @@ hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_
     rows_blocks = A.lin_blocks + (nfn * 8 + 255) / 256;
   }
   const size_t lds_eval = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(want_jac, P.use_mfma != 0, false, true) * 4);
-  const size_t lds_aero = sizeof(double) * ((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1);
+  const size_t lds_aero = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + (size_t)kAeroWaves * kAeroParkSlots * 64);
   const size_t lds = lds_eval > lds_aero ? lds_eval : lds_aero;
   const dim3 grid((unsigned)(A.nb_eval + A.nb_aero + rows_blocks));
   if (want_jac) {
