@@ -379,20 +379,33 @@ struct AeroOut {
 // store of a gradient block is one contiguous segment (which is what lets the B = 1 callback write straight into pinned
 // host memory).  Four wavefronts (four tiles) per workgroup.
 constexpr int kAeroWaves = 4;
-GEL_DEV double aero_vair_eci(const double r[3], const double v[3], const double w[3], double a[3]) {
+// air-relative velocity in ECI (wrapper_utils.hpp:93-100) and its SQUARED norm (q needs no root; alpha takes the reciprocal root)
+GEL_DEV double aero_vair2(const double r[3], const double v[3], const double w[3], double a[3]) {
   a[0] = (v[0] + kOmega * r[1]) - w[0]; a[1] = (v[1] - kOmega * r[0]) - w[1]; a[2] = v[2] - w[2];
-  return fsqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  return a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
 }
-// angle of attack (wrapper_utils.hpp:89-111) from the body axis d (thrust_dir(q)): the cosine as one dot product times the two
-// reciprocal norms (the reference divides component by component: <= 3 ulp of the cosine apart)
-GEL_DEV double aero_alpha_dir(const double a[3], double nv, const double d[3]) {
-  const double ind = frsqrt(fmax(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1.0e-300));
-  const double c_alpha = ((a[0] * d[0] + a[1] * d[1] + a[2] * d[2]) * frcp(fmax(nv, 1.0e-300))) * ind;
-  return (c_alpha > 1.0) ? 0.0 : ((nv < 1e-6) ? 0.0 : acos(c_alpha));
+// cosine of the angle of attack (wrapper_utils.hpp:101-106): one dot product times the two reciprocal norms (the reference divides
+// component by component: <= 3 ulp of the cosine apart); d = thrust_dir(q), ind = 1/|d|
+GEL_DEV double aero_cos(const double a[3], double nv2, const double d[3], double ind) {
+  return ((a[0] * d[0] + a[1] * d[1] + a[2] * d[2]) * frsqrt(fmax(nv2, 1.0e-300))) * ind;
+}
+// the reference's clamps (wrapper_utils.hpp:107-111): cos > 1 -> 0, |v_air| < 1e-6 -> 0
+GEL_DEV double aero_acos(double c, double nv2) { return (c > 1.0) ? 0.0 : ((nv2 < 1.0e-12) ? 0.0 : acos(c)); }
+// Exact-difference form of alpha: with c = cos(alpha_c), s = sin(alpha_c) and the perturbed cosine c_p,
+//   c_p - c = c (cos t - 1) - s sin t   =>   t = -(c_p - c)/s - (c / 2s) t^2 + t^3/6 - ...        (t = alpha_p - alpha_c)
+// solved by two substitutions (t ~ 1e-8 .. 1e-5: the third is below 1e-16 of t wherever the form is used).  One reciprocal
+// root and a dozen operations instead of a second acos.  false: a lane where the form does not apply (a clamp of the
+// reference is active at either point, sin(alpha) < 1e-6, or the step is not small against sin(alpha)).
+GEL_DEV bool aero_dalpha(double c_p, double nv2_p, double c_c, double inv_s, bool centre_ok, double& t) {
+  const double t0 = (c_c - c_p) * inv_s, k = (0.5 * c_c) * inv_s;
+  const double t1 = t0 - (k * t0) * t0;
+  t = (t0 - (k * t1) * t1) + (t1 * t1) * (t1 * (1.0 / 6.0));
+  return centre_ok && (c_p <= 1.0) && (nv2_p >= 1.0e-12) && (fabs(k * t0) < 1.0e-2);
 }
 
-// park slots of one wavefront (doubles; the last five hold 10 ints per lane)
-enum { AP_ILIM = 0, AP_FCEN = 3, AP_W = 6, AP_A0 = 9, AP_DIR = 12, AP_NV0 = 15, AP_RHO = 16, AP_INTS = 17, kAeroParkSlots = 22 };
+// park slots of one wavefront (doubles; the last six hold up to 12 ints per lane)
+enum { AP_ILIM = 0, AP_AC = 3, AP_QC, AP_CC, AP_IS, AP_IND, AP_W = 8, AP_A0 = 11, AP_DIR = 14, AP_RHO = 17, AP_NV2 = 18, AP_INTS = 19,
+       kAeroParkSlots = 25 };
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) double lds_f64;
 // ROLES (the B = 1 callback launch, where the length of one wavefront's chain is what counts): the four wavefronts of a
@@ -416,72 +429,89 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   const double* xb = x + (size_t)b * P.nvars;
   const int M = P.M, N = P.N, xi = ph.xa + Nd.k;
   const double dx = P.dx;
-  double re[3], ve[3], q[4];
+  double re[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) { re[c] = xb[M + 3 * xi + c]; ve[c] = xb[4 * M + 3 * xi + c]; }
-#pragma unroll
-  for (int c = 0; c < 4; c++) q[c] = xb[7 * M + 4 * xi + c];
-  const double to = xb[11 * M + 2 * N + Nd.phase], tf = xb[11 * M + 2 * N + Nd.phase + 1];
-  const double tau = (Nd.k == 0) ? 0.0 : P.tau[ph.toff + Nd.k - 1];
-  // PSparams.time_nodes (SectionParameters.py:77-81): node 0 is t0 itself; t in seconds here (con_aero.py:45)
-  const double t = ((Nd.k == 0) ? to : (tau * (tf - to) / 2 + (tf + to) / 2)) * P.ut;
+  for (int c = 0; c < 3; c++) re[c] = xb[M + 3 * xi + c];
   const bool want_jac = O.jac[0] || O.jac[1] || O.jac[2];
   // does any lane of this wavefront have an alpha or q-alpha row?  (wave-uniform)
   const bool need_alpha = __builtin_amdgcn_ballot_w64(live && ((O.con[0] && Nd.row[0] >= 0) || (O.con[2] && Nd.row[2] >= 0))) != 0;
-  // ---- centre (con_aero.py:39-87: scale, evaluate)
-  double r[3], v[3];
-#pragma unroll
-  for (int c = 0; c < 3; c++) { r[c] = re[c] * P.up; v[c] = ve[c] * P.uv; }
-  PosCentre pc;
-  PosCentreTail pt;
-  PosPart pp = pos_part<true, PosCentreSink, false>(r, tb, 0.0, nullptr, PosCentreSink{&pc}, &pt);
-  pos_centre_tail(pt, pp.rho, pp.P, tb, pc, pp.wn, pp.we);
-  const EarthAngle ea = earth_angle(t);
-  double w[3], a0[3], dir[3];
-  wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
-  const double nv0 = aero_vair_eci(r, v, w, a0);
-  thrust_dir(q, dir);
-  const double alpha_c = need_alpha ? aero_alpha_dir(a0, nv0, dir) : 0.0;
-  const double qdyn_c = 0.5 * pp.rho * nv0 * nv0;
-  double chk = 0.0;
-  // f / units[3] (con_aero.py:85-87) as f * (1 / units[3]) (one rounding apart from the division); con = 1 - f (:127-139);
-  // jac = -(f_p - f_c)/dx (:437-463)
-  const double inv_dx = 1.0 / dx;
-  // The park: this wavefront's [slot][lane] region of LDS behind the tables.  What every store needs (1/limit, the centre's f,
-  // the node's rows) and what only the light sweeps need (centre wind, air velocity, body axis) wait there instead of in
-  // registers across the position sweeps: 234 -> fewer VGPRs, one more wavefront per SIMD.
+  // The park: this wavefront's [slot][lane] region of LDS behind the tables.  What every store needs (1/limit, the centre's alpha,
+  // q, cos, 1/sin, the node's rows) and what only the light sweeps need (centre wind, air velocity, body axis) wait there
+  // instead of in registers across the position sweeps (234 -> 164 VGPRs).
   lds_f64* park = (lds_f64*)lds + ((table_doubles(P.Kw, P.Kc) + 1) & ~1) + (size_t)(threadIdx.x >> 6) * (kAeroParkSlots * 64) + lane;
-  lds_int* ipark = (lds_int*)(park - lane + AP_INTS * 64) + lane;      // [10][64] ints: k, row0[3], nk[3], row[3]
+  lds_int* ipark = (lds_int*)(park - lane + AP_INTS * 64) + lane;      // ints: k, row0[3], nk[3], row[3] (or -1), centre_ok
 #define AP_GET(i) (park[(i) * 64])
 #define AP_SET(i, v) (park[(i) * 64] = (v))
+  // ---- centre (con_aero.py:39-87: scale, evaluate)
+  PosCentre pc;
+  PosPart pp;
+  EarthAngle ea;
+  double chk = 0.0;
   {
-    double fc_[3];
+    double r[3], v[3], q[4], w[3], a0[3], dir[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { r[c] = re[c] * P.up; v[c] = xb[4 * M + 3 * xi + c] * P.uv; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = xb[7 * M + 4 * xi + c];
+    PosCentreTail pt;
+    pp = pos_part<true, PosCentreSink, false>(r, tb, 0.0, nullptr, PosCentreSink{&pc}, &pt);
+    pos_centre_tail(pt, pp.rho, pp.P, tb, pc, pp.wn, pp.we);
+    {
+      const double to = xb[11 * M + 2 * N + Nd.phase], tf = xb[11 * M + 2 * N + Nd.phase + 1];
+      const double tau = (Nd.k == 0) ? 0.0 : P.tau[ph.toff + Nd.k - 1];
+      // PSparams.time_nodes (SectionParameters.py:77-81): node 0 is t0 itself; t in seconds here (con_aero.py:45)
+      ea = earth_angle(((Nd.k == 0) ? to : (tau * (tf - to) / 2 + (tf + to) / 2)) * P.ut);
+    }
+    wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
+    const double nv2 = aero_vair2(r, v, w, a0);
+    thrust_dir(q, dir);
+    const double ind = frsqrt(fmax(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2], 1.0e-300));
+    const double cc = need_alpha ? aero_cos(a0, nv2, dir, ind) : 0.0;
+    const double alpha_c = need_alpha ? aero_acos(cc, nv2) : 0.0;
+    const double qdyn_c = 0.5 * pp.rho * nv2;                       // 0.5 rho |v_air|^2 (wrapper_utils.hpp:163-175)
+    double sc, isc;
+    fsqrt_rsqrt(fmax((1.0 - cc) * (1.0 + cc), 1.0e-300), sc, isc);  // sin(alpha_c) and its reciprocal
+    const bool centre_ok = (cc <= 1.0) && (nv2 >= 1.0e-12) && (sc > 1.0e-6);
+    // f / units[3] (con_aero.py:85-87) as f * (1 / units[3]) (one rounding apart from the division); con = 1 - f (:127-139)
 #pragma unroll
     for (int kind = 0; kind < 3; kind++) {
       const double il = frcp(Nd.limit[kind]);
-      fc_[kind] = ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
-      AP_SET(AP_ILIM + kind, il); AP_SET(AP_FCEN + kind, fc_[kind]);
+      AP_SET(AP_ILIM + kind, il);
       ipark[(1 + kind) * 64] = Nd.row0[kind]; ipark[(4 + kind) * 64] = Nd.nk[kind];
       ipark[(7 + kind) * 64] = (live && O.jac[kind]) ? Nd.row[kind] : -1;
-    }
-    ipark[0] = Nd.k;
-#pragma unroll
-    for (int kind = 0; kind < 3; kind++) {     // the constraint values (con_aero.py:127-139)
       const int row = Nd.row[kind];
       if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
-      const double cv = 1.0 - fc_[kind];
+      const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
       O.con[kind][(size_t)b * O.nrows[kind] + row] = cv;
       chk += cv;
     }
-  }
+    ipark[0] = Nd.k; ipark[10 * 64] = centre_ok ? 1 : 0;
+    AP_SET(AP_AC, alpha_c); AP_SET(AP_QC, qdyn_c); AP_SET(AP_CC, cc); AP_SET(AP_IS, isc); AP_SET(AP_IND, ind);
 #pragma unroll
-  for (int c = 0; c < 3; c++) { AP_SET(AP_W + c, w[c]); AP_SET(AP_A0 + c, a0[c]); AP_SET(AP_DIR + c, dir[c]); }
-  AP_SET(AP_NV0, nv0); AP_SET(AP_RHO, pp.rho);
-#define GEL_AERO_F(kind, al, qd) ((((kind) == 0) ? (al) : ((kind) == 1) ? (qd) : (qd) * (al)) * AP_GET(AP_ILIM + (kind)))
-  // one gradient entry of every kind that has this node, from the perturbed pair (alpha, q): block offset `boff` (in units of R
-  // rows: 0 position, 3 velocity, 6 quaternion, -1 = t: 6 + nq), `width` columns per row in the block, column `col`
-#define GEL_AERO_EMIT(boff, width, col, al, qd, skip_q, zero)                                                   \
+    for (int c = 0; c < 3; c++) { AP_SET(AP_W + c, w[c]); AP_SET(AP_A0 + c, a0[c]); AP_SET(AP_DIR + c, dir[c]); }
+    AP_SET(AP_RHO, pp.rho); AP_SET(AP_NV2, nv2);
+  }
+  const double inv_dx = 1.0 / dx;
+  // One gradient entry of every kind that has this node, jac = -(f_p - f_c)/dx (con_aero.py:437-463), from the perturbed point's
+  // air velocity a (squared norm nv2), body axis d (1/|d| = ind) and density: alpha_p - alpha_c in exact-difference form
+  // (aero_dalpha; a wavefront with a lane it does not cover takes two acos like the reference), q_p - q_c as it is, and
+  //   alpha:   d f = t / limit        q:   d f = (q_p - q_c) / limit        q alpha:   d f = (q_p t + (q_p - q_c) alpha_c) / limit
+  // (q_p alpha_p - q_c alpha_c, regrouped).  Block offset `boff` in units of R rows (0 position, 3 velocity, 6 quaternion, -1 = t:
+  // 6 + nq), `width` columns per row, column `col`; zero: the entry is an exact zero.
+#define GEL_AERO_EMIT(boff, width, col, a, nv2, d, ind, rho, skip_q, zero)                                        \
   do {                                                                                                            \
+    double t_ = 0.0, dq_ = 0.0, qp_ = 0.0;                                                                        \
+    const double ac_ = AP_GET(AP_AC);                                                                             \
+    if (!(zero)) {                                                                                                \
+      const double qc_ = AP_GET(AP_QC);                                                                           \
+      qp_ = 0.5 * (rho) * (nv2);                                                                                  \
+      dq_ = qp_ - qc_;                                                                                            \
+      if (need_alpha) {                                                                                           \
+        const double cp_ = aero_cos(a, nv2, d, ind);                                                              \
+        if (__builtin_amdgcn_ballot_w64(!aero_dalpha(cp_, nv2, AP_GET(AP_CC), AP_GET(AP_IS), ipark[10 * 64] != 0, t_)) != 0) \
+          t_ = aero_acos(cp_, nv2) - ac_;                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
     const int k_ = ipark[0];                                                                                      \
     _Pragma("unroll") for (int kind = 0; kind < 3; kind++) {                                                      \
       if ((skip_q) && kind == 1) continue;                 /* dynamic pressure has no quaternion block */        \
@@ -489,7 +519,8 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       const int R = O.nrows[kind], nq = (kind == 1) ? 0 : 4;                                                      \
       const int bo = ((boff) < 0) ? (6 + nq) : (boff);                                                            \
       double* jb = O.jac[kind] + (size_t)b * R * (8 + nq);                                                        \
-      const double gv = (zero) ? 0.0 : (AP_GET(AP_FCEN + kind) - GEL_AERO_F(kind, al, qd)) * inv_dx;              \
+      const double df_ = (kind == 0) ? t_ : ((kind == 1) ? dq_ : qp_ * t_ + dq_ * ac_);                           \
+      const double gv = (zero) ? 0.0 : -(df_ * AP_GET(AP_ILIM + kind)) * inv_dx;                                  \
       jb[(size_t)bo * R + (width) * ipark[(1 + kind) * 64] + (col) * ipark[(4 + kind) * 64] + k_] = gv;           \
       chk += gv;                                                                                                  \
     }                                                                                                             \
@@ -498,7 +529,6 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     // ---- t0 / tf columns
 #pragma unroll 1
     for (int c = (ROLES && sw != 0) ? 2 : 0; c < 2; c++) {
-      double al = 0.0, qd = 0.0;
       if (P.fd_recompute) {   // audit form: the knot times and the node's abscissa are read again (not carried in registers)
         const int kn = ipark[0], phn = nodes[ni].phase;
         const double to2 = xb[11 * M + 2 * N + phn], tf2 = xb[11 * M + 2 * N + phn + 1];
@@ -506,14 +536,17 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
         const double to_p = (c == 0) ? to2 + dx : to2, tf_p = (c == 1) ? tf2 + dx : tf2;
         const double tp = ((kn == 0) ? to_p : (tau2 * (tf_p - to_p) / 2 + (tf_p + to_p) / 2)) * P.ut;
         const EarthAngle eq = earth_angle(tp);
+        const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
+        const double vq[3] = {xb[4 * M + 3 * xi] * P.uv, xb[4 * M + 3 * xi + 1] * P.uv, xb[4 * M + 3 * xi + 2] * P.uv};
         double wq[3], aq[3];
         wind_eci(r, eq, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, wq);
-        const double nvq = aero_vair_eci(r, v, wq, aq);
-        const double dq_[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};
-        al = need_alpha ? aero_alpha_dir(aq, nvq, dq_) : 0.0;
-        qd = 0.5 * pp.rho * nvq * nvq;
+        const double nvq = aero_vair2(r, vq, wq, aq);
+        const double dq[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};
+        GEL_AERO_EMIT(-1, 2, c, aq, nvq, dq, AP_GET(AP_IND), pp.rho, false, false);
+      } else {
+        const double none[3] = {0.0, 0.0, 0.0};
+        GEL_AERO_EMIT(-1, 2, c, none, 0.0, none, 0.0, 0.0, false, true);
       }
-      GEL_AERO_EMIT(-1, 2, c, al, qd, false, !P.fd_recompute);
     }
     // ---- position sweeps
 #define GEL_AERO_POS_TAIL(c, rp, pq)                                                                 \
@@ -521,10 +554,9 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     double wq_[3], a_[3];                                                                            \
     wind_eci(rp, ea, (pq).shp, (pq).chp, (pq).inv_p, (pq).wn, (pq).we, wq_);                         \
     const double vq_[3] = {xb[4 * M + 3 * xi] * P.uv, xb[4 * M + 3 * xi + 1] * P.uv, xb[4 * M + 3 * xi + 2] * P.uv}; \
-    const double nv_ = aero_vair_eci(rp, vq_, wq_, a_);                                              \
-    const double dq_[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};                  \
-    const double al_ = need_alpha ? aero_alpha_dir(a_, nv_, dq_) : 0.0;                              \
-    GEL_AERO_EMIT(0, 3, c, al_, 0.5 * (pq).rho * nv_ * nv_, false, false);                           \
+    const double nv2_ = aero_vair2(rp, vq_, wq_, a_);                                                \
+    const double dd_[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};                  \
+    GEL_AERO_EMIT(0, 3, c, a_, nv2_, dd_, AP_GET(AP_IND), (pq).rho, false, false);                   \
   } while (0)
     const unsigned mine = ROLES ? ((sw == 0) ? 0u : (1u << (sw - 1))) : 7u;   // this wavefront's position sweeps
     unsigned todo = P.fd_recompute ? mine : 0u;   // sweeps with a lane the difference form does not cover (wave-uniform)
@@ -558,37 +590,33 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     }
 #undef GEL_AERO_POS_TAIL
     asm volatile("" ::: "memory");   // the light sweeps read their inputs again
-    // ---- velocity sweeps: [component][node] per spec
+    // ---- velocity sweeps: only the air-relative velocity changes
 #pragma unroll 1
     for (int c = (ROLES && sw != 0) ? 3 : 0; c < 3; c++) {
       double vp[3], a[3];
       const double r[3] = {xb[M + 3 * xi] * P.up, xb[M + 3 * xi + 1] * P.up, xb[M + 3 * xi + 2] * P.up};
-      const double ve[3] = {xb[4 * M + 3 * xi], xb[4 * M + 3 * xi + 1], xb[4 * M + 3 * xi + 2]};
 #pragma unroll
-      for (int d = 0; d < 3; d++) vp[d] = ((d == c) ? ve[d] + dx : ve[d]) * P.uv;
+      for (int d = 0; d < 3; d++) vp[d] = ((d == c) ? xb[4 * M + 3 * xi + d] + dx : xb[4 * M + 3 * xi + d]) * P.uv;
       const double wc[3] = {AP_GET(AP_W), AP_GET(AP_W + 1), AP_GET(AP_W + 2)};
       const double dc[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};
-      const double nv = aero_vair_eci(r, vp, wc, a);
-      const double al = need_alpha ? aero_alpha_dir(a, nv, dc) : 0.0;
-      GEL_AERO_EMIT(3, 3, c, al, 0.5 * AP_GET(AP_RHO) * nv * nv, false, false);
+      const double nv2 = aero_vair2(r, vp, wc, a);
+      GEL_AERO_EMIT(3, 3, c, a, nv2, dc, AP_GET(AP_IND), AP_GET(AP_RHO), false, false);
     }
-    // ---- quaternion sweeps
+    // ---- quaternion sweeps: only the body axis changes
     if (need_alpha && !(ROLES && sw != 0)) {
 #pragma unroll 1
       for (int c = 0; c < 4; c++) {
         double qp[4], dp[3];
-        const double q[4] = {xb[7 * M + 4 * xi], xb[7 * M + 4 * xi + 1], xb[7 * M + 4 * xi + 2], xb[7 * M + 4 * xi + 3]};
 #pragma unroll
-        for (int d = 0; d < 4; d++) qp[d] = (d == c) ? q[d] + dx : q[d];
+        for (int d = 0; d < 4; d++) qp[d] = (d == c) ? xb[7 * M + 4 * xi + d] + dx : xb[7 * M + 4 * xi + d];
         thrust_dir(qp, dp);
+        const double indp = frsqrt(fmax(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2], 1.0e-300));
         const double ac[3] = {AP_GET(AP_A0), AP_GET(AP_A0 + 1), AP_GET(AP_A0 + 2)};
-        const double nvc = AP_GET(AP_NV0);
-        GEL_AERO_EMIT(6, 4, c, aero_alpha_dir(ac, nvc, dp), 0.5 * AP_GET(AP_RHO) * nvc * nvc, true, false);
+        GEL_AERO_EMIT(6, 4, c, ac, AP_GET(AP_NV2), dp, indp, AP_GET(AP_RHO), true, false);
       }
     }
   }
 #undef GEL_AERO_EMIT
-#undef GEL_AERO_F
 #undef AP_GET
 #undef AP_SET
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
