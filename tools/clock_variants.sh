@@ -27,6 +27,7 @@ if not ids:
 m = lambda k: sum(cnt[k][i] for i in ids) / len(ids)
 d = sum(dur[i] for i in ids) / len(ids)
 cyc = m("GRBM_GUI_ACTIVE") / 8
+print("(%d launches averaged) " % len(ids), end="")
 print("%-16s %.4f ms  %.3f Mcycles  clock %.3f GHz  VALU busy %.1f%%  VALU insts/wave %.0f  wait_any %.1f%% wait_inst %.1f%%" % (
     name, d / 1e6, cyc / 1e6, cyc / d, 100 * m("SQ_ACTIVE_INST_VALU") * 4 / 1024 / cyc, m("SQ_INSTS_VALU") / max(m("SQ_WAVES") if "SQ_WAVES" in cnt else 98304, 1),
     100 * m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES"), 100 * m("SQ_WAIT_INST_ANY") / m("SQ_WAVE_CYCLES")), " MFMA busy %.1f%%" % (100 * m("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / cyc) if "SQ_VALU_MFMA_BUSY_CYCLES" in cnt else "")

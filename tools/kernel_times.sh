@@ -24,10 +24,11 @@ except Exception as e:
 print("%-12s %s" % (name, v))
 tot = 0.0
 for k, v in sorted(d.items()):
+    n_all = len(v)
     v = sorted(v)[-20:]
     avg = sum(b - a for a, b in v) / len(v) / 1e6
     tot += avg
-    print("   <%s>  %.4f ms" % (k, avg))
+    print("   <%s>  %.4f ms  (mean of the last %d of %d launches)" % (k, avg, len(v), n_all))
 print("   sum %.4f ms" % tot)
 PY
 done

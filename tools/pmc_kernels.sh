@@ -32,7 +32,7 @@ for grp in "abc":
             if k in keep and int(r["Dispatch_Id"]) in keep[k]:
                 m = re.search(r"eval_kernel<([^>]*)>", k)
                 a = agg.setdefault(m.group(1) if m else k, {})
-                a[r["Counter_Name"]] = a.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"]) / 10.0
+                a[r["Counter_Name"]] = a.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"]) / len(keep[k])   # mean over the launches kept
         if grp == "a":
             for k, v in keep.items():
                 m = re.search(r"eval_kernel<([^>]*)>", k)
