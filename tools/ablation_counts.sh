@@ -1,3 +1,4 @@
+# ablation builds (tools/build_variants.sh) under rocprofv3 --pmc: VALU / store instructions per wavefront and kernel time.  VARIANTS="base novel ..." tools/ablation_counts.sh
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for n in ${VARIANTS:-base novel nopos noqm lean nodx nostore}; do

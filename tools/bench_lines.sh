@@ -1,5 +1,5 @@
+# the four BASELINE bench lines, one summary line each (box-to-box spread): tools/bench_lines.sh
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "^FAILED|^ERROR|passed|failed|Error|assert" | head -20
 for a in "" "--workload dense-6x64" "--workload stress-12x128 --batch 16384" "--workload 3x32 --residual-only --batch 65536"; do
 python3 bench.py --no-cpu-baseline --no-extras $a 2>/dev/null | python3 -c "
 import json,sys

@@ -1,3 +1,4 @@
+# the whole record of a round: tools/record_all.sh + tools/record_others.sh, then one summary line per workload
 cd $GRAFT_REPO_ROOT
 tools/record_all.sh r03 > gpurun_out/record_r03.log 2>&1
 tools/record_others.sh r03 > gpurun_out/others_r03.log 2>&1
