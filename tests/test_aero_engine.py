@@ -157,3 +157,30 @@ def test_all_kinds_in_one_launch_equal_the_single_kind_calls():
     E.aero_configure("q", [])
     con3, jac3, _ = E.eval_aero_all(X)
     assert sorted(con3) == ["alpha", "qalpha"] and np.array_equal(con3["alpha"], con["alpha"]) and np.array_equal(jac3["qalpha"], jac["qalpha"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 8])
+def test_callback_form_of_the_aero_rows_equals_the_batch_form(flags):
+    """B = 1 inside the callback launch runs four wavefronts per tile (centre + light sweeps | one position sweep each), the batch
+    kernel one wavefront per tile: same operations on the same operands -- the same bits, in the exact-difference form and with
+    GEL_FLAG_FD_RECOMPUTE (position and t sweeps re-run like the reference)."""
+    from gelato_amd import Engine
+    g = load_golden("g9_aero_example.npz")
+    prob = problem_from_golden(g)
+    D, tau = D_tau_from_golden(g, prob)
+    E = Engine(prob, D=D, tau=tau, flags=flags)
+    for kind in KINDS:
+        E.aero_configure(kind, spec_from_golden(g, "synthetic", kind))
+    x = g["x"] * (1.0 + 3e-7)
+    fr = E.eval_callback(x, True)
+    con, jac, rc = E.eval_aero_all(x[None, :])
+    assert fr["rc"] == 0 and rc == 0
+    for kind in KINDS:
+        assert np.array_equal(fr["aero_con"][kind], con[kind][0]) and np.array_equal(fr["aero_jac"][kind], jac[kind][0]), kind
+        nrow, nnz = E.aero_dims(kind)
+        t_block = jac[kind][0][sum(nnz[:3]):]
+        if flags == 0:
+            assert not t_block.any()                     # the exact value
+        elif kind == "q":
+            assert t_block.any()                         # the sweeps are run: rounding noise around zero, like the reference's
