@@ -47,7 +47,8 @@ def g9_cases():
 
 def state_cases():
     for name, build in (("ragged", states.ragged_state), ("polar", lambda: states.with_coast_tail(states.polar_dense_state)),
-                        ("layers", lambda: states.with_coast_tail(states.all_layers_state))):
+                        ("layers", lambda: states.with_coast_tail(states.all_layers_state)),
+                        ("breaks", lambda: states.with_coast_tail(states.layer_break_state))):
         prob, x = build()
         P = oracle.Problem(prob)
         prob = dict(prob)

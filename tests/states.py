@@ -139,3 +139,38 @@ def with_coast_tail(build, n_tail=2):
     rep = n_tail + 1
     return prob, np.concatenate([mass, np.repeat(mass[-1:], rep), pos, np.tile(pos[-3:], rep), vel, np.tile(vel[-3:], rep),
                                  quat, np.tile(quat[-4:], rep), u, np.zeros(2 * n_tail), t, [t[-1] + 0.01]])
+
+
+def layer_break_state():
+    """One aerodynamic phase whose nodes sit within a few centimetres of the breaks of the atmosphere layers (geopotential 11, 20, 32, 47,
+    51, 71 km), of the geopotential branch (86 km geometric) and of the wind table's pieces (1, 3, 11, 15, 16, 23 km): the position
+    step of a sweep (dx * unit = 6.4 cm) carries some of them across -- what the exact-difference forms hand back to the recomputing
+    sweeps.  Mid latitudes, 400 .. 3000 m/s."""
+    prob = _example_prob()
+    rng = np.random.default_rng(5)
+    r0 = 6356766.0
+    breaks_h = [11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0, 1000.0, 3000.0, 15000.0, 16000.0, 23000.0]
+    alt = [r0 * h / (r0 - h) + off for h in breaks_h for off in (-0.04, -0.004, 0.004, 0.04)] + [86000.0 + off for off in (-0.04, -0.004, 0.004, 0.04)]
+    alt = np.array(alt + [5000.0])
+    n = len(alt) - 1
+    prob["num_nodes"] = np.array([n], dtype=np.int32)
+    for k, v in [("thrust", 420000.0), ("massflow", 140.9), ("reference_area", 2.21), ("nozzle_area", 0.68)]:
+        prob[k] = np.array([v])
+    prob["engine_on"] = np.array([1], dtype=np.int32)
+    prob["attitude_hold"] = np.array([0], dtype=np.int32)
+    up, uv, ut = prob["units"][1], prob["units"][2], prob["units"][4]
+    lat = rng.uniform(-1.0, 1.0, n + 1)
+    lon = rng.uniform(-np.pi, np.pi, n + 1)
+    a_e, b_e = 6378137.0, 6356752.314245
+    # geodetic latitude `lat`, altitude `alt` exactly (to rounding): x = (N + alt) cos lat cos lon, z = (N (1 - e^2) + alt) sin lat
+    e2 = 1.0 - (b_e / a_e) ** 2
+    Np = a_e / np.sqrt(1.0 - e2 * np.sin(lat) ** 2)
+    pos = np.column_stack([(Np + alt) * np.cos(lat) * np.cos(lon), (Np + alt) * np.cos(lat) * np.sin(lon), (Np * (1.0 - e2) + alt) * np.sin(lat)]) / up
+    speed = rng.uniform(400.0, 3000.0, n + 1) / uv
+    d = rng.standard_normal((n + 1, 3))
+    vel = d / np.linalg.norm(d, axis=1, keepdims=True) * speed[:, None]
+    quat = rng.standard_normal((n + 1, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    x = np.concatenate([np.linspace(1.0, 0.5, n + 1), pos.ravel(), vel.ravel(), quat.ravel(),
+                        2.0 * rng.standard_normal(2 * n), [10.0 / ut, 160.0 / ut]])
+    return prob, x

@@ -21,7 +21,7 @@ from test_aero_oracle_golden import KINDS, VARS, spec_from_golden
 
 COLS = {"position": slice(0, 3), "velocity": slice(3, 6), "quaternion": slice(6, 10), "t": slice(10, 12)}
 LIMITS = {"alpha": 0.2, "q": 4.0e4, "qalpha": 5.0e3}
-CASES = ["g9_example", "g9_synthetic", "ragged", "polar", "layers"]
+CASES = ["g9_example", "g9_synthetic", "ragged", "polar", "layers", "breaks"]
 
 
 def case(name):
@@ -34,7 +34,8 @@ def case(name):
         prob["tau"] = tau
         return prob, D, g["x"], {k: spec_from_golden(g, name[3:], k) for k in KINDS}, g
     build = {"ragged": states.ragged_state, "polar": lambda: states.with_coast_tail(states.polar_dense_state),
-             "layers": lambda: states.with_coast_tail(states.all_layers_state)}[name]
+             "layers": lambda: states.with_coast_tail(states.all_layers_state),
+             "breaks": lambda: states.with_coast_tail(states.layer_break_state)}[name]
     prob, x = build()
     P = oracle.Problem(prob)
     prob = dict(prob)

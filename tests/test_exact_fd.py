@@ -26,7 +26,7 @@ def example_state():
 
 
 STATES = {"example": example_state, "ragged": states.ragged_state, "polar": states.polar_dense_state,
-          "layers": states.all_layers_state, "long": lambda: states.long_state((87, 129, 64))}
+          "layers": states.all_layers_state, "long": lambda: states.long_state((87, 129, 64)), "breaks": states.layer_break_state}
 VARS = ["mass", "position", "velocity", "quaternion"]
 
 
