@@ -153,13 +153,16 @@ class _Rows:
                 r = len(lin) - k0
                 lin.append((o["mass"] + ig, -1.0, o["mass"] + co, 1.0, d_mass / unitdict["mass"]))
                 rows += [r, r]; cols += [ig, co]; vals += [-1.0, 1.0]
-            else:
-                # the reference looks the two events up by name and raises IndexError when one is missing
-                # (lib/con_trajectory.py:40-49); the cut-down event lists of the synthetic bench meshes lack some on purpose,
-                # so the stage's row is left out here -- but never silently
+            elif pdict.get("gelato_amd_allow_missing_stage_events"):
+                # the cut-down event lists of the synthetic bench meshes (problem.make_problem) lack some stages' events on
+                # purpose and say so with this key: the stage's row is left out, with a warning
                 import warnings
                 warnings.warn("inequality_mass: stage without its ignition_at / cutoff_at events (%r, %r) in the event list: "
                               "no propellant limit row for it" % (stage.get("ignition_at"), stage.get("cutoff_at")), stacklevel=2)
+            else:
+                # the reference looks the two events up by name and indexes the empty match list (lib/con_trajectory.py:40-49)
+                raise IndexError("inequality_mass: RocketStage events %r / %r are not section names (lib/con_trajectory.py:40-49 "
+                                 "raises IndexError too)" % (stage.get("ignition_at"), stage.get("cutoff_at")))
         self.slices["imass"] = (k0, len(lin))
         self.jac["imass"] = {"mass": _coo(rows, cols, vals, (len(lin) - k0, M))}
         # inequality_kickturn (:106-125): the pitch rate of a kick-turn section is not positive; Jacobian :128-160

@@ -15,8 +15,13 @@ ground antenna (fn 14) -- with its forward difference over position, velocity an
 the reference's scaling of value and difference.  One launch per callback evaluates all of them together with the other
 rows; the functions here slice the shared frame.  xdict is never mutated (the reference perturbs views of it in place).
 
-Not offered: the "downrange" rows.  Every one of their Jacobian blocks in the reference appends the t entry to the
-position list (con_waypoint.py:702-706,915-919,932-936), so the reference itself cannot assemble them.
+The "downrange" rows (Vincenty distance from the launch point, fn 15): values exactly as the reference computes them
+(con_waypoint.py:531-534,551-554,742,771-778 -- including its `max` row, which divides by the `min` bound, :778, and
+therefore needs one).  Their Jacobian blocks come in the form the reference intended: downrange_gradient (:583-607)
+scaled like the value (`/ exact`, `/ min`, `-... / min`), position entries on the position list and the t entry on the
+t list.  The reference itself appends the t VALUE to the position list (:702-706,915-919,932-936: four values for three
+index pairs, none for the t pair) and scales the `max` row's t entry by the `max` bound although its value uses `min`;
+tests/test_waypoint.py unscrambles its lists to check every number against the reference's own output.
 """
 import math
 
@@ -68,12 +73,8 @@ def build_rows(pdict, condition, xa):
             if names[i] not in wp:
                 continue
             w = wp[names[i]]
-            if "downrange" in w:
-                raise NotImplementedError(
-                    "waypoint %r: downrange rows are not offered -- the reference cannot assemble their Jacobian "
-                    "(lib/con_waypoint.py:702-706,915-919,932-936)" % names[i])
             specs = (("latitude_deg", "lat", 90.0, "pos"), ("longitude_deg", "lon", 180.0, "pos"),
-                     ("altitude", "altitude", None, "pos"),
+                     ("altitude", "altitude", None, "pos"), ("downrange", "downrange", None, "pos"),
                      ("lat_IIP_deg", "lat_IIP", 90.0, "iip"), ("lon_IIP_deg", "lon_IIP", 180.0, "iip"))
             for f, key, scale, fam in specs:
                 if key not in w:
@@ -84,7 +85,12 @@ def build_rows(pdict, condition, xa):
                     bound = float(w[key][kind])
                     grp = ("eq" if kind == "exact" else "ineq") + fam
                     neg = NEG if kind == "max" else 0
-                    if scale is None:                               # f / bound - 1 (:549,766,769); difference / bound
+                    if f == "downrange":                            # downrange / bound - 1 (:554,774); max: -(downrange / MIN) + 1 (:778)
+                        if kind == "max":
+                            bound = float(w[key]["min"])            # KeyError without a min bound, as in the reference
+                        lc = pdict["LaunchCondition"]               # :533-534
+                        row = (f, xa[i], i, RAW | neg, [bound, 1.0, float(lc["lat"]), float(lc["lon"])])
+                    elif scale is None:                             # f / bound - 1 (:549,766,769); difference / bound
                         row = (f, xa[i], i, RAW | neg, [bound, 1.0])
                     else:                                           # (f - bound) / scale (:539,544,749-759)
                         row = (f, xa[i], i, SH | RAW | neg, [scale, bound])
@@ -124,9 +130,11 @@ def _jac(xdict, pdict, unitdict, condition, group, with_velocity):
             np.repeat(np.arange(n, dtype=np.int32), 3), np.array([3 * node + c for (_, _, node, _) in meta for c in range(3)], dtype=np.int32),
             np.arange(n, dtype=np.int32), np.array([sec for (_, sec, _, _) in meta], dtype=np.int32))
     rows3, cols3, rows1, secs = pat
-    jac = {"position": {"coo": [rows3, cols3, jfn[:, 0:3].ravel()], "shape": (n, 3 * M)}}     # ravel of a column slice: a copy
+    # fresh arrays per call: ravel() of a column slice copies only when the group has more than one row (a one-row slice is
+    # contiguous and would be a view of the buffer the next callback overwrites)
+    jac = {"position": {"coo": [rows3, cols3, np.array(jfn[:, 0:3]).ravel()], "shape": (n, 3 * M)}}
     if with_velocity:
-        jac["velocity"] = {"coo": [rows3, cols3, jfn[:, 3:6].ravel()], "shape": (n, 3 * M)}
+        jac["velocity"] = {"coo": [rows3, cols3, np.array(jfn[:, 3:6]).ravel()], "shape": (n, 3 * M)}
     jac["t"] = {"coo": [rows1, secs, jfn[:, 6].copy()], "shape": (n, S + 1)}
     return jac
 

@@ -1029,10 +1029,10 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #ifndef GEL_ABL_NOPOS
       if (JAC && (!SPLIT || part)) {
         const int k0 = SPLIT ? part - 1 : 0, k1 = SPLIT ? part : 3;
-        // the tail of a sweep, given the position part at the perturbed point
-#define GEL_POS_SWEEP_TAIL(kk, rp, pq)                                                                        \
+        // the tail of a sweep, given the position part at the perturbed point: the perturbed RHS value f_
+#define GEL_POS_SWEEP_F(rp, pq, f_)                                                                           \
   do {                                                                                                        \
-    double wq_[3], Fp_[3], f_[3];                                                                             \
+    double wq_[3], Fp_[3];                                                                                    \
     GEL_NEED_EARTH_ANGLE((pq).wn, (pq).we);                                                                   \
     const EarthAngle ea = full_angle(eh);                                                                     \
     wind_eci_or_calm(rp, ea, (pq).shp, (pq).chp, (pq).inv_p, (pq).wn, (pq).we, wq_);                          \
@@ -1041,7 +1041,10 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
     const double Tp_ = ph.thrust - ph.nozzle * (pq).P;                                                        \
     const double Td_[3] = {Tp_ * PARK_GET(PK_Q3), Tp_ * PARK_GET(PK_DJJ), Tp_ * dir2};                        \
     accel(Td_, Fp_, inv_m, (pq).g, inv_uv, f_);                                                               \
-    _Pragma("unroll") for (int c = 0; c < 3; c++) EMIT(kSlotVP + 3 * (kk) + c, FDQ(f_[c], PARK_GET(PK_Q0 + c))); \
+  } while (0)
+#define GEL_POS_SWEEP_EMIT(kk, f_)                                                                            \
+  do {                                                                                                        \
+    _Pragma("unroll") for (int c = 0; c < 3; c++) EMIT(kSlotVP + 3 * (kk) + c, FDQ((f_)[c], PARK_GET(PK_Q0 + c))); \
   } while (0)
         // PosCentre and the centre's position part as far as pos_delta() reads them, from the park
 #define GEL_LOAD_POS_CENTRE(pc, pcv)                                                                                   \
@@ -1067,15 +1070,25 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
             for (int c = 0; c < 3; c++) rp[c] = (k == c) ? (re[c] + dx) * P.up : r[c];
             const double dlt = (k == 0) ? rp[0] - r[0] : ((k == 1) ? rp[1] - r[1] : rp[2] - r[2]);   // exact
             PosPart pq;
-            if (__builtin_amdgcn_ballot_w64(!pos_delta(r, k, dlt, pcv, pc, tb, pq)) != 0) { todo |= 1u << k; continue; }
+            const bool ok = pos_delta(r, k, dlt, pcv, pc, tb, pq);
+            if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
+              todo |= 1u << k;
+              if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
+            }
             gravity_eci(rp, P.barC20, pq.g);
-            GEL_POS_SWEEP_TAIL(k, rp, pq);
+            double f[3];
+            GEL_POS_SWEEP_F(rp, pq, f);
+            // in a wavefront with a lane the difference form does not cover, the covered lanes write now and the others after
+            // the recomputation below: every lane writes once, and a covered lane always writes the value of the difference
+            // form -- a lane's entries do not depend on which other nodes (or, with two vectors per wavefront, which other
+            // decision vector) share its wavefront
+            if (ok) GEL_POS_SWEEP_EMIT(k, f);
           }
         }
 #ifndef GEL_EXP_NOFALLBACK
         if (todo) {
-          // the chain once more on the perturbed position, for the whole wavefront; a lane the difference form does cover
-          // still takes its values from there (each lane's entries do not depend on which other nodes share its wavefront)
+          // the chain once more on the perturbed position, for the lanes the difference form does not cover (all lanes of a
+          // problem created with GEL_FLAG_FD_RECOMPUTE)
 #pragma unroll 1
           for (int k = k0; k < k1; k++) {
             if (!((todo >> k) & 1u)) continue;
@@ -1083,28 +1096,26 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
             double rp[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) rp[c] = fresh_product((k == c) ? re[c] + dx : re[c], P.up);
-            // ... its atmosphere, the part that feels the altitude cancellation; wind and NED pair are insensitive to how the
-            // altitude was rounded and come from the recomputation
-            bool ok = false;
-            double d_rho = 0.0, d_P = 0.0, d_inv_a = 0.0;
+            bool ok = false;   // a lane mask on the scalar unit: the verdict of the difference form once more
             if (!P.fd_recompute) {
               GEL_LOAD_POS_CENTRE(pc, pcv);
               const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
               const double dlt = (k == 0) ? rp[0] - r[0] : ((k == 1) ? rp[1] - r[1] : rp[2] - r[2]);
               PosPart pd;
               ok = pos_delta(r, k, dlt, pcv, pc, tb, pd);
-              d_rho = pd.rho; d_P = pd.P; d_inv_a = pd.inv_a;
             }
             asm volatile("" ::: "memory");
             PosPart pq = pos_part(rp, tb, P.barC20);
-            pq.rho = ok ? d_rho : pq.rho; pq.P = ok ? d_P : pq.P; pq.inv_a = ok ? d_inv_a : pq.inv_a;
-            GEL_POS_SWEEP_TAIL(k, rp, pq);
+            double f[3];
+            GEL_POS_SWEEP_F(rp, pq, f);
+            if (!ok) GEL_POS_SWEEP_EMIT(k, f);
           }
         }
 #endif
 #undef GEL_LOAD_POS_CENTRE
 #undef GEL_NEED_EARTH_ANGLE
-#undef GEL_POS_SWEEP_TAIL
+#undef GEL_POS_SWEEP_F
+#undef GEL_POS_SWEEP_EMIT
       }
 #endif
 #ifndef GEL_EXP_NOTFD

@@ -1394,7 +1394,7 @@ int gel_rows_configure(gel_problem* p, int32_t nlin, const gel_linear_row* lin, 
     if (lin[i].idx0 < 0 || lin[i].idx0 >= p->dims.num_vars || lin[i].idx1 >= p->dims.num_vars)
       return fail(GEL_ERR_ARG, "linear row: variable index out of range");
   for (int i = 0; i < nfn; i++)
-    if (fn[i].fn < 0 || fn[i].fn > 14 || fn[i].node < 0 || fn[i].node >= p->dims.M || !(fn[i].p[0] != 0.0) ||
+    if (fn[i].fn < 0 || fn[i].fn > 15 || fn[i].node < 0 || fn[i].node >= p->dims.M || !(fn[i].p[0] != 0.0) ||
         fn[i].tcol < -1 || fn[i].tcol > p->dims.S || (fn[i].fn >= 9 && fn[i].tcol < 0) || (fn[i].mode & ~15) || (fn[i].mode & 3) > 1)
       return fail(GEL_ERR_ARG, "node-function row: unknown function or mode, node / time column out of range, or zero scale");
   p->lin_rows.resize(nlin);

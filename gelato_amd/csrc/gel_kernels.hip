@@ -393,14 +393,16 @@ GEL_DEV double aero_cos(const double a[3], double nv2, const double d[3], double
 GEL_DEV double aero_acos(double c, double nv2) { return (c > 1.0) ? 0.0 : ((nv2 < 1.0e-12) ? 0.0 : acos(c)); }
 // Exact-difference form of alpha: with c = cos(alpha_c), s = sin(alpha_c) and the perturbed cosine c_p,
 //   c_p - c = c (cos t - 1) - s sin t   =>   t = -(c_p - c)/s - (c / 2s) t^2 + t^3/6 - ...        (t = alpha_p - alpha_c)
-// solved by two substitutions (t ~ 1e-8 .. 1e-5: the third is below 1e-16 of t wherever the form is used).  One reciprocal
-// root and a dozen operations instead of a second acos.  false: a lane where the form does not apply (a clamp of the
-// reference is active at either point, sin(alpha) < 1e-6, or the step is not small against sin(alpha)).
+// solved by two substitutions.  With x = (c / 2s) t0 the fixed point is t0 (1 - x + 2x^2 - 5x^3 + ...) and two substitutions
+// give t0 (1 - x + 2x^2 - x^3): 4 |x|^3 of t short, i.e. <= 4e-12 of t under the guard |x| < 1e-4 below (t ~ 1e-8 .. 1e-5, so
+// the guard refuses only angles of attack below a few degrees at the largest steps) -- four orders below what a second acos
+// would carry.  One reciprocal root and a dozen operations instead of that acos.  false: a lane where the form does not
+// apply (a clamp of the reference is active at either point, sin(alpha) < 1e-6, or the step is not small against sin(alpha)).
 GEL_DEV bool aero_dalpha(double c_p, double nv2_p, double c_c, double inv_s, bool centre_ok, double& t) {
   const double t0 = (c_c - c_p) * inv_s, k = (0.5 * c_c) * inv_s;
   const double t1 = t0 - (k * t0) * t0;
   t = (t0 - (k * t1) * t1) + (t1 * t1) * (t1 * (1.0 / 6.0));
-  return centre_ok && (c_p <= 1.0) && (nv2_p >= 1.0e-12) && (fabs(k * t0) < 1.0e-2);
+  return centre_ok && (c_p <= 1.0) && (nv2_p >= 1.0e-12) && (fabs(k * t0) < 1.0e-4);
 }
 
 // park slots of one wavefront (doubles; the last six hold up to 12 ints per lane)
@@ -698,6 +700,36 @@ GEL_DEV void iip_faa(const double pe[3], const double ve[3], double& lat_deg, do
   lon_deg = lam * 180.0 / kPi;
 }
 
+// Vincenty's inverse formula, lib/downrange.py:32-111 (iteration limit 5000, |d lambda| < 1e-12)
+GEL_DEV double distance_vincenty(double lat_o, double lon_o, double lat_t, double lon_t) {
+  const double Ra = 6378137.0, f = 1.0 / 298.257223563, Rb = Ra * (1.0 - f);
+  const double lat1 = lat_o * kPi / 180.0, lon1 = lon_o * kPi / 180.0, lat2 = lat_t * kPi / 180.0, lon2 = lon_t * kPi / 180.0;
+  if (lon2 - lon1 == 0.0) return 0.0;
+  const double U1 = atan((1.0 - f) * tan(lat1)), U2 = atan((1.0 - f) * tan(lat2)), dl = lon2 - lon1;
+  const double sU1 = sin(U1), cU1 = cos(U1), sU2 = sin(U2), cU2 = cos(U2);
+  double lam = dl, sin_sigma = 0.0, cos_sigma = 0.0, sigma = 0.0, cos_alpha = 0.0, cos_2sm = 0.0;
+  for (int it = 0; it < 5000; it++) {
+    const double sl = sin(lam), cl = cos(lam);
+    const double t1 = cU2 * sl, t2 = cU1 * sU2 - sU1 * cU2 * cl;
+    sin_sigma = sqrt(t1 * t1 + t2 * t2);
+    cos_sigma = sU1 * sU2 + cU1 * cU2 * cl;
+    sigma = atan2(sin_sigma, cos_sigma);
+    const double sin_alpha = cU1 * cU2 * sl / sin_sigma;
+    cos_alpha = sqrt(1.0 - sin_alpha * sin_alpha);
+    cos_2sm = cos_sigma - 2.0 * sU1 * sU2 / (cos_alpha * cos_alpha);
+    const double coeff = f / 16.0 * (cos_alpha * cos_alpha) * (4.0 + f * (4.0 - 3.0 * (cos_alpha * cos_alpha)));
+    const double prev = lam;
+    lam = dl + (1.0 - coeff) * f * sin_alpha * (sigma + coeff * sin_sigma * (cos_2sm + coeff * cos_sigma * (-1.0 + 2.0 * cos_2sm)));
+    if (fabs(lam - prev) < 1e-12) break;
+  }
+  const double u2 = (cos_alpha * cos_alpha) * (Ra * Ra - Rb * Rb) / (Rb * Rb);
+  const double A = 1.0 + u2 / 16384.0 * (4096.0 + u2 * (-768.0 + u2 * (320.0 - 175.0 * u2)));
+  const double Bc = u2 / 1024.0 * (256.0 + u2 * (-128.0 + u2 * (74.0 - 47.0 * u2)));
+  const double ds = Bc * sin_sigma * (cos_2sm + 0.25 * Bc * (cos_sigma * (-1.0 + 2.0 * (cos_2sm * cos_2sm)) -
+                    (1.0 / 6.0) * Bc * cos_2sm * (-3.0 + 4.0 * (sin_sigma * sin_sigma)) * (-3.0 + 4.0 * (cos_2sm * cos_2sm))));
+  return Rb * A * (sigma - ds);
+}
+
 // functions of ONE knot state (r, v in SI units, t in seconds, row parameters p):
 //   0 orbit energy (src/wrapper_coordinate.hpp:246-250)   1 |angular momentum| (:222-228)   2 inclination [rad] (:229-236)
 //   3 a   4 e   5 a (1 - e)   6 a (1 + e)   (src/Coordinate.cpp:197-245)   7 |r|   8 |v|
@@ -706,6 +738,8 @@ GEL_DEV void iip_faa(const double pe[3], const double ve[3], double& lat_deg, do
 //   12 / 13 latitude / longitude [deg] of the instantaneous impact point (lib/con_waypoint.py:164-207, lib/IIP.py)
 //   14 sine of the elevation above an antenna's horizon, p[2..4] = antenna ECEF, p[5..7] = its local vertical
 //       (lib/con_waypoint.py:45-51)
+//   15 downrange [m]: Vincenty distance from the launch point p[2] = latitude, p[3] = longitude [deg] to the geodetic
+//       latitude / longitude of the position (lib/con_waypoint.py:531-534,590-598; lib/downrange.py:32-111)
 GEL_DEV double node_fn(int fn, const double r[3], const double v[3], double t, const double* p) {
   if (fn >= 9) {
     double sn, cs;
@@ -715,6 +749,11 @@ GEL_DEV double node_fn(int fn, const double r[3], const double v[3], double t, c
       double lat, lon, alt;
       geodetic_full(pe[0], pe[1], pe[2], lat, lon, alt);
       return (fn == 9) ? lat * (180.0 / kPi) : (fn == 10) ? lon * (180.0 / kPi) : alt;   // math.degrees
+    }
+    if (fn == 15) {
+      double lat, lon, alt;
+      geodetic_full(pe[0], pe[1], pe[2], lat, lon, alt);
+      return distance_vincenty(p[2], p[3], lat * (180.0 / kPi), lon * (180.0 / kPi));
     }
     if (fn <= 13) {
       const double d0 = v[0] + kOmega * r[1], d1 = v[1] - kOmega * r[0];             // vel_eci2ecef (:69-73)
@@ -883,36 +922,6 @@ GEL_DEV void qrot(const Quat& q, const double v[3], double o[3]) {   // conj(q) 
   o[0] = r.x; o[1] = r.y; o[2] = r.z;
 }
 GEL_DEV double norm3(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
-
-// Vincenty's inverse formula, lib/downrange.py:32-111 (iteration limit 5000, |d lambda| < 1e-12)
-GEL_DEV double distance_vincenty(double lat_o, double lon_o, double lat_t, double lon_t) {
-  const double Ra = 6378137.0, f = 1.0 / 298.257223563, Rb = Ra * (1.0 - f);
-  const double lat1 = lat_o * kPi / 180.0, lon1 = lon_o * kPi / 180.0, lat2 = lat_t * kPi / 180.0, lon2 = lon_t * kPi / 180.0;
-  if (lon2 - lon1 == 0.0) return 0.0;
-  const double U1 = atan((1.0 - f) * tan(lat1)), U2 = atan((1.0 - f) * tan(lat2)), dl = lon2 - lon1;
-  const double sU1 = sin(U1), cU1 = cos(U1), sU2 = sin(U2), cU2 = cos(U2);
-  double lam = dl, sin_sigma = 0.0, cos_sigma = 0.0, sigma = 0.0, cos_alpha = 0.0, cos_2sm = 0.0;
-  for (int it = 0; it < 5000; it++) {
-    const double sl = sin(lam), cl = cos(lam);
-    const double t1 = cU2 * sl, t2 = cU1 * sU2 - sU1 * cU2 * cl;
-    sin_sigma = sqrt(t1 * t1 + t2 * t2);
-    cos_sigma = sU1 * sU2 + cU1 * cU2 * cl;
-    sigma = atan2(sin_sigma, cos_sigma);
-    const double sin_alpha = cU1 * cU2 * sl / sin_sigma;
-    cos_alpha = sqrt(1.0 - sin_alpha * sin_alpha);
-    cos_2sm = cos_sigma - 2.0 * sU1 * sU2 / (cos_alpha * cos_alpha);
-    const double coeff = f / 16.0 * (cos_alpha * cos_alpha) * (4.0 + f * (4.0 - 3.0 * (cos_alpha * cos_alpha)));
-    const double prev = lam;
-    lam = dl + (1.0 - coeff) * f * sin_alpha * (sigma + coeff * sin_sigma * (cos_2sm + coeff * cos_sigma * (-1.0 + 2.0 * cos_2sm)));
-    if (fabs(lam - prev) < 1e-12) break;
-  }
-  const double u2 = (cos_alpha * cos_alpha) * (Ra * Ra - Rb * Rb) / (Rb * Rb);
-  const double A = 1.0 + u2 / 16384.0 * (4096.0 + u2 * (-768.0 + u2 * (320.0 - 175.0 * u2)));
-  const double Bc = u2 / 1024.0 * (256.0 + u2 * (-128.0 + u2 * (74.0 - 47.0 * u2)));
-  const double ds = Bc * sin_sigma * (cos_2sm + 0.25 * Bc * (cos_sigma * (-1.0 + 2.0 * (cos_2sm * cos_2sm)) -
-                    (1.0 / 6.0) * Bc * cos_2sm * (-3.0 + 4.0 * (sin_sigma * sin_sigma)) * (-3.0 + 4.0 * (cos_2sm * cos_2sm))));
-  return Rb * A * (sigma - ds);
-}
 
 // quat_ecef2nedg (lib/coordinate.py:335-359) from the geodetic latitude / longitude [rad]
 GEL_DEV Quat quat_ecef2nedg(double lat, double lon) {

@@ -412,14 +412,21 @@ class Engine:
         t_ref, table, knot_times = _f64(t_ref), _f64(table), _f64(knot_times)
         assert table.shape == (t_ref.size, 13) and knot_times.size == self.S + 1
         x = np.empty(self.nvars)
-        check(lib().gel_initial_guess(self._h, t_ref.size, _d(t_ref), _d(table), _d(knot_times), _d(x)))
+        rc = check(lib().gel_initial_guess(self._h, t_ref.size, _d(t_ref), _d(table), _d(knot_times), _d(x)))
+        if rc == _lib.GEL_NONFINITE:
+            # np.interp semantics of the reference (initialize.py:346-409): a node time on a zero-width interval of the table
+            # (a repeated time at either end) extrapolates to NaN / Inf there; the guess is returned as the reference would
+            # return it, with a warning
+            import warnings
+            warnings.warn("initial_guess: non-finite node values (the reference table repeats a time where a node time "
+                          "falls): %d of %d" % (int(np.count_nonzero(~np.isfinite(x))), x.size), RuntimeWarning, stacklevel=2)
         return x
 
     # ---- knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py) ----
     NODE_FUNCTIONS = {"orbit_energy": 0, "angular_momentum": 1, "inclination_rad": 2, "semi_major_axis": 3,
                       "eccentricity": 4, "periapsis_radius": 5, "apoapsis_radius": 6, "radius": 7, "speed": 8,
                       "latitude_deg": 9, "longitude_deg": 10, "altitude": 11, "lat_IIP_deg": 12, "lon_IIP_deg": 13,
-                      "sin_elevation": 14}
+                      "sin_elevation": 14, "downrange": 15}
     # row modes (include/gelato_amd.h): value f / p0 - p1 | (f - p1) / p0; difference of the value | scaled raw difference
     MODE_SHIFTED, MODE_RAW_DIFFERENCE, MODE_NEGATED = 1, 4, 8
 

@@ -152,4 +152,9 @@ def make_problem(name="mixed-6x64", vehicle=None, ps_params=None):
     else:
         rows, knots, nodes = CONFIGS[name]
     pdict, unitdict, condition = build_pdict(vehicle, rows, knots, nodes, ps_params)
+    if name in CONFIGS:
+        # the cut-down event lists of the synthetic meshes do not hold every stage's ignition / cut-off event:
+        # inequality_mass leaves those stages out (with a warning) instead of raising like the reference does for a real
+        # event list (con_init_terminal_knot.py; lib/con_trajectory.py:40-49)
+        pdict["gelato_amd_allow_missing_stage_events"] = True
     return pdict, unitdict, condition, initial_xdict(vehicle, pdict, unitdict)

@@ -227,8 +227,10 @@ int gel_eval_aero_all_device(gel_problem* p, int32_t B, const double* d_x, doubl
  *        inequality_posLLH (lib/con_waypoint.py:507-560,717-784); fn 12 / 13 latitude / longitude [deg] of the
  *        instantaneous impact point (FAA algorithm, lib/IIP.py:30-135) -> equality_IIP, inequality_IIP (:164-207,330-381);
  *        fn 14 sine of the elevation above an antenna's horizon, p[2..4] = antenna ECEF position, p[5..7] = its local
- *        vertical -> inequality_antenna (:45-51,70-105).  (The "downrange" rows are not offered: their Jacobian code in
- *        the reference is inconsistent, con_waypoint.py:686-689,917-935.)
+ *        vertical -> inequality_antenna (:45-51,70-105); fn 15 downrange [m]: Vincenty distance (lib/downrange.py:32-111)
+ *        from the launch point p[2] = latitude, p[3] = longitude [deg] to the position's geodetic latitude / longitude
+ *        -> the "downrange" rows of equality_posLLH / inequality_posLLH (:531-534,551-554,742,771-778) and their gradient
+ *        (downrange_gradient, :583-607).
  *  con [B][nlin + nfn] (linear rows first); jfn [B][nfn][7]. ---- */
 typedef struct { int32_t idx0, idx1; double coef0, coef1, c0; } gel_linear_row;
 typedef struct { int32_t fn, node, tcol, mode; double p[8]; } gel_nodefn_row;

@@ -96,39 +96,7 @@ def orbital_elements(r, v):                           # :591-649
     return np.array([a, e, math.degrees(inc), math.degrees(asc), math.degrees(argp), math.degrees(ta)])
 
 
-def distance_vincenty(lat_o, lon_o, lat_t, lon_t):    # lib/downrange.py:32-111
-    Ra = 6378137.0
-    f = 1.0 / 298.257223563
-    Rb = Ra * (1.0 - f)
-    lat1, lon1 = lat_o * math.pi / 180.0, lon_o * math.pi / 180.0
-    lat2, lon2 = lat_t * math.pi / 180.0, lon_t * math.pi / 180.0
-    if lon2 - lon1 == 0.0:
-        return 0.0
-    U1 = math.atan((1.0 - f) * math.tan(lat1))
-    U2 = math.atan((1.0 - f) * math.tan(lat2))
-    dl = lon2 - lon1
-    lam = dl
-    sin_sigma = cos_sigma = sigma = cos_alpha = cos_2sm = 0.0
-    for _ in range(5000):
-        sin_sigma = math.sqrt((math.cos(U2) * math.sin(lam)) ** 2 +
-                              (math.cos(U1) * math.sin(U2) - math.sin(U1) * math.cos(U2) * math.cos(lam)) ** 2)
-        cos_sigma = math.sin(U1) * math.sin(U2) + math.cos(U1) * math.cos(U2) * math.cos(lam)
-        sigma = math.atan2(sin_sigma, cos_sigma)
-        sin_alpha = math.cos(U1) * math.cos(U2) * math.sin(lam) / sin_sigma
-        cos_alpha = math.sqrt(1.0 - sin_alpha ** 2)
-        cos_2sm = cos_sigma - 2.0 * math.sin(U1) * math.sin(U2) / cos_alpha ** 2
-        coeff = f / 16.0 * cos_alpha ** 2 * (4.0 + f * (4.0 - 3.0 * cos_alpha ** 2))
-        prev = lam
-        lam = dl + (1.0 - coeff) * f * sin_alpha * (
-            sigma + coeff * sin_sigma * (cos_2sm + coeff * cos_sigma * (-1.0 + 2.0 * cos_2sm)))
-        if abs(lam - prev) < 1e-12:
-            break
-    u2 = cos_alpha ** 2 * (Ra ** 2 - Rb ** 2) / Rb ** 2
-    A = 1.0 + u2 / 16384.0 * (4096.0 + u2 * (-768.0 + u2 * (320.0 - 175.0 * u2)))
-    B = u2 / 1024.0 * (256.0 + u2 * (-128.0 + u2 * (74.0 - 47.0 * u2)))
-    ds = B * sin_sigma * (cos_2sm + 0.25 * B * (cos_sigma * (-1.0 + 2.0 * cos_2sm ** 2) -
-                                                (1.0 / 6.0) * B * cos_2sm * (-3.0 + 4.0 * sin_sigma ** 2) * (-3.0 + 4.0 * cos_2sm ** 2)))
-    return Rb * A * (sigma - ds)
+distance_vincenty = wp.distance_vincenty        # lib/downrange.py:32-111 (restated in oracle/waypoint.py: the downrange rows use it too)
 
 
 def euler_from_quat(q):                               # lib/coordinate.py:505-528

@@ -14,8 +14,11 @@ the later rows (and later callbacks) see has drifted by an ulp.  `drift=True` re
 bit for bit; `drift=False` (the product's semantics: x is never mutated, every row differences the same centre) agrees
 with it to forward-difference noise.
 
-The "downrange" rows are not restated: every one of their Jacobian blocks appends the t entry to the position list
-(con_waypoint.py:702-706,915-919,932-936), so the reference cannot assemble them.
+The "downrange" rows: values as con_waypoint.py:531-534,551-554,742,771-778 (the `max` row divides by the `min` bound,
+:778); Jacobian = downrange_gradient (:583-607) scaled like the value, position entries on the position list and the t
+entry on the t list -- the form the reference intended.  The reference's own lists are scrambled (it appends the t VALUE
+to the position values, :702-706,915-919,932-936, and scales the `max` row's t entry by the `max` bound):
+`reference_downrange_lists()` restates that scramble, so that the fixture written from the reference pins every number.
 """
 import math
 
@@ -93,6 +96,42 @@ def antenna_vertical(pos_ecef):
     return _quatmult(_conj(qc), _quatmult(vq, qc))[1:4]
 
 
+# ---------------------------------------------------------------- lib/downrange.py:32-111
+def distance_vincenty(lat_o, lon_o, lat_t, lon_t):    # lib/downrange.py:32-111
+    Ra = 6378137.0
+    f = 1.0 / 298.257223563
+    Rb = Ra * (1.0 - f)
+    lat1, lon1 = lat_o * math.pi / 180.0, lon_o * math.pi / 180.0
+    lat2, lon2 = lat_t * math.pi / 180.0, lon_t * math.pi / 180.0
+    if lon2 - lon1 == 0.0:
+        return 0.0
+    U1 = math.atan((1.0 - f) * math.tan(lat1))
+    U2 = math.atan((1.0 - f) * math.tan(lat2))
+    dl = lon2 - lon1
+    lam = dl
+    sin_sigma = cos_sigma = sigma = cos_alpha = cos_2sm = 0.0
+    for _ in range(5000):
+        sin_sigma = math.sqrt((math.cos(U2) * math.sin(lam)) ** 2 +
+                              (math.cos(U1) * math.sin(U2) - math.sin(U1) * math.cos(U2) * math.cos(lam)) ** 2)
+        cos_sigma = math.sin(U1) * math.sin(U2) + math.cos(U1) * math.cos(U2) * math.cos(lam)
+        sigma = math.atan2(sin_sigma, cos_sigma)
+        sin_alpha = math.cos(U1) * math.cos(U2) * math.sin(lam) / sin_sigma
+        cos_alpha = math.sqrt(1.0 - sin_alpha ** 2)
+        cos_2sm = cos_sigma - 2.0 * math.sin(U1) * math.sin(U2) / cos_alpha ** 2
+        coeff = f / 16.0 * cos_alpha ** 2 * (4.0 + f * (4.0 - 3.0 * cos_alpha ** 2))
+        prev = lam
+        lam = dl + (1.0 - coeff) * f * sin_alpha * (
+            sigma + coeff * sin_sigma * (cos_2sm + coeff * cos_sigma * (-1.0 + 2.0 * cos_2sm)))
+        if abs(lam - prev) < 1e-12:
+            break
+    u2 = cos_alpha ** 2 * (Ra ** 2 - Rb ** 2) / Rb ** 2
+    A = 1.0 + u2 / 16384.0 * (4096.0 + u2 * (-768.0 + u2 * (320.0 - 175.0 * u2)))
+    B = u2 / 1024.0 * (256.0 + u2 * (-128.0 + u2 * (74.0 - 47.0 * u2)))
+    ds = B * sin_sigma * (cos_2sm + 0.25 * B * (cos_sigma * (-1.0 + 2.0 * cos_2sm ** 2) -
+                                                (1.0 / 6.0) * B * cos_2sm * (-3.0 + 4.0 * sin_sigma ** 2) * (-3.0 + 4.0 * cos_2sm ** 2)))
+    return Rb * A * (sigma - ds)
+
+
 # ---------------------------------------------------------------- lib/IIP.py:30-135
 def posLLH_IIP_FAA(pe, ve, n_iter=5):
     a = 6378137
@@ -154,6 +193,11 @@ def _f_elev(p_, v_, t_, sp, ant):                     # con_waypoint.py:45-51
     return np.array([np.dot(d, antenna_vertical(ant))])
 
 
+def _f_downrange(p_, v_, t_, sp, origin):             # con_waypoint.py:590-598
+    llh = eci2geodetic(p_ * sp["units"]["position"], t_ * sp["units"]["t"])
+    return np.array([distance_vincenty(origin[0], origin[1], llh[0], llh[1])])
+
+
 def make_rows(sp, pdict, condition):
     """Row descriptors of the five groups, in the reference's emission order.  Each row:
     (group, section, node, function, component, kind, bound, scale, antenna_ecef | None) with kind in
@@ -167,13 +211,16 @@ def make_rows(sp, pdict, condition):
             if names[i] not in wp:
                 continue
             w = wp[names[i]]
-            if "downrange" in w:
-                raise NotImplementedError("downrange rows: the reference cannot assemble their Jacobian")
-            for comp, key, scale in ((0, "lat", 90.0), (1, "lon", 180.0), (2, "altitude", None)):
+            for comp, key, scale in ((0, "lat", 90.0), (1, "lon", 180.0), (2, "altitude", None), (0, "downrange", None)):
                 for kind in ("exact", "min", "max"):
                     if key in w and kind in w[key]:
                         grp = "eqpos" if kind == "exact" else "ineqpos"
-                        rows.append((grp, i, sp["xa"][i], "llh", comp, kind, float(w[key][kind]), scale, None))
+                        if key == "downrange":
+                            lc = pdict["LaunchCondition"]             # :533-534; max reads the MIN bound (:778)
+                            bound = float(w[key]["min" if kind == "max" else kind])
+                            rows.append((grp, i, sp["xa"][i], "dr", 0, kind, bound, None, (float(lc["lat"]), float(lc["lon"]))))
+                        else:
+                            rows.append((grp, i, sp["xa"][i], "llh", comp, kind, float(w[key][kind]), scale, None))
             for comp, key, scale in ((0, "lat_IIP", 90.0), (1, "lon_IIP", 180.0)):
                 for kind in ("exact", "min", "max"):
                     if key in w and kind in w[key]:
@@ -188,8 +235,8 @@ def make_rows(sp, pdict, condition):
     return rows
 
 
-_FN = {"llh": _f_llh, "iip": _f_iip, "elev": _f_elev}
-_VARS = {"llh": ("position", "t"), "iip": ("position", "velocity", "t"), "elev": ("position", "t")}
+_FN = {"llh": _f_llh, "iip": _f_iip, "elev": _f_elev, "dr": _f_downrange}
+_VARS = {"llh": ("position", "t"), "iip": ("position", "velocity", "t"), "elev": ("position", "t"), "dr": ("position", "t")}
 
 
 def _value(f, row):
@@ -259,3 +306,25 @@ def jacobian(x, sp, rows, group, drift=False):
     res = {k: (np.array(v[0], dtype=np.int32), np.array(v[1], dtype=np.int32), np.array(v[2], dtype=np.float64),
                (len(mine), width[k])) for k, v in out.items()}
     return (res, x) if drift else res
+
+
+def reference_downrange_lists(J, rows, group, condition_bounds):
+    """The value lists the reference itself returns for a position group that contains downrange rows (module docstring):
+    jac["position"]["coo"][2] takes, after the three position values of a downrange row, that row's t value as a fourth
+    (:702-706,915-919,932-936), jac["t"]["coo"][2] gets none; the `max` row's t value is scaled by -1/max where its
+    position values (and ours) are scaled by -1/min.  condition_bounds[row index] = (min, max) of a max row.
+    -> (position values, t values) as flat arrays in the reference's order."""
+    mine = [r for r in rows if r[0] == group]
+    pv, tv = [], []
+    for ir, r in enumerate(mine):
+        pos3 = list(J["position"][2][3 * ir:3 * ir + 3])
+        tval = J["t"][2][ir]
+        if r[3] == "dr":
+            if r[5] == "max":
+                lo, hi = condition_bounds[ir]
+                tval = tval * lo / hi
+            pv.extend(pos3 + [tval])
+        else:
+            pv.extend(pos3)
+            tv.append(tval)
+    return np.array(pv), np.array(tv)

@@ -49,6 +49,19 @@ def test_lgr_generator_matches_reference(n):
     assert np.max(np.abs(D @ tx ** 2 - 2 * tau)) <= 1e-11 * np.abs(D).max()
 
 
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 8, 16, 32, 64])
+def test_lgr_unflipped_set_matches_reference(n):
+    """nodes_LGR / differentiation_matrix_LGR with reverse=False (lib/PSfunctions.py:149-168,182-208): the set that contains -1"""
+    g = load_golden("g1b_lgr_unflipped.npz")
+    tau, D = nodes_LGR(n, reverse=False), differentiation_matrix_LGR(n, reverse=False)
+    assert tau[0] == -1.0 and np.all(np.diff(tau) > 0) and D.shape == (n, n + 1) and D.flags.c_contiguous
+    assert np.max(np.abs(tau - g["tau_%d" % n])) <= 1e-14
+    Dg = g["D_%d" % n]
+    assert np.max(np.abs(D - Dg) / np.max(np.abs(Dg), axis=1, keepdims=True)) <= 1e-11
+    tx = np.concatenate([tau, [1.0]])
+    assert np.max(np.abs(D @ tx ** 2 - 2 * tau)) <= 1e-11 * np.abs(D).max()
+
+
 def test_lgr_rejects_small_n():
     with pytest.raises(_lib.GelatoAmdError):
         nodes_LGR(1)

@@ -104,6 +104,15 @@ def test_oracle_initial_guess_vs_reference_output():
         assert np.array_equal(X[k], g["example_" + k]), k
     with pytest.raises(Exception, match="must not decrease"):
         E.initial_guess(tab[::-1, col["time"]], table, g["knot_times"])
+    # a reference table that ends in a repeated time, with knots beyond it: the extrapolation interval has zero width; the
+    # non-finite guess comes back like the reference's would, and the caller is told (GEL_NONFINITE -> RuntimeWarning)
+    t2 = tab[:, col["time"]].copy()
+    t2[-1] = t2[-2]
+    knots = g["knot_times"].copy()
+    knots[-1] = t2[-1] + 50.0
+    with pytest.warns(RuntimeWarning, match="non-finite"):
+        xbad = E.initial_guess(t2, table, knots)
+    assert not np.all(np.isfinite(xbad))
 
 
 @pytest.mark.parametrize("cname", list(CONDS))
@@ -157,3 +166,24 @@ def test_device_form_user_module_declares_the_shipped_constraint():
     assert get_index_event(pdict, "IIP_END", "position") == (3 * xa, 3 * (xa + pdict["ps_params"].nodes(i) + 1))
     assert np.array_equal(get_value(xdict, pdict, unitdict, "IIP_END", "velocity"),
                           xdict["velocity"][3 * xa:3 * xa + 3] * unitdict["velocity"])
+
+
+def test_inequality_mass_raises_like_the_reference_when_a_stage_event_is_missing():
+    """lib/con_trajectory.py:40-49 indexes the empty list of sections named like the stage's ignition_at / cutoff_at event:
+    IndexError.  Only the synthetic bench meshes (cut-down event lists, flagged by problem.make_problem) skip such a stage."""
+    import warnings
+    from gelato_amd import con_init_terminal_knot as ck2
+    from gelato_amd import problem as pb
+    pdict, unitdict, condition, _ = pb.make_problem("example")
+    pdict["device"] = -1
+    pdict["RocketStage"] = {k: dict(v) for k, v in pdict["RocketStage"].items()}
+    first = next(iter(pdict["RocketStage"].values()))
+    first["cutoff_at"] = "NO_SUCH_EVENT"
+    with pytest.raises(IndexError, match="NO_SUCH_EVENT"):
+        ck2.rows_of(pdict, unitdict, condition)
+    assert pb.make_problem("mixed-6x64")[0]["gelato_amd_allow_missing_stage_events"]
+    pdict["gelato_amd_allow_missing_stage_events"] = True
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ck2.rows_of(pdict, unitdict, condition)
+    assert any("inequality_mass" in str(x.message) for x in w)

@@ -126,11 +126,12 @@ def test_product_row_table_reproduces_the_reference_values(cname):
     assert E._nfn == R.nfn and E._nlin == R.nlin
 
 
-def test_product_rejects_downrange_rows_and_returns_none_without_rows():
+def test_product_returns_none_without_rows_and_needs_a_min_bound_for_downrange_max():
     from gelato_amd import con_waypoint as cw
-    pdict, unitdict, condition, xdict = example({"waypoint": {"FAIRING": {"downrange": {"min": 1.0e5}}}, "antenna": {}})
-    with pytest.raises(NotImplementedError, match="downrange"):
-        cw.equality_posLLH(xdict, pdict, unitdict, condition)
+    # the reference's downrange `max` row divides by the `min` bound (con_waypoint.py:778): without one it raises KeyError
+    pdict, unitdict, condition, xdict = example({"waypoint": {"FAIRING": {"downrange": {"max": 1.0e5}}}, "antenna": {}})
+    with pytest.raises(KeyError, match="min"):
+        cw.inequality_posLLH(xdict, pdict, unitdict, condition)
     pdict, unitdict, condition, xdict = example()
     condition = {k: v for k, v in condition.items() if k not in ("waypoint", "antenna")}
     for f in (cw.equality_posLLH, cw.equality_jac_posLLH, cw.inequality_posLLH, cw.inequality_jac_posLLH, cw.equality_IIP,
@@ -156,10 +157,117 @@ def test_row_abi_validation():
                 ("latitude_deg", 3, 1, 16, [90.0, 42.0]),          # unknown mode bit
                 ("latitude_deg", 3, 1, 2, [90.0, 42.0]),           # unknown value form
                 ("latitude_deg", 3, pdict["num_sections"] + 1, 5, [90.0, 42.0]),
-                (15, 3, 1, 5, [90.0, 42.0]),
+                (16, 3, 1, 5, [90.0, 42.0]),
                 ("altitude", 3, 1, 4, [0.0, 1.0])):                # zero scale
         with pytest.raises(Exception):
             E.rows_configure([], [bad])
+
+
+# ------------------------------------------------------------------ the "downrange" rows (G13b)
+def _dr_bounds(rows, grp, cond):
+    """(min, max) of the group's downrange `max` rows, by row index (the reference scales that row's t entry by max)"""
+    out = {}
+    mine = [r for r in rows if r[0] == grp]
+    names = None
+    for ir, r in enumerate(mine):
+        if r[3] == "dr" and r[5] == "max":
+            out[ir] = r
+    return out
+
+
+@pytest.mark.parametrize("cname", ["dr", "dronly"])
+@pytest.mark.parametrize("xname", ["init", "moved"])
+def test_oracle_downrange_rows_vs_reference_golden(xname, cname):
+    """Values bit for bit; Jacobian numbers bit for bit against the reference's RAW (scrambled) lists: it appends a downrange
+    row's t value to the position values (con_waypoint.py:702-706,915-919,932-936)."""
+    g = load_golden("g13b_downrange.npz")
+    cd = conditions(g)[cname]
+    pdict, unitdict, condition, _ = example(dict(cd, antenna={}))
+    sp = kt.make_spec(pdict, unitdict, condition)
+    rows = wp.make_rows(sp, pdict, condition)
+    names = [pdict["params"][i]["name"] for i in range(pdict["num_sections"])]
+    x = g["x_" + xname]
+    seen = 0
+    for grp in ("eqpos", "ineqpos"):
+        base = "%s_%s_%s" % (xname, cname, grp)
+        v = wp.values(x, sp, rows, grp)
+        if bool(g[base + "_none"]):
+            assert v is None
+            continue
+        seen += 1
+        assert np.array_equal(v, g[base + "_con"]), base
+        J, _ = wp.jacobian(x, sp, rows, grp, drift=True)
+        mine = [r for r in rows if r[0] == grp]
+        # index lists: what the reference emits (three position pairs and one t pair per row)
+        assert np.array_equal(J["position"][0], g[base + "_jac_position_rows"]) and np.array_equal(J["position"][1], g[base + "_jac_position_cols"])
+        assert np.array_equal(J["t"][0], g[base + "_jac_t_rows"]) and np.array_equal(J["t"][1], g[base + "_jac_t_cols"])
+        bounds = {ir: (cd["waypoint"][names[r[1]]]["downrange"]["min"], cd["waypoint"][names[r[1]]]["downrange"]["max"])
+                  for ir, r in enumerate(mine) if r[3] == "dr" and r[5] == "max"}
+        pv, tv = wp.reference_downrange_lists(J, rows, grp, bounds)
+        rp, rt = g[base + "_jac_position_vals"], g[base + "_jac_t_vals"]
+        ndr = sum(r[3] == "dr" for r in mine)
+        assert len(rp) == 3 * len(mine) + ndr and len(rt) == len(mine) - ndr       # the scramble, as documented
+        assert np.array_equal(tv, rt), base
+        exact = np.ones(len(pv), dtype=bool)
+        k = 0
+        for ir, r in enumerate(mine):                                              # the re-scaled t value of a max row: one rounding
+            k += 3
+            if r[3] == "dr":
+                exact[k] = r[5] != "max"
+                k += 1
+        assert np.array_equal(pv[exact], rp[exact]), base
+        assert np.all(np.abs(pv[~exact] - rp[~exact]) <= 4e-16 * np.abs(rp[~exact])), base
+        J0 = wp.jacobian(x, sp, rows, grp)                                         # the product's semantics: x untouched
+        for var in ("position", "t"):
+            assert np.all(np.abs(J0[var][2] - J[var][2]) <= 1e-5 + 1e-6 * np.abs(J[var][2])), (base, var)
+    assert seen == (2 if cname == "dr" else 1)
+
+
+def test_oracle_downrange_gradient_vs_reference_golden():
+    g = load_golden("g13b_downrange.npz")
+    pdict, unitdict, condition, _ = example()
+    sp = kt.make_spec(pdict, unitdict, condition)
+    origin = tuple(g["launch_lat_lon"])
+    dx = sp["dx"]
+    for p_, t_, f0, gp, gt in zip(g["pt_pos"], g["pt_t"], g["pt_downrange"], g["pt_grad_position"], g["pt_grad_t"]):
+        fc = wp._f_downrange(p_, None, t_, sp, origin)[0]
+        assert fc == f0
+        q = p_.copy()
+        for j in range(3):                                                          # con_waypoint.py:597-601, in place
+            q[j] += dx
+            assert (wp._f_downrange(q, None, t_, sp, origin)[0] - fc) / dx == gp[j]
+            q[j] -= dx
+        assert (wp._f_downrange(q, None, t_ + dx, sp, origin)[0] - fc) / dx == gt
+
+
+@pytest.mark.parametrize("cname", ["dr", "dronly"])
+def test_product_row_table_reproduces_the_reference_downrange_values(cname):
+    from gelato_amd import con_init_terminal_knot as ck
+    g = load_golden("g13b_downrange.npz")
+    pdict, unitdict, condition, _ = example(dict(conditions(g)[cname], antenna={}))
+    R = ck.rows_of(pdict, unitdict, condition)
+    sp = kt.make_spec(pdict, unitdict, condition)
+    orows = wp.make_rows(sp, pdict, condition)
+    assert [(r[0], r[1]) for r in R.waypoint_rows] == [(r[0], r[1]) for r in sorted(orows, key=lambda r: GROUPS.index(r[0]))]
+    fam = {"latitude_deg": (wp._f_llh, 0), "longitude_deg": (wp._f_llh, 1), "altitude": (wp._f_llh, 2), "downrange": (wp._f_downrange, 0)}
+    assert sum(r[3][0] == "downrange" for r in R.waypoint_rows) == (6 if cname == "dr" else 1)
+    for xname in ("init", "moved"):
+        x = g["x_" + xname]
+        _, pos, vel, _, _, t = kt.split(x, sp["M"], sp["N"])
+        for grp in ("eqpos", "ineqpos"):
+            a, b = R.waypoint_slices[grp]
+            base = "%s_%s_%s" % (xname, cname, grp)
+            if bool(g[base + "_none"]):
+                assert a == b
+                continue
+            vals = []
+            for (_, sec, node, row) in R.waypoint_rows[a:b]:
+                f, comp = fam[row[0]]
+                aux = tuple(row[4][2:4]) if row[0] == "downrange" else None
+                if aux is not None:
+                    assert aux == tuple(g["launch_lat_lon"]) and row[3] & 4 and row[2] == sec
+                vals.append(mode_value(f(pos[node], vel[node], t[sec], sp, aux)[comp], row))
+            assert np.array_equal(np.array(vals), g[base + "_con"]), base
 
 
 # ------------------------------------------------------------------ the device rows
@@ -257,3 +365,54 @@ def test_device_rows_batch_vs_oracle_including_states_without_an_impact_point():
     # one decision vector through the callback's single round trip gives the same bits
     fr = E.eval_callback(X[2], True)
     assert np.array_equal(fr["rows_con"], con[2]) and np.array_equal(fr["rows_jfn"], jfn[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cname", ["dr", "dronly"])
+def test_device_downrange_rows_vs_reference_golden(cname):
+    """The downrange rows through the reference-named functions: values against the reference's; Jacobian numbers against the
+    reference's raw lists, unscrambled (position values of a downrange row = entries 0-2 of its four, t value = the fourth;
+    the max row's t value re-scaled from the reference's -1/max to the -1/min of its value and position entries)."""
+    from gelato_amd import con_waypoint as cw
+    g = load_golden("g13b_downrange.npz")
+    cd = conditions(g)[cname]
+    pdict, unitdict, condition, _ = example(dict(cd, antenna={}), device=None)
+    sp = kt.make_spec(pdict, unitdict, condition)
+    rows = wp.make_rows(sp, pdict, condition)
+    names = [pdict["params"][i]["name"] for i in range(pdict["num_sections"])]
+    dx = sp["dx"]
+    for xname in ("init", "moved"):
+        xd = xdict_of(g["x_" + xname], pdict)
+        for grp, f, jf in (("eqpos", cw.equality_posLLH, cw.equality_jac_posLLH), ("ineqpos", cw.inequality_posLLH, cw.inequality_jac_posLLH)):
+            base = "%s_%s_%s" % (xname, cname, grp)
+            con, jac = f(xd, pdict, unitdict, condition), jf(xd, pdict, unitdict, condition)
+            if bool(g[base + "_none"]):
+                assert con is None and jac is None
+                continue
+            mine = [r for r in rows if r[0] == grp]
+            ref = g[base + "_con"]
+            # Vincenty's iteration stops at |d lambda| < 1e-12 rad (lib/downrange.py:93): two libms may stop one trip apart,
+            # 1e-12 rad of longitude = 6.4e-6 m of distance
+            tolv = np.array([6.4e-6 / r[6] + 1e-12 if r[3] == "dr" else 1e-12 for r in mine])
+            assert con.shape == ref.shape and np.all(np.abs(con - ref) <= tolv), (base, np.abs(con - ref).max())
+            assert sorted(jac) == ["position", "t"]
+            assert np.array_equal(jac["position"]["coo"][0], g[base + "_jac_position_rows"]) and np.array_equal(jac["position"]["coo"][1], g[base + "_jac_position_cols"])
+            assert np.array_equal(jac["t"]["coo"][0], g[base + "_jac_t_rows"]) and np.array_equal(jac["t"]["coo"][1], g[base + "_jac_t_cols"])
+            rp, rt = list(g[base + "_jac_position_vals"]), list(g[base + "_jac_t_vals"])
+            for ir, r in enumerate(mine):
+                pos3 = [rp.pop(0) for _ in range(3)]
+                if r[3] == "dr":
+                    tval = rp.pop(0)
+                    if r[5] == "max":
+                        b = cd["waypoint"][names[r[1]]]["downrange"]
+                        tval = tval * b["max"] / b["min"]
+                    # forward difference of a distance of up to 2e6 m: an ulp of it is worth 4e-10 / dx / bound; the stop
+                    # criterion of the iteration adds up to 6.4e-6 m / dx / bound when the two evaluations stop a trip apart
+                    tol = (4e-10 + 6.4e-6) / dx / r[6]
+                else:
+                    tval = rt.pop(0)
+                    tol = 2e-5
+                got = list(jac["position"]["coo"][2][3 * ir:3 * ir + 3]) + [jac["t"]["coo"][2][ir]]
+                for a_, b_ in zip(got, pos3 + [tval]):
+                    assert abs(a_ - b_) <= tol + 1e-6 * abs(b_), (base, ir, a_, b_, tol)
+            assert not rp and not rt
