@@ -10,7 +10,8 @@ resident in HBM when the timed region starts; outputs stay in HBM.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: the path shards by independent decision vectors (replicas of the static problem, B
-vectors per rank, no data-path collective) -> "scaling": "weak".  Rank 0 prints ONE JSON line.
+vectors per rank, no data-path collective) -> "scaling": "weak".  Rank 0 prints ONE JSON line, with a per-rank `roofline`
+and the `cpu_baseline` leg (rank 0's host cores) at every N.
 """
 import argparse
 import json
@@ -232,18 +233,25 @@ def main():
         from gelato_amd import parallel
         # units = (work item, part): the position-sweep columns of the FD Jacobian are dealt to ranks too, so
         # that 8 GPUs have something to do on a 6-phase mesh (BASELINE.json configs[3]).  Every output entry has one
-        # owning unit; a rank evaluates its units, packs what it owns, and ONE all-gather completes res / jvar on
-        # every rank (no fills, (N-1)/N of the outputs received per rank).
+        # owning unit; a rank's kernel writes the entries of its units straight into its slice of ONE exchange buffer
+        # out [world][B][width], and ONE in-place all-gather completes it on every rank: no pack / unpack launches, no
+        # fills, (N-1)/N of the outputs received per rank.
         shards = parallel.UnitShards(E, world, rank)
+        dout = shards.buffer(B, dev)
 
-        def evaluate(u0, cnt, res_t, jv_t):
-            E.eval_shard_units_device(B, dX.data_ptr(), res_t.data_ptr(), jv_t.data_ptr(), u0, cnt, stream)
+        def evaluate(out_t, r):
+            E.eval_shard_packed_device(B, dX.data_ptr(), out_t.data_ptr(), r, stream)
 
         def step():
-            shards.step(evaluate, dres, djv)
+            shards.step(evaluate, dout)
+
+        def kernel_only():
+            if shards.ranges[rank][1] > 0:
+                evaluate(dout, rank)
     else:
         def step():
             E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv_ptr, stream)
+        kernel_only = step
 
     def barrier():
         if use_dist:
@@ -265,7 +273,21 @@ def main():
 
     # (1) `value`: exactly the contract -- W untimed warm-up steps, then K timed steps.  From an idle GPU these sit inside the
     # chip's start-up power transient (tools/launch_series.py: first launch fast, a dip ~3 ms later, steady after ~40 ms).
+    # Warm-up: the W untimed steps of the contract -- and, when a step is short, more of them until WARM_MS of launches have
+    # gone by (same count on every rank): 5 steps of 0.3 ms end inside the start-up dip of the clock, and the K timed steps
+    # would measure the transient, not the kernel (3 x 32 residual-only: 167 M evals/s against 204 M).
+    WARM_MS = 40.0
+    t0 = time.perf_counter()
     for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    per_step_ms = 1e3 * (time.perf_counter() - t0) / max(W, 1)
+    w_extra = 0 if W == 0 else max(0, min(4000, int(WARM_MS / max(per_step_ms, 1e-3)) - W))
+    if use_dist:
+        we = torch.tensor([w_extra], dtype=torch.int64, device=dev)
+        dist.all_reduce(we, op=dist.ReduceOp.MAX)
+        w_extra = int(we.item())
+    for _ in range(w_extra):
         step()
     torch.cuda.synchronize()
     elapsed, kern_ms = timed(K)
@@ -293,28 +315,47 @@ def main():
 
     # element 0 of what was just timed, kept for the oracle check inside the cpu_baseline leg
     gpu_first = None
-    if not a.no_cpu_baseline and world == 1:
-        gpu_first = (dres[0].cpu().numpy(), None if djv is None else E.expand(djv[0].cpu().numpy()))
+    if not a.no_cpu_baseline:
+        if shard:
+            r_t, j_t = shards.gather(dout[:, :1])
+            gpu_first = (r_t[0].cpu().numpy(), E.expand(j_t[0].cpu().numpy()))
+        else:
+            gpu_first = (dres[0].cpu().numpy(), None if djv is None else E.expand(djv[0].cpu().numpy()))
 
     evals = (1 if shard else world) * B * K
     # per launch: SURVEY.md 8(d) A_min x evals per launch (residual only: read x once, write the residual once)
     a_min = 8 * (E.nvars + E.nres) if a.residual_only else E.algorithmic_bytes
     abytes = a_min * B
     achieved = abytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
     wl_tag = a.workload + ("_resonly" if a.residual_only else "")
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s_B%d.json" % (wl_tag, B))
-    if os.path.exists(tpath):  # PMC-derived HBM bytes per launch (separate rocprofv3 --pmc passes, tools/gpu_record.sh)
+    from gelato_amd import _lib
+    build = _lib.build_info()
+
+    def static_counters(kind):
+        """profiles/<kind>_<workload>_B<batch>.json (separate rocprofv3 --pmc passes of this command, tools/gpu_record.sh) --
+        only if it was recorded with THE library that is loaded now (build_so_sha256); -> (dict or None, why not)"""
+        path = os.path.join(ROOT, "profiles", "%s_%s_B%d.json" % (kind, wl_tag, B))
+        if not os.path.exists(path):
+            return None, "no profiles/%s on record for this workload and batch" % os.path.basename(path)
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+            d = json.load(open(path))
+        except Exception as ex:  # noqa: BLE001
+            return None, "unreadable: %s" % ex
+        if d.get("build_so_sha256") != build["so_sha256"]:
+            return None, ("profiles/%s describes another build (so_sha256 %s..., git %s; loaded: %s...): not reported"
+                          % (os.path.basename(path), str(d.get("build_so_sha256"))[:12], str(d.get("build_git_head"))[:10], build["so_sha256"][:12]))
+        d["_file"] = os.path.basename(path)
+        return d, None
+
+    tdata, traffic_why = (None, "phase-shard mode: no counters on record") if shard else static_counters("traffic")
+    traffic = None if tdata is None else tdata.get("hbm_bytes_per_launch")
     info = E.launch_info(B, True, not a.residual_only)   # which instantiation the launcher picked
     kname = "gel::eval_kernel<%s, %s, %s, %s>" % tuple("true" if v else "false" for v in (info[0], info[1], info[2], info[4]))
     out = {
         "metric": "residual+Jacobian evals/sec (and ms/eval), 6-phase x 64-node LGR mesh",
         "value": evals / T, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "world_size": world, "collective_backend": ("nccl (RCCL over xGMI)" if use_dist else None),
+        "warmup_steps_run": W + w_extra,
         "ms_per_step": 1e3 * T / K, "ms_per_eval": 1e3 * T / (B * K), "higher_is_better": True,
         "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         # informational: the same K steps in the settled power state (config.settle_launches_before_second_timing untimed
@@ -329,38 +370,37 @@ def main():
                               "4 defect residuals + all x-dependent COO Jacobian values (compact), in HBM")},
         "status": int(status),
     }
+    out["build"] = build
     if not shard:
         # one launch = B evals on this rank; HIP events on the launch stream over the K timed launches
         stored = 8 * E.nres if a.residual_only else E.stored_bytes
         fp64 = None
-        fpath = os.path.join(ROOT, "profiles", "fp64_%s_B%d.json" % (wl_tag, B))
-        if os.path.exists(fpath):   # fp64 instruction counters + datapath occupancy of this command (tools/gpu_record.sh)
-            try:
-                f = json.load(open(fpath))
-                peak_tf = FP64_FLOP_PER_CYCLE * FP64_SPEC_CLOCK_GHZ / 1e3
-                fp64 = {"flops_per_launch": f["fp64_flops_per_launch"], "achieved": f["fp64_flops_per_launch"] / (kern_ms * 1e-3) / 1e12,
-                        "peak": peak_tf, "unit": "TFLOP/s", "frac": f["fp64_flops_per_launch"] / (kern_ms * 1e-3) / 1e12 / peak_tf,
-                        "peak_note": "256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 at the 2.4 GHz spec clock; vector fp64 and "
-                                     "v_mfma_f64 share that datapath (DESIGN.md 3.1)",
-                        # the datapath's occupancy in TIME (profiled pass): fp64 adds / multiplies, conversions, integer and move
-                        # instructions occupy issue slots without counting two flops per lane, so this, not `frac`, says how close
-                        # the kernel is to the pipe
-                        "pipe_busy": f.get("fp64_pipe_busy"), "valu_busy": f.get("valu_busy"), "mfma_busy": f.get("mfma_busy"),
-                        "valu_instructions_per_wave": f.get("valu_instructions_per_wave"), "clock_ghz_profiled": f.get("clock_ghz"),
-                        "source": "static: profiles/%s (rocprofv3 --pmc passes of this command; not re-measured in this run)" % os.path.basename(fpath)}
-            except Exception:
-                fp64 = None
+        f, fp64_why = static_counters("fp64")
+        if f is not None:   # fp64 instruction counters + datapath occupancy of this command (tools/gpu_record.sh)
+            peak_tf = FP64_FLOP_PER_CYCLE * FP64_SPEC_CLOCK_GHZ / 1e3
+            fp64 = {"flops_per_launch": f["fp64_flops_per_launch"], "achieved": f["fp64_flops_per_launch"] / (kern_ms * 1e-3) / 1e12,
+                    "peak": peak_tf, "unit": "TFLOP/s", "frac": f["fp64_flops_per_launch"] / (kern_ms * 1e-3) / 1e12 / peak_tf,
+                    "peak_note": "256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 at the 2.4 GHz spec clock; vector fp64 and "
+                                 "v_mfma_f64 share that datapath (DESIGN.md 3.1)",
+                    # the datapath's occupancy in TIME (profiled pass): fp64 adds / multiplies, conversions, integer and move
+                    # instructions occupy issue slots without counting two flops per lane, so this, not `frac`, says how close
+                    # the kernel is to the pipe
+                    "pipe_busy": f.get("fp64_pipe_busy"), "valu_busy": f.get("valu_busy"), "mfma_busy": f.get("mfma_busy"),
+                    "wait_inst_share": f.get("wait_inst_share"),
+                    "valu_instructions_per_wave": f.get("valu_instructions_per_wave"), "clock_ghz_profiled": f.get("clock_ghz"),
+                    "source": "static: profiles/%s (rocprofv3 --pmc passes of this command with this build; not re-measured in this run)" % f["_file"]}
         hbm_real = None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         # which limit binds, from the data: the share of the HBM peak the bytes that REALLY moved reach, against the share of
-        # time the fp64 datapath was occupied
-        bound = "hbm"
-        if fp64 is not None and fp64.get("pipe_busy") is not None and hbm_real is not None and fp64["pipe_busy"] > hbm_real:
-            bound = "mfma"
-        out["roofline"] = {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # time the fp64 datapath was occupied.  Without counters of THIS build: SURVEY 8(d)'s a-priori bound, and said so.
+        bound, bound_source = "hbm", "SURVEY.md 8(d) (a priori): no counters of the loaded build on record"
+        if fp64 is not None and fp64.get("pipe_busy") is not None and hbm_real is not None:
+            bound = "mfma" if fp64["pipe_busy"] > hbm_real else "hbm"
+            bound_source = "counters of this build: fp64.pipe_busy %.2f against hbm_frac_of_bytes_moved %.2f" % (fp64["pipe_busy"], hbm_real)
+        out["roofline"] = {"bound": bound, "bound_source": bound_source, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "traffic_source": None if traffic is None else
-                           "static: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                           "(2*FETCH_SIZE + WRITE_SIZE)*1024; not re-measured in this run)" % os.path.basename(tpath),
+                           "traffic_source": traffic_why if traffic is None else
+                           "static: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command with this build, "
+                           "(2*FETCH_SIZE + WRITE_SIZE)*1024; not re-measured in this run)" % tdata["_file"],
                            "kernel": kname, "kernel_ms": kern_ms,
                            "frac_settled": abytes / (kern_ms_settled * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_settled": kern_ms_settled,
                            "algorithmic_bytes_per_eval": a_min, "algorithmic_bytes_per_launch": abytes,
@@ -368,19 +408,38 @@ def main():
                            # restores negated / shared / structurally constant entries) -- `achieved` uses SURVEY 8(d)'s
                            # A_min as the contract prescribes, `traffic` shows the bytes that really moved
                            "stored_bytes_per_eval": stored, "hbm_frac_of_bytes_moved": hbm_real,
-                           "fp64": fp64,
+                           "fp64": fp64, "fp64_source": fp64_why,
                            "bound_note": "`achieved` / `peak` / `frac` are the HBM figures of SURVEY 8(d) (algorithmic bytes); `bound` names "
                                          "the limit the counters show nearer: 'mfma' = the fp64 datapath that v_mfma_f64 and vector fp64 "
                                          "share (fp64.pipe_busy) is busier than HBM is with the bytes that really move "
                                          "(hbm_frac_of_bytes_moved); see DESIGN.md 3.1"}
     else:
-        out["shard"] = {"step_ms": kern_ms, "step_ms_settled": kern_ms_settled,
-                        "units_per_rank": [c for _, c in shards.ranges],
+        # this rank's kernel alone (its unit range of all B vectors, split form, written into its slice of the exchange buffer):
+        # HIP events over K launches without the collective
+        for _ in range(3):
+            kernel_only()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(K):
+            kernel_only()
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / K
+        own = sum(shards.counts[rank])
+        r_bytes = 8 * (E.nvars + own) * B     # this rank reads every vector once and writes the entries its units own once
+        out["roofline"] = {"bound": "hbm", "bound_source": "SURVEY.md 8(d) (a priori); the split (latency) form at this batch is launch- and "
+                           "latency-bound, see `shard`", "achieved": r_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": r_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": traffic_why,
+                           "kernel": kname, "kernel_ms": k_ms, "rank": rank,
+                           "algorithmic_bytes_per_launch": r_bytes, "owned_entries_per_vector": own}
+        out["shard"] = {"step_ms": kern_ms, "step_ms_settled": kern_ms_settled, "kernel_ms": k_ms,
+                        "exchange_ms": max(kern_ms - k_ms, 0.0), "pack_launches": 0, "unpack_launches": 0,
+                        "units_per_rank": [c for _, c in shards.ranges], "slice_doubles_per_vector": shards.width,
                         "all_gather_bytes_received_per_rank_per_step": shards.bytes_received_per_vector() * B,
-                        "note": "one step = this rank's unit range (split-form kernel) + one all-gather of the owned "
-                                "slices; no roofline block: the step is exchange-latency bound, not a kernel figure"}
+                        "note": "one step = this rank's unit range (split-form kernel writing straight into its slice of the exchange "
+                                "buffer) + ONE in-place all-gather; a consumer reads the buffer through gel_shard_plan's map"}
 
-    if not a.no_extras and not a.residual_only:
+    if not a.no_extras and not a.residual_only and not shard:
         # informational: materialise every COO value like the reference does (compact -> full expansion)
         try:
             Bf = min(B, 1024)
@@ -477,7 +536,7 @@ def main():
         except Exception as ex:  # noqa: BLE001
             out["aero_constraints"] = {"error": str(ex)}
 
-    if not a.no_cpu_baseline and world == 1:
+    if not a.no_cpu_baseline:   # rank 0, at every N
         out["cpu_baseline"] = cpu_baseline(prob, D, tau, X, gpu_first, residual_only=a.residual_only)
         # informational only (the roofline fraction is the kernel-quality figure): the GPU writes compact
         # Jacobian values, the scalar port materialises every COO value

@@ -83,6 +83,9 @@ SIGNATURES = {
     "gel_eval_shard_units_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_void_p]),
     "gel_unit_owner": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "gel_shard_plan": (C.c_int, [C.c_void_p, C.c_int32, _ip, _lp, _lp, _lp]),
+    "gel_eval_shard_packed_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "gel_shard_unpack_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gel_num_chunks": (C.c_int, [C.c_void_p, _ip]),
     "gel_chunk_phase": (C.c_int, [C.c_void_p, _ip]),
     "gel_launch_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _ip]),
@@ -120,7 +123,57 @@ def build(force=False):
     subprocess.check_call(["make", "-s", "-C", src_dir])
     if not os.path.exists(SO_PATH):
         raise RuntimeError("building %s failed" % SO_PATH)
+    _write_build_info()
     return SO_PATH
+
+
+BUILD_INFO_PATH = os.path.join(_HERE, "build_info.json")
+
+
+def so_sha256(path=None):
+    """sha256 of the engine library as it lies on disk (the build is bit-reproducible: same sources + same hipcc -> same bytes)"""
+    import hashlib
+    h = hashlib.sha256()
+    with open(path or SO_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def _write_build_info():
+    """Provenance of the in-tree library, written where it is built (this container has the git history, the GPU box does not;
+    the file travels with the snapshot): recorded counter files name the build they describe, bench.py ignores the others."""
+    import json
+    info = {"so_sha256": so_sha256(os.path.join(_HERE, "libgelato_amd.so")), "git_head": None, "git_dirty": None}
+    try:
+        root = os.path.dirname(_HERE)
+        info["git_head"] = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+        info["git_dirty"] = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "gelato_amd/csrc", "include"],
+                                                         text=True, stderr=subprocess.DEVNULL).strip())
+    except Exception:  # noqa: BLE001  (no git on the GPU box)
+        pass
+    try:
+        old = json.load(open(BUILD_INFO_PATH))
+        if old.get("so_sha256") == info["so_sha256"] and info["git_head"] is None:
+            return      # same library, rebuilt where there is no git: keep what the build container wrote
+    except Exception:  # noqa: BLE001
+        pass
+    with open(BUILD_INFO_PATH, "w") as f:
+        json.dump(info, f)
+
+
+def build_info():
+    """{"so_sha256": of the library that is LOADED (GELATO_AMD_LIB honoured), "git_head", "git_dirty": of the build that produced
+    the in-tree library, if that is the one loaded}"""
+    import json
+    out = {"so_sha256": so_sha256(), "git_head": None, "git_dirty": None}
+    try:
+        rec = json.load(open(BUILD_INFO_PATH))
+        if rec.get("so_sha256") == out["so_sha256"]:
+            out.update(git_head=rec.get("git_head"), git_dirty=rec.get("git_dirty"))
+    except Exception:  # noqa: BLE001
+        pass
+    return out
 
 
 def _preload_torch_hip_runtime():

@@ -102,7 +102,11 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_CA_CACHE 1  // the Mach interval of a node's first CA lookup serves its other aerodynamic-force evaluations
 #endif
 #ifndef GEL_XLDS_A_PF_JAC
-#define GEL_XLDS_A_PF_JAC 1  // LDS-staged cooperative D.X, one vector per wavefront: A slabs in flight, fused launch
+#define GEL_XLDS_A_PF_JAC 17  // LDS-staged cooperative D.X, one vector per wavefront: A slabs in flight, fused launch.  17 = all of a
+                              // 64-node phase, requested before the operand barrier: their (L2) round trips run under the state
+                              // rows' (HBM) one instead of one per k-step in a row -- a wavefront's vector-memory results come
+                              // back in order behind every older request of its CU, so even an L2 hit costs 600-1000 cycles
+                              // under the store stream and 17 of them in a row were 20 % of a wavefront's life (round 4 stamps)
 #endif
 #ifndef GEL_XLDS_A_PF_RES
 #define GEL_XLDS_A_PF_RES 4  // ... residual-only launch (6x64: +11 % over 1; the fused launch does not care: +-1 % for 1..8)
@@ -133,7 +137,9 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 // The body is a device function of a (virtual) workgroup index: eval_kernel runs it for every workgroup of a launch,
 // callback_kernel (gel_kernels.hip) for the first workgroups of the one launch that serves a whole callback.  In the forms
 // that are not cooperative a workgroup may have any number of wavefronts (each its own work item).
-template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false>
+// SPLITB (split form): k-steps of D.X whose state column is requested at once -- 17 (a whole 64-node phase) inside callback_kernel,
+// which has registers to spare; 9 in the stand-alone launch, which is held to 128 VGPRs.
+template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, int SPLITB = 9>
 __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const double* __restrict__ x, double* __restrict__ res,
                                           double* __restrict__ jvar, const unsigned vblk) {
   extern __shared__ double lds[];
@@ -253,18 +259,52 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   const double* xt = xb + 11 * M + 2 * N;
   // wave-uniform scalars live in SGPRs (two decision vectors per wavefront: per half, so they stay vector values there)
 #define GEL_UNI(v) (PACK ? (v) : wave_uniform(v))
-  const double to = GEL_UNI(xt[sec]), tf = GEL_UNI(xt[sec + 1]);
+#ifndef GEL_FRONT_EARLY_T
+#define GEL_FRONT_EARLY_T 0   // A/B: 1 = round 3's order (the knot times are waited for before the state rows are requested)
+#endif
+  // The phase's two knot times: requested here, TAKEN (v_readfirstlane: the first wait of the wavefront) only once every other
+  // load of phase A has been requested -- one HBM round trip instead of two in a row in front of the D.X product.
+  const double to_ld = xt[sec], tf_ld = xt[sec + 1];
+  double to = 0.0, tf = 0.0, fds = 0.0, fdt = 0.0;
   const double dx = P.dx, ut = P.ut;
+  const double inv_dx = 1.0 / dx;
+  // Jacobian entry from a perturbed/centre pair: -(f_p - f_c)/dx*(tf-to)*unit_t/2  (con_dynamics.py:372),
+  // as (f_c - f_p) times the wave-uniform scale (tf-to)*unit_t/2/dx
+#define GEL_TAKE_KNOT_TIMES()                                   \
+  do {                                                          \
+    to = GEL_UNI(to_ld); tf = GEL_UNI(tf_ld);                   \
+    fds = GEL_UNI(inv_dx * (tf - to) * ut / 2.0);               \
+    fdt = GEL_UNI(inv_dx * ut / 2.0);                           \
+  } while (0)
+#if GEL_FRONT_EARLY_T
+  GEL_TAKE_KNOT_TIMES();
+#endif
   // NaN / Inf detector: lanes that wrote a non-finite value, accumulated on the scalar unit (a running per-lane sum would hold
   // two VGPRs for the whole kernel)
   unsigned long long bad = 0;
 #define GEL_CHK(v) (bad |= __builtin_amdgcn_ballot_w64(!(fabs(v) <= 1.79769313486231570815e308)))
 
   GEL_STAMP_AT(1);
-  double* rb = (res && lead) ? res + (size_t)b * 11 * N : nullptr;
+  // PACKED (split form only, P.shard_width != 0: gel_eval_shard_packed_device): every unit writes ITS entries of a decision
+  // vector as one contiguous block -- compact Jacobian slots first ([slot][node of the chunk], only the slots the unit owns),
+  // then the phase scalar (first chunk of a phase), then the residual rows mass | position | velocity | quaternion of the
+  // chunk's nodes -- at unit_base[unit] inside the rank's block of the vector, `res` being the rank's slice [B][shard_width]
+  // of the exchange buffer (gel_shard_plan has the map back to the reference layouts).
+  const bool packed = SPLIT && P.shard_width != 0;
+  const int nn = min(64, n - j0);                         // nodes of this chunk
+  // slots a packed unit skips in front of the ones it owns: part k > 0 owns the three slots of position column k - 1; part 0
+  // of an aerodynamic phase everything but the nine position-sweep slots 6 .. 14
+  const int sub_hi = packed ? (part ? kSlotVP + 3 * (part - 1) : (ph.air ? 9 : 0)) : 0;
+  const int sub_lo = (packed && part) ? sub_hi : 0;
+  const int pk_nj = (ph.K - sub_hi) * nn + (j0 == 0 ? 1 : 0);   // part 0: doubles of its Jacobian part (residual rows follow)
+  double* const pk_out = packed ? res + (size_t)b * P.shard_width + load_const(P.unit_base + P.unit0 + q) : nullptr;
+  double* rb = packed ? (lead ? pk_out : nullptr) : ((res && lead) ? res + (size_t)b * 11 * N : nullptr);
+  const int gn = packed ? lane : g;                       // node index inside a residual group
+  const int rs_m = packed ? pk_nj : 0, rs_p = packed ? pk_nj + nn : N, rs_v = packed ? pk_nj + 4 * nn : 4 * N,
+            rs_q = packed ? pk_nj + 7 * nn : 7 * N;
 #ifdef GEL_ABL_NOSTORE  // ablation (tools/variant.sh): everything computed, (almost) nothing stored
   double* jb = JAC ? jvar + (size_t)b * P.V + ph.voff + (size_t)j0 * ph.K + (j - j0) : nullptr;
-  const int cw8 = min(64, n - j0) * 8;
+  const int cw8 = nn * 8;
 #define EMIT_AT(byteoff, val)                             \
   do {                                                    \
     const double _v = (val);                              \
@@ -283,11 +323,11 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
       __builtin_amdgcn_make_buffer_rsrc(JAC ? (void*)(jvar + ph.voff + j0) : (void*)nullptr, 0, -1, 0x00020000);
 #else
       // a phase's node values are laid out [64-node chunk][slot][node of the chunk]: this wavefront's block starts at j0 * K
-      __builtin_amdgcn_make_buffer_rsrc(JAC ? (void*)(jvar + (size_t)(PACK ? min(b0 + 2 * wv, B - 1) : b) * P.V + ph.voff + (size_t)j0 * ph.K) : (void*)nullptr,
+      __builtin_amdgcn_make_buffer_rsrc(JAC ? (packed ? (void*)pk_out : (void*)(jvar + (size_t)(PACK ? min(b0 + 2 * wv, B - 1) : b) * P.V + ph.voff + (size_t)j0 * ph.K)) : (void*)nullptr,
                                         0, -1, 0x00020000);
 #endif
   const int jvo = PACK ? (half * (int)P.V + j) * 8 : lane * 8;
-  const int cw8 = min(64, n - j0) * 8;   // bytes between two slots of this wavefront's block
+  const int cw8 = nn * 8;   // bytes between two slots of this wavefront's block
 #define EMIT_AT(byteoff, val)                                                           \
   do {                                                                                  \
     const double _v = (val);                                                            \
@@ -313,18 +353,13 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
     GEL_CHK(_v);                                                                                             \
   } while (0)
 #else
-#define EMIT(slot, val) EMIT_AT((int)(slot) * cw8, val)
+#define EMIT(slot, val) EMIT_AT(((int)(slot) - (SPLIT ? (((int)(slot) >= kSlotVP) ? sub_hi : sub_lo) : 0)) * cw8, val)
 #endif
 #ifdef GEL_ABL_NORES  // ablation: residual rows computed, not stored
 #define RSTORE(idx, val) do { if ((val) == 1.2345e300) rb[idx] = (val); } while (0)
 #else
 #define RSTORE(idx, val) rb[idx] = (val)
 #endif
-  // Jacobian entry from a perturbed/centre pair: -(f_p - f_c)/dx*(tf-to)*unit_t/2  (con_dynamics.py:372),
-  // as (f_c - f_p) times the wave-uniform scale (tf-to)*unit_t/2/dx
-  const double inv_dx = 1.0 / dx;
-  const double fds = GEL_UNI(inv_dx * (tf - to) * ut / 2.0);
-  const double fdt = GEL_UNI(inv_dx * ut / 2.0);
   const double inv_uv = wave_uniform(1.0 / P.uv);   // the same for both halves of a two-vector wavefront
 #define FDQ(fp, fc) (((fc) - (fp)) * fds)
 
@@ -350,6 +385,10 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
     if (!ph.hold) { u0 = xu[2 * (ph.ua + jc)]; u1 = xu[2 * (ph.ua + jc) + 1]; }
     const double djj = JAC ? P.Dt[ph.doff + (size_t)(jc + 1) * n + jc] : 0.0;  // D[j][j+1]
 
+    // the reference rows of engine-off / hold phases (state row 0 of the phase): from the LDS image of the state rows where a
+    // form stages one (no load at all), else fetched after the product
+    double m0 = 0.0, q0[4] = {0, 0, 0, 0};
+    bool ref0_done = false;
     // D.X rows (lib/con_dynamics.py:54,146,256,524)
     double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
     if (rb) {
@@ -381,71 +420,87 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
         const double* ap = P.Dst + (size_t)dsw * 4 + (PACK ? (wv & 1) : wv) * 64 + lane;
         const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4) <= kSlabK: the phase is one slab
+        // Every load of phase A is REQUESTED before anything waits: the A slabs first (they do not depend on x: L2), then the
+        // state rows (HBM), and only then the first s_waitcnt of the wavefront.  A slabs: all k-steps of the phase at once
+        // (kAAll), or a ring of kAPF in flight.
+        constexpr int kAPF = JAC ? GEL_XLDS_A_PF_JAC : GEL_XLDS_A_PF_RES;
+        constexpr int kAllN = PACK ? 9 : kSlabK;
+        constexpr bool kAAll = PACK ? (GEL_PACK_A_PRELOAD != 0) : (kAPF >= kSlabK);
+        double a_all[kAAll ? kAllN : 1], a_ring[kAAll ? 1 : kAPF];
+        if (kAAll) {
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
-          const int rr = lane + 64 * it;
-          if (rr < (PACK ? 2 * kPackRows : kSlabRows)) {
-            const int hv = PACK ? rr / kPackRows : 0;          // PACK: which of the wavefront's two vectors
-            const int k = PACK ? rr - kPackRows * hv : rr;
-            const double* xs = PACK ? x + (size_t)min(b0 + 2 * wv + hv, B - 1) * P.nvars : xb;
-            lds_double* dst = wave_lds + rr * 11;
-            if (k <= n) {
-              const int xk = ph.xa + k;
-              dst[0] = xs[xk];
+          for (int ks = 0; ks < kAllN; ks++) a_all[ks] = ap[min(ks, ksteps - 1) * 256];
+        } else {
 #pragma unroll
-              for (int c = 0; c < 3; c++) { dst[1 + c] = xs[M + 3 * xk + c]; dst[4 + c] = xs[4 * M + 3 * xk + c]; }
+          for (int i = 0; i < kAPF; i++) a_ring[i] = ap[min(i, ksteps - 1) * 256];
+        }
+        // State rows: lane = row for rows 0 .. 63 (eleven loads, addresses clamped into the phase: no branch around a load);
+        // the few rows behind them (64 .. 67; two vectors per wavefront: 64 .. 71) element by element, lane e -> row e / 11,
+        // column e % 11 (one or two loads).  Rows past the phase meet zero columns of D: written as zeros.
+        constexpr int kRowsStaged = PACK ? 2 * kPackRows : kSlabRows, kExtra = (kRowsStaged - 64) * 11;
+        double st[11], sx[(kExtra + 63) / 64];
+        {
+          const int hv = PACK ? lane / kPackRows : 0;          // PACK: which of the wavefront's two vectors
+          const int k = PACK ? lane - kPackRows * hv : lane;
+          const double* xs = PACK ? x + (size_t)min(b0 + 2 * wv + hv, B - 1) * P.nvars : xb;
+          const int xk = ph.xa + min(k, n);
+          st[0] = xs[xk];
 #pragma unroll
-              for (int c = 0; c < 4; c++) dst[7 + c] = xs[7 * M + 4 * xk + c];
-            } else {  // rows past the phase meet zero columns of D: any finite value
+          for (int c = 0; c < 3; c++) { st[1 + c] = xs[M + 3 * xk + c]; st[4 + c] = xs[4 * M + 3 * xk + c]; }
 #pragma unroll
-              for (int c = 0; c < 11; c++) dst[c] = 0.0;
+          for (int c = 0; c < 4; c++) st[7 + c] = xs[7 * M + 4 * xk + c];
+#pragma unroll
+          for (int i = 0; i < (kExtra + 63) / 64; i++) {
+            const int e = min(lane + 64 * i, kExtra - 1);
+            const int rr = 64 + e / 11, c = e - 11 * (e / 11);
+            const int hx = PACK ? rr / kPackRows : 0;
+            const int kx = min(PACK ? rr - kPackRows * hx : rr, n);
+            const double* xe = PACK ? x + (size_t)min(b0 + 2 * wv + hx, B - 1) * P.nvars : xb;
+            const int xr_ = ph.xa + kx;
+            const int off = (c == 0) ? xr_ : ((c < 4) ? M + 3 * xr_ + (c - 1) : ((c < 7) ? 4 * M + 3 * xr_ + (c - 4) : 7 * M + 4 * xr_ + (c - 7)));
+            sx[i] = xe[off];
+          }
+          // ---- first wait of the wavefront ----
+          const bool in = k <= n;
+          lds_double* dst = wave_lds + lane * 11;
+#pragma unroll
+          for (int c = 0; c < 11; c++) dst[c] = in ? st[c] : 0.0;
+#pragma unroll
+          for (int i = 0; i < (kExtra + 63) / 64; i++) {
+            const int e = lane + 64 * i;
+            if (e < kExtra) {
+              const int rr = 64 + e / 11;
+              const int kx = PACK ? rr - kPackRows * (rr / kPackRows) : rr;
+              wave_lds[64 * 11 + e] = (kx <= n) ? sx[i] : 0.0;
             }
           }
         }
-        double a_ring[JAC ? GEL_XLDS_A_PF_JAC : GEL_XLDS_A_PF_RES];
-        if (!(PACK && GEL_PACK_A_PRELOAD)) {
-#pragma unroll
-          for (int i = 0; i < (JAC ? GEL_XLDS_A_PF_JAC : GEL_XLDS_A_PF_RES); i++) a_ring[i] = ap[min(i, ksteps - 1) * 256];
-        }
-#if GEL_PACK_A_PRELOAD
-        // PACK: at most nine k-steps -- all A slabs are requested before the barrier, so their latency runs under the state
-        // rows' (they do not depend on x)
-        double a_all[9];
-        if (PACK) {
-#pragma unroll
-          for (int ks = 0; ks < 9; ks++) a_all[ks] = ap[min(ks, ksteps - 1) * 256];
-        }
-#endif
         stage_tables_commit(P, lds, tab_mine);
         __syncthreads();
         GEL_STAMP_AT(2);
-#if GEL_PACK_A_PRELOAD
-        if (PACK) {
+#ifdef GEL_ABL_NODX
+        const int klast = 0;
+#else
+        const int klast = ksteps;
+#endif
+        if (kAAll) {
 #pragma unroll
-          for (int ks = 0; ks < 9; ks++) {
-            if (ks < ksteps) {   // wave-uniform
-              const int ro = ks * 44;
+          for (int ks = 0; ks < kAllN; ks++) {
+            if (ks < klast) {   // wave-uniform
+              const int ro = ks * 44;                                        // 4 rows of 11 columns per k-step
               const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
               acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl0, acc[0], 0, 0, 0);
               acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl1, acc[1], 0, 0, 0);
               acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl2, acc[2], 0, 0, 0);
             }
           }
-        } else
-#endif
-        {
-          // k-steps of A slabs in flight ahead of the matrix pipe (an L2 round trip each; requested before the barrier)
-          constexpr int kAPF = JAC ? GEL_XLDS_A_PF_JAC : GEL_XLDS_A_PF_RES;
-#ifdef GEL_ABL_NODX
-          const int klast = 0;
-#else
-          const int klast = ksteps;
-#endif
+        } else {
+          // k-steps of A slabs in flight ahead of the matrix pipe (an L2 round trip each; the first ones requested before the barrier)
           for (int ks = 0; ks < klast; ks += kAPF) {
 #pragma unroll
             for (int i = 0; i < kAPF; i++) {
               if (ks + i < klast) {   // wave-uniform
-                const int ro = (ks + i) * 44;                                // 4 rows of 11 columns per k-step
+                const int ro = (ks + i) * 44;
                 const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
                 acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ring[i], bl0, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ring[i], bl1, acc[1], 0, 0, 0);
@@ -464,6 +519,13 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           for (int c = 0; c < 3; c++) { re[c] = src[1 + c]; ve[c] = src[4 + c]; }
 #pragma unroll
           for (int c = 0; c < 4; c++) q[c] = src[7 + c];
+          lds_double* src0 = wave_lds + (half * kPackRows) * 11;   // state row 0 of the phase
+          if (!ph.engine_on) m0 = src0[0];
+          if (ph.hold) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) q0[c] = src0[7 + c];
+          }
+          ref0_done = true;
         }
         __syncthreads();                   // the hand-over area overlaps the state-row image: everyone is done reading it
         lds_double* wg_lds = regions + kHO;
@@ -686,12 +748,25 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         const gel_double4* ap = reinterpret_cast<const gel_double4*>(P.Dsw) + (size_t)dsw * 1 + lane;
         const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4)
         const unsigned un = (unsigned)n, ubs = (unsigned)bs;
-        for (int ks = 0; ks < ksteps; ks++) {
-          const unsigned k = min(4u * ks + kq, un);
-          const double bl = bp[k * ubs];
-          const gel_double4 a4 = ap[ks * 64];
+        // Latency form: the round trips are what counts (B = 1: x sits in pinned HOST memory, a load is a PCIe read).  The state
+        // column of the first kSplitB k-steps (a 64-node phase: all 17) is requested at once, the A operands run kSplitA
+        // k-steps ahead (L2), instead of one dependent round trip per k-step; longer phases go on in blocks of kSplitB k-steps.
+        constexpr int kSplitB = SPLITB, kSplitA = 2;
+        for (int k0 = 0; k0 < ksteps; k0 += kSplitB) {
+          double bl[kSplitB];
+          gel_double4 a4[kSplitA];
 #pragma unroll
-          for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], bl, acc[t], 0, 0, 0);
+          for (int i = 0; i < kSplitB; i++) bl[i] = bp[min(4u * (k0 + i) + kq, un) * ubs];
+#pragma unroll
+          for (int i = 0; i < kSplitA; i++) a4[i] = ap[min(k0 + i, ksteps - 1) * 64];
+#pragma unroll
+          for (int i = 0; i < kSplitB; i++) {
+            if (k0 + i < ksteps) {   // wave-uniform
+#pragma unroll
+              for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[i % kSplitA][t], bl[i], acc[t], 0, 0, 0);
+              a4[i % kSplitA] = ap[min(k0 + i + kSplitA, ksteps - 1) * 64];
+            }
+          }
         }
         // transpose through the wave's LDS region: tile -> one row (node) per lane
 #pragma unroll
@@ -724,6 +799,9 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         }
       }
     }
+#if !GEL_FRONT_EARLY_T
+    GEL_TAKE_KNOT_TIMES();
+#endif
     if (MFMA && !active) return;  // ragged tail: nothing to write
     // the staging tile has been consumed: the region now becomes the park of what the velocity group
     // needs late (its sweeps re-read quaternion, velocity and D[j][j+1]; its defect needs the D.X row)
@@ -731,19 +809,20 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
     PARK_SET(PK_V0, ve[0]); PARK_SET(PK_V1, ve[1]); PARK_SET(PK_V2, ve[2]);
     if (JAC) PARK_SET(PK_DJJ, djj);
     if (rb) { PARK_SET(PK_LV0, lv[0]); PARK_SET(PK_LV1, lv[1]); PARK_SET(PK_LV2, lv[2]); }
-    // last global loads: the reference rows of engine-off / hold phases
-    const double m0 = (rb && !ph.engine_on) ? xm[ph.xa] : 0.0;
-    double q0[4] = {0, 0, 0, 0};
-    if (rb && ph.hold) {
+    // last global loads: the reference rows of engine-off / hold phases, in the forms without an image of the state rows
+    if (!ref0_done) {
+      if (rb && !ph.engine_on) m0 = xm[ph.xa];
+      if (rb && ph.hold) {
 #pragma unroll
-      for (int c = 0; c < 4; c++) q0[c] = xq[4 * ph.xa + c];
+        for (int c = 0; c < 4; c++) q0[c] = xq[4 * ph.xa + c];
+      }
     }
 
     // ---- everything that needs no velocity RHS is finished here, while its inputs are in registers:
     //      position Jacobian entries, the whole quaternion group (:155-213, :499-632) ----
     if (JAC && lead) {
       // pos/velocity diagonal (:190-196): the same value for every node and component -> one scalar per phase
-      if (j == 0) EMIT_AT(ph.K * n * 8, -P.uv * (tf - to) * ut / 2.0 / P.up);   // behind all chunks' blocks of the phase
+      if (j == 0) EMIT_AT(packed ? (ph.K - sub_hi) * cw8 : ph.K * n * 8, -P.uv * (tf - to) * ut / 2.0 / P.up);   // behind all chunks' blocks of the phase (packed: behind the unit's slots)
 #pragma unroll
       for (int c = 0; c < 3; c++) EMIT(kSlotPT + c, ve[c] * P.uv * ut / 2.0 / P.up);  // t0 column; tf = its negative
     }
@@ -755,7 +834,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         for (int c = 0; c < 4; c++) {
           const double rh = fq[c] * (tf - to) * ut / 2.0;
           const double cq = lq[c] - rh;
-          RSTORE(7 * N + 4 * g + c, cq);  // ordinary store: the interleaved residual rows are partial lines that
+          RSTORE(rs_q + 4 * gn + c, cq);  // ordinary store: the interleaved residual rows are partial lines that
           GEL_CHK(cq);                   // L2 merges; written non-temporally they cost 4 % more HBM writes (PMC)
         }
       }
@@ -810,20 +889,20 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
       } else {
         cm = me - m0;
       }
-      RSTORE(g, cm);
+      RSTORE(rs_m + gn, cm);
       GEL_CHK(cm);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const double rh = ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
         const double cp = lr[c] - rh;
-        RSTORE(N + 3 * g + c, cp);
+        RSTORE(rs_p + 3 * gn + c, cp);
         GEL_CHK(cp);
       }
       if (ph.hold) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const double cq = q[c] - q0[c];
-          RSTORE(7 * N + 4 * g + c, cq);
+          RSTORE(rs_q + 4 * gn + c, cq);
           GEL_CHK(cq);
         }
       }
@@ -944,7 +1023,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           for (int c = 0; c < 3; c++) {
             const double rh = fc[c] * (tf - to) * ut / 2.0;
             const double cv = PARK_GET(PK_LV0 + c) - rh;
-            RSTORE(4 * N + 3 * g + c, cv);
+            RSTORE(rs_v + 3 * gn + c, cv);
             GEL_CHK(cv);
           }
         }
@@ -1180,7 +1259,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         for (int c = 0; c < 3; c++) {
           const double rh = fc[c] * (tf - to) * ut / 2.0;
           const double cv = PARK_GET(PK_LV0 + c) - rh;
-          RSTORE(4 * N + 3 * g + c, cv);
+          RSTORE(rs_v + 3 * gn + c, cv);
           GEL_CHK(cv);
         }
       }
@@ -1235,6 +1314,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #undef FDQ
 #undef GEL_CHK
 #undef GEL_UNI
+#undef GEL_TAKE_KNOT_TIMES
 #undef PARK_GET
 #undef PARK_SET
   GEL_STAMP_AT(7);

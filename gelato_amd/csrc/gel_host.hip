@@ -137,6 +137,13 @@ struct gel_problem {
   struct Run { int64_t dst0, dstride, src0, sstride, len; double sign; };
   std::vector<Run> var_runs;     // the gather map as constant-stride runs (about one per (phase, slot, use): the n nodes)
   std::vector<int32_t> chunk_phase;  // [nchunks] phase of every 64-node work item
+  // packed unit-shard exchange (gel_shard_plan): contiguous unit ranges per rank; every unit's entries of a vector form one
+  // block at unit_base[unit] inside its rank's slice; shard_pos = the map back to the ordinary layouts
+  std::vector<int32_t> shard_begin;  // [nranks + 1]
+  std::vector<int64_t> unit_base;    // [4 * nchunks]
+  int64_t shard_width = 0;
+  int64_t* d_unit_base = nullptr;
+  int64_t* d_shard_pos = nullptr;    // [11N + V]: rank * width + offset of every res entry, then of every compact value
   // aero path constraints: kind 0 = AOA_max, 1 = dynamic_pressure_max, 2 = Q_alpha_max
   std::vector<gel::AeroRowDev> aero_rows[3];
   std::vector<gel::AeroNodeDev> aero_nodes;                   // the constrained state nodes, shared by the kinds
@@ -869,7 +876,7 @@ int gel_problem_destroy(gel_problem* p) {
   hipSetDevice(p->device);
   if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
   hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dsw); hipFree(p->d_Dst); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
-  hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag);
+  hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag); hipFree(p->d_unit_base); hipFree(p->d_shard_pos);
   hipFree(p->d_aero_nodes); hipFree(p->d_aero_x); hipFree(p->d_aero_out);
   free_slots(p);
   hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv);
@@ -1041,6 +1048,115 @@ int gel_unit_owner(const gel_problem* p, int32_t* res_owner, int32_t* jvar_owner
       if (j0 == 0) jvar_owner[h.voff + (int64_t)h.K * h.n] = 4 * item;
     }
   }
+  return GEL_OK;
+}
+
+// Packed unit-shard exchange: the layout every rank agrees on.  Rank r holds units [unit_begin[r], unit_begin[r + 1]); the block
+// of a unit inside its rank's per-vector block: the compact slots it owns as [slot][node of the chunk] (part 0 of an aerodynamic
+// phase: all but slots 6 .. 14; part k > 0: slots 6 + 3 (k - 1) .. + 2), the phase scalar behind them (part 0 of a phase's first
+// chunk), then (part 0) the residual rows mass | position 3 | velocity 3 | quaternion 4 of the chunk's nodes -- what
+// eval_body<.., SPLIT> writes when ProblemDev::shard_width != 0.
+int gel_shard_plan(gel_problem* p, int32_t nranks, const int32_t* unit_begin, int64_t* width, int64_t* res_pos, int64_t* jvar_pos) {
+  if (!p || nranks < 1 || !unit_begin || !width) return fail(GEL_ERR_ARG, "bad argument");
+  const int32_t nunits = 4 * (int32_t)p->chunk_phase.size();
+  if (unit_begin[0] != 0 || unit_begin[nranks] != nunits) return fail(GEL_ERR_ARG, "the unit ranges must cover every unit");
+  for (int r = 0; r < nranks; r++)
+    if (unit_begin[r + 1] < unit_begin[r]) return fail(GEL_ERR_ARG, "the unit ranges must be ordered");
+  const int N = p->dims.N;
+  const int64_t V = p->dims.num_var_entries;
+  std::vector<int64_t> usize(nunits, 0), pos((size_t)11 * N + V, -1);
+  std::vector<int32_t> urank(nunits, 0);
+  for (int r = 0; r < nranks; r++)
+    for (int u = unit_begin[r]; u < unit_begin[r + 1]; u++) urank[u] = r;
+  // sizes first (bases need them), then positions
+  {
+    int item = 0;
+    for (const HostPhase& h : p->ph)
+      for (int j0 = 0; j0 < h.n; j0 += 64, item++) {
+        const int64_t nn = std::min(64, h.n - j0);
+        const int skip = h.air ? 9 : 0;
+        usize[4 * item] = (int64_t)(h.K - skip) * nn + (j0 == 0 ? 1 : 0) + 11 * nn;
+        for (int k = 1; k < 4; k++) usize[4 * item + k] = h.air ? 3 * nn : 0;
+      }
+  }
+  std::vector<int64_t> base(nunits, 0);
+  int64_t w = 0;
+  for (int r = 0; r < nranks; r++) {
+    int64_t off = 0;
+    for (int u = unit_begin[r]; u < unit_begin[r + 1]; u++) { base[u] = off; off += usize[u]; }
+    w = std::max(w, off);
+  }
+  w = (w + 1) & ~(int64_t)1;   // 16-byte multiples: every rank's slice and every vector's block start aligned
+  {
+    int item = 0;
+    for (const HostPhase& h : p->ph)
+      for (int j0 = 0; j0 < h.n; j0 += 64, item++) {
+        const int nn = std::min(64, h.n - j0);
+        const int skip = h.air ? 9 : 0;
+        const int64_t nj = (int64_t)(h.K - skip) * nn + (j0 == 0 ? 1 : 0);
+        const int u0 = 4 * item;
+        const int64_t b0 = (int64_t)urank[u0] * w + base[u0];
+        for (int jl = 0; jl < nn; jl++) {
+          const int j = j0 + jl, g = h.ua + j;
+          pos[g] = b0 + nj + jl;
+          for (int c = 0; c < 3; c++) { pos[N + 3 * g + c] = b0 + nj + nn + 3 * jl + c; pos[4 * N + 3 * g + c] = b0 + nj + 4 * nn + 3 * jl + c; }
+          for (int c = 0; c < 4; c++) pos[7 * N + 4 * g + c] = b0 + nj + 7 * nn + 4 * jl + c;
+          for (int sl = 0; sl < h.K; sl++) {
+            const int part = (h.air && sl >= 6 && sl < 15) ? 1 + (sl - 6) / 3 : 0;
+            const int u = u0 + part;
+            const int local = part ? sl - (6 + 3 * (part - 1)) : (sl >= 6 ? sl - skip : sl);
+            pos[(size_t)11 * N + compact_index(h, sl, j)] = (int64_t)urank[u] * w + base[u] + (int64_t)local * nn + jl;
+          }
+        }
+        if (j0 == 0) pos[(size_t)11 * N + h.voff + (int64_t)h.K * h.n] = b0 + (int64_t)(h.K - skip) * nn;
+      }
+  }
+  for (int64_t v : pos)
+    if (v < 0) return fail(GEL_ERR_ARG, "shard plan: an output entry without an owner (internal)");
+  p->shard_begin.assign(unit_begin, unit_begin + nranks + 1);
+  p->unit_base = base;
+  p->shard_width = w;
+  *width = w;
+  if (res_pos) std::memcpy(res_pos, pos.data(), sizeof(int64_t) * 11 * (size_t)N);
+  if (jvar_pos) std::memcpy(jvar_pos, pos.data() + (size_t)11 * N, sizeof(int64_t) * (size_t)V);
+  if (p->device >= 0) {
+    HIPCHK(hipSetDevice(p->device));
+    hipFree(p->d_unit_base); hipFree(p->d_shard_pos);
+    p->d_unit_base = nullptr; p->d_shard_pos = nullptr;
+    HIPCHK(hipMalloc(&p->d_unit_base, sizeof(int64_t) * (size_t)nunits));
+    HIPCHK(hipMemcpy(p->d_unit_base, base.data(), sizeof(int64_t) * (size_t)nunits, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&p->d_shard_pos, sizeof(int64_t) * pos.size()));
+    HIPCHK(hipMemcpy(p->d_shard_pos, pos.data(), sizeof(int64_t) * pos.size(), hipMemcpyHostToDevice));
+  }
+  return GEL_OK;
+}
+
+int gel_eval_shard_packed_device(gel_problem* p, int32_t B, const double* d_x, double* d_out, int32_t rank, void* stream) {
+  if (!p || !d_x || !d_out || B < 1) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  if (p->shard_width <= 0 || !p->d_unit_base) return fail(GEL_ERR_ARG, "gel_shard_plan has not been called on this handle");
+  const int nranks = (int)p->shard_begin.size() - 1;
+  if (rank < 0 || rank >= nranks) return fail(GEL_ERR_ARG, "rank outside the plan");
+  const int32_t u0 = p->shard_begin[rank], cnt = p->shard_begin[rank + 1] - u0;
+  if (cnt == 0) return GEL_OK;
+  gel::ProblemDev dv = p->dev;
+  dv.chunks = p->d_chunks;  // unit ids refer to the phase-ordered list
+  dv.chunk0 = 0;
+  dv.unit0 = u0;
+  dv.nunits = cnt;
+  dv.shard_width = p->shard_width;
+  dv.unit_base = p->d_unit_base;
+  double* slice = d_out + (size_t)rank * (size_t)B * (size_t)p->shard_width;
+  HIPCHK(gel::launch_eval(dv, B, d_x, slice, slice, stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
+int gel_shard_unpack_device(gel_problem* p, int32_t B, const double* d_out, double* d_res, double* d_jvar, void* stream) {
+  if (!p || !d_out || B < 1 || (!d_res && !d_jvar)) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  if (p->shard_width <= 0 || !p->d_shard_pos) return fail(GEL_ERR_ARG, "gel_shard_plan has not been called on this handle");
+  HIPCHK(gel::launch_shard_unpack(11 * p->dims.N, p->dims.num_var_entries, p->shard_width, B, p->d_shard_pos, d_out, d_res, d_jvar,
+                                  stream ? (hipStream_t)stream : p->stream));
   return GEL_OK;
 }
 

@@ -869,7 +869,7 @@ template <bool JAC, bool MFMA>
 __global__ __launch_bounds__(256) void callback_kernel(ProblemDev P, const double* __restrict__ x, double* __restrict__ res,
                                                        double* __restrict__ jvar, CallbackArgs A) {
   const unsigned b = blockIdx.x;
-  if (b < (unsigned)A.nb_eval) eval_body<JAC, MFMA, true, false>(P, 1, x, res, jvar, b);
+  if (b < (unsigned)A.nb_eval) eval_body<JAC, MFMA, true, false, 17>(P, 1, x, res, jvar, b);
   else if (b < (unsigned)(A.nb_eval + A.nb_aero)) aero_body<true>(P, A.nnodes, A.nodes, A.tiles, 1, x, A.O, b - (unsigned)A.nb_eval);
   else rows_body(P, A.nlin, A.lin, A.nfn, A.fr, 1, A.lin_blocks, x, A.con, A.jfn, b - (unsigned)(A.nb_eval + A.nb_aero));
 }
@@ -1161,6 +1161,30 @@ hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, 
     hipLaunchKernelGGL(expand_kernel, dim3(gx, (nb + kExpandGroup - 1) / kExpandGroup), dim3(kBlock), 0, s, nnz, V, nb,
                        cval, src, d_jvar + (size_t)b0 * V, d_full + (size_t)b0 * nnz);
   }
+  return hipGetLastError();
+}
+
+// pos[i] = rank * width + offset of output entry i (res entries first, then compact Jacobian values): entry i of vector b
+// sits at out[(rank * B + b) * width + offset]
+__global__ __launch_bounds__(kBlock) void shard_unpack_kernel(long long nres, long long V, long long width, int B,
+                                                              const int64_t* __restrict__ pos, const double* __restrict__ out,
+                                                              double* __restrict__ res, double* __restrict__ jvar) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nres + V) return;
+  if ((i < nres) ? (res == nullptr) : (jvar == nullptr)) return;
+  const long long pz = pos[i], r = pz / width, off = pz - r * width;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const double v = out[((size_t)r * B + b) * width + off];
+    if (i < nres) res[(size_t)b * nres + i] = v;
+    else jvar[(size_t)b * V + (i - nres)] = v;
+  }
+}
+
+hipError_t launch_shard_unpack(long long nres, long long V, long long width, int B, const int64_t* pos, const double* out,
+                               double* d_res, double* d_jvar, hipStream_t s) {
+  const unsigned gx = (unsigned)((nres + V + kBlock - 1) / kBlock);
+  const unsigned gy = (unsigned)std::min(B, 4096);
+  hipLaunchKernelGGL(shard_unpack_kernel, dim3(gx, gy), dim3(kBlock), 0, s, nres, V, width, B, pos, out, d_res, d_jvar);
   return hipGetLastError();
 }
 

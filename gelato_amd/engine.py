@@ -82,6 +82,7 @@ class Engine:
         else:
             d.D, d.tau = None, None
         d.device = device
+        self.flags = int(flags)
         d.flags = int(flags)  # 0, or GEL_FLAG_DX_MFMA (1) / GEL_FLAG_DX_VALU (2) to force the D.X path, GEL_FLAG_NO_PACK (4), GEL_FLAG_FD_RECOMPUTE (8)
         h = C.c_void_p()
         check(L.gel_problem_create(C.byref(d), C.byref(h)))
@@ -261,6 +262,26 @@ class Engine:
         """unit = 4 * work_item + part (part 0: all but the three position sweeps; 1..3: one position sweep)."""
         check(lib().gel_eval_shard_units_device(self._h, B, d_x, d_res or None, d_jvar, int(unit_begin),
                                                 int(unit_count), stream or None))
+
+    def shard_plan(self, unit_begin):
+        """Packed unit-shard exchange layout (gel_shard_plan) for ranks holding the contiguous unit ranges
+        [unit_begin[r], unit_begin[r + 1]) -> (width, res_pos [11N], jvar_pos [V]); pos = rank * width + offset."""
+        ub = np.ascontiguousarray(unit_begin, dtype=np.int32)
+        width = C.c_int64(0)
+        rp = np.zeros(self.nres, dtype=np.int64)
+        jp = np.zeros(self.V, dtype=np.int64)
+        _lp = C.POINTER(C.c_int64)
+        check(lib().gel_shard_plan(self._h, len(ub) - 1, ub.ctypes.data_as(_ip), C.byref(width), rp.ctypes.data_as(_lp),
+                                   jp.ctypes.data_as(_lp)))
+        return int(width.value), rp, jp
+
+    def eval_shard_packed_device(self, B, d_x, d_out, rank, stream=0):
+        """rank `rank`'s units of all B vectors straight into its slice of the exchange buffer d_out [nranks][B][width]"""
+        check(lib().gel_eval_shard_packed_device(self._h, B, d_x, d_out, int(rank), stream or None))
+
+    def shard_unpack_device(self, B, d_out, d_res, d_jvar, stream=0):
+        """exchange buffer -> the ordinary res [B][11N] / jvar [B][V] layouts (one gather launch; either may be 0)"""
+        check(lib().gel_shard_unpack_device(self._h, B, d_out, d_res or None, d_jvar or None, stream or None))
 
     def jac_fd(self, group, x):
         gi = GROUPS.index(group)

@@ -8,12 +8,13 @@ replicas      the defect path has no coupling between decision vectors, so a bat
 phase shards  ONE batch evaluated by all ranks together (BASELINE.json config 4): the path is
               block-diagonal per phase (lib/con_dynamics.py:46,132,237,320,512,554) and its forward-difference
               columns are independent, so the UNITS (work item, part) of every vector are dealt to ranks in
-              contiguous, cost-balanced ranges.  A rank evaluates its units into the ordinary res / jvar buffers
-              (entries of other ranks are simply not touched: no zero fill), packs the entries it owns, and ONE
-              all-gather (all_gather_into_tensor) hands every rank every other rank's entries: (N-1)/N of
-              8*(11N + V) bytes per vector (up to padding to the largest share) -- latency-bound over xGMI, which
-              is why replicas are preferred whenever there is more than one vector.  `UnitShards` is that
-              exchange; bench.py --mode phase-shard and the gloo world_size-2 test drive the same object.
+              contiguous, cost-balanced ranges.  A rank's kernel writes the entries its units own STRAIGHT into its
+              slice of one exchange buffer out [world][B][width] (every unit's entries one contiguous run), and ONE
+              in-place all-gather (all_gather_into_tensor, send = out[rank]) completes the buffer on every rank:
+              no pack, no unpack, no zero fill; (N-1)/N of 8*(11N + V) bytes per vector (up to padding to the
+              largest share) -- latency-bound over xGMI, which is why replicas are preferred whenever there is more
+              than one vector.  `UnitShards` is that exchange; bench.py --mode phase-shard and the gloo tests
+              (world sizes 2 and 4, one rank without units) drive the same object.
 """
 import numpy as np
 
@@ -64,71 +65,73 @@ def shard_chunks(costs, world):
 
 
 class UnitShards:
-    """The unit partition of one problem over `world` ranks and the exchange of owned entries.
+    """The unit partition of one problem over `world` ranks and the exchange of owned entries with ZERO pack / unpack launches.
 
-    engine: an Engine (a host-only handle is enough: only the partition is read from it).  The evaluator is any
-    callable ``evaluate(unit_begin, unit_count, res, jvar)`` that fills the entries owned by those units in the
-    [B, 11N] / [B, V] tensors -- Engine.eval_shard_units_device on a GPU."""
+    engine: an Engine (a host-only handle is enough to plan).  Every rank agrees on one exchange buffer
+    ``out [world][B][width]`` (gel_shard_plan): rank r's kernel writes the entries its units own, of all B vectors, straight
+    into its slice out[r] (Engine.eval_shard_packed_device), and ONE in-place all-gather over the slices completes the
+    buffer on every rank.  ``res_pos`` / ``jv_pos`` map the ordinary res / compact-value layouts into it
+    (pos = rank * width + offset); `gather` reads a finished buffer through them, Engine.shard_unpack_device does it in one
+    launch on the device."""
 
     def __init__(self, engine, world, rank):
-        import torch
         self.world, self.rank = int(world), int(rank)
         self.ranges = shard_chunks(unit_costs(engine), world)
-        ro, jo = engine.unit_owner()
-        self.res_idx, self.jv_idx = [], []
-        for (u0, cnt) in self.ranges:
-            self.res_idx.append(torch.from_numpy(np.nonzero((ro >= u0) & (ro < u0 + cnt))[0]))
-            self.jv_idx.append(torch.from_numpy(np.nonzero((jo >= u0) & (jo < u0 + cnt))[0]))
-        self.counts = [(len(a), len(b)) for a, b in zip(self.res_idx, self.jv_idx)]
-        assert sum(c[0] for c in self.counts) == engine.nres and sum(c[1] for c in self.counts) == engine.V
-        self.width = max(a + b for a, b in self.counts)     # doubles per vector and rank in the exchange (padded)
-        self._dev = None
-        self._send = self._recv = None
+        self.unit_begin = np.array([r[0] for r in self.ranges] + [self.ranges[-1][0] + self.ranges[-1][1]], dtype=np.int32)
+        self.width, self.res_pos, self.jv_pos = engine.shard_plan(self.unit_begin)
+        self.nres, self.V = engine.nres, engine.V
+        # entries per rank (what a rank really contributes; the slices are padded to the largest share)
+        self.counts = [(int(np.count_nonzero(self.res_pos // self.width == r)), int(np.count_nonzero(self.jv_pos // self.width == r)))
+                       for r in range(self.world)]
+        assert sum(c[0] for c in self.counts) == self.nres and sum(c[1] for c in self.counts) == self.V
+        assert max(a + b for a, b in self.counts) <= self.width
 
     def bytes_received_per_vector(self):
         """what the one collective delivers to a rank per decision vector, padding included"""
         return 8 * self.width * (self.world - 1)
 
-    def _buffers(self, B, like):
-        if self._send is None or self._send.shape[0] != B or self._send.device != like.device:
-            import torch
-            self._send = torch.empty((B, self.width), dtype=like.dtype, device=like.device)
-            self._recv = torch.empty((self.world, B, self.width), dtype=like.dtype, device=like.device)
-            self.res_idx = [i.to(like.device) for i in self.res_idx]
-            self.jv_idx = [i.to(like.device) for i in self.jv_idx]
-        return self._send, self._recv
-
-    def pack(self, res, jvar, out, rank=None):
-        """the entries rank `rank` (default: this one) owns, of every vector: res rows then compact values -> out [B, width]"""
+    def buffer(self, B, device=None, dtype=None):
+        """the exchange buffer out [world][B][width] (never zero-filled: every entry that is read has an owner)"""
         import torch
-        r = self.rank if rank is None else rank
-        nr, nj = self.counts[r]
-        torch.index_select(res, 1, self.res_idx[r], out=out[:, :nr])
-        torch.index_select(jvar, 1, self.jv_idx[r], out=out[:, nr:nr + nj])
+        return torch.empty((self.world, int(B), self.width), dtype=dtype or torch.float64, device=device)
+
+    def step(self, evaluate_packed, out, group=None):
+        """out [world][B][width] (torch).  ``evaluate_packed(out, rank)`` writes this rank's entries into out[rank]
+        (Engine.eval_shard_packed_device on a GPU); then ONE all-gather, in place: send = out[rank], receive = out.
+        Afterwards every rank holds every entry."""
+        import torch.distributed as dist
+        if self.ranges[self.rank][1] > 0:
+            evaluate_packed(out, self.rank)
+        if self.world > 1:
+            dist.all_gather_into_tensor(out.view(-1), out[self.rank].view(-1), group=group)
         return out
 
-    def unpack(self, recv, res, jvar, skip=None):
-        """recv [world, B, width]: every rank's packed entries -> their places in res / jvar (rank `skip` left alone)"""
-        for r in range(self.world):
-            if r != skip:
-                nr, nj = self.counts[r]
-                res.index_copy_(1, self.res_idx[r], recv[r, :, :nr])
-                jvar.index_copy_(1, self.jv_idx[r], recv[r, :, nr:nr + nj])
-        return res, jvar
+    def flat_index(self, B):
+        """(res_idx [11N], jv_idx [V], stride): entry i of vector b sits at out.view(-1)[idx[i] + b * stride]"""
+        w = self.width
+        f = lambda pos: (pos // w) * (int(B) * w) + pos % w          # noqa: E731
+        return f(self.res_pos), f(self.jv_pos), w
 
-    def step(self, evaluate, res, jvar, group=None):
-        """res [B, 11N], jvar [B, V] (torch).  Evaluates this rank's units, exchanges owned entries with ONE
-        all-gather, and leaves the complete result in res / jvar on every rank.  No buffer is ever zero-filled."""
-        import torch.distributed as dist
-        u0, cnt = self.ranges[self.rank]
-        if cnt > 0:
-            evaluate(u0, cnt, res, jvar)
-        if self.world == 1:
-            return res, jvar
-        send, recv = self._buffers(res.shape[0], res)
-        self.pack(res, jvar, send)
-        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
-        return self.unpack(recv, res, jvar, skip=self.rank)
+    def gather(self, out):
+        """a finished exchange buffer -> (res [B][11N], jvar [B][V]) in the ordinary layouts (host-side reader of the map)"""
+        import torch
+        B = out.shape[1]
+        ri, ji, w = self.flat_index(B)
+        flat = out.reshape(-1)
+        boff = (torch.arange(B, device=out.device) * w)[:, None]
+        ri_t, ji_t = torch.from_numpy(ri).to(out.device)[None, :], torch.from_numpy(ji).to(out.device)[None, :]
+        return flat[ri_t + boff], flat[ji_t + boff]
+
+    def scatter_owned(self, res, jvar, out, rank=None):
+        """the inverse, for one rank's entries: what a packed evaluation of `rank` writes, given the ordinary-layout results
+        (the CPU tests' stand-in for the kernel)"""
+        import torch
+        r = self.rank if rank is None else rank
+        w = self.width
+        rsel, jsel = np.nonzero(self.res_pos // w == r)[0], np.nonzero(self.jv_pos // w == r)[0]
+        out[r][:, torch.from_numpy(self.res_pos[rsel] % w)] = res[:, torch.from_numpy(rsel)]
+        out[r][:, torch.from_numpy(self.jv_pos[jsel] % w)] = jvar[:, torch.from_numpy(jsel)]
+        return out
 
 
 def max_over_ranks(value, device=None, group=None):

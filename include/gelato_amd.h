@@ -173,6 +173,22 @@ int gel_eval_shard_units_device(gel_problem* p, int32_t B, const double* d_x, do
 /* which unit writes which output entry: res_owner [11N], jvar_owner [V] (unit ids as above).  With it ranks owning disjoint
  * unit ranges exchange exactly their own entries (one all-gather, gelato_amd/parallel.py) instead of reducing full buffers. */
 int gel_unit_owner(const gel_problem* p, int32_t* res_owner, int32_t* jvar_owner);
+/* Packed exchange of a unit-sharded evaluation: zero pack / unpack launches around the one collective.  gel_shard_plan fixes the
+ * layout for `nranks` ranks holding the contiguous unit ranges [unit_begin[r], unit_begin[r+1]) (unit_begin[0] = 0,
+ * unit_begin[nranks] = 4 * work items): ONE buffer out [nranks][B][width]; rank r's entries of vector b are the contiguous block
+ * out[r][b][0 .. its share), every unit's entries one contiguous run inside it.  res_pos [11N] / jvar_pos [V] (either may be NULL)
+ * = rank * width + offset of every entry of the ordinary res / compact-value layouts: entry i of vector b sits at
+ * out[(pos / width) * B * width + b * width + pos % width].  gel_eval_shard_packed_device makes rank `rank`'s kernel write its
+ * entries STRAIGHT into its slice out[rank] (all B vectors), so an in-place all-gather over the slices (send = out[rank],
+ * receive = out) completes the buffer on every rank; a consumer reads it through the map, or asks
+ * gel_shard_unpack_device for the ordinary layouts (one gather launch; d_res or d_jvar may be NULL).  A host-only handle can plan
+ * (the CPU tests do); the plan is per handle and replaced by the next call.
+ * (lib/con_dynamics.py:46,132,237,320,512,554: per-phase independence; :381-400: independent forward-difference columns.) */
+int gel_shard_plan(gel_problem* p, int32_t nranks, const int32_t* unit_begin /* [nranks + 1] */, int64_t* width,
+                   int64_t* res_pos /* [11N] or NULL */, int64_t* jvar_pos /* [V] or NULL */);
+int gel_eval_shard_packed_device(gel_problem* p, int32_t B, const double* d_x, double* d_out /* [nranks][B][width] */, int32_t rank,
+                                 void* stream);
+int gel_shard_unpack_device(gel_problem* p, int32_t B, const double* d_out, double* d_res, double* d_jvar, void* stream);
 int gel_num_chunks(const gel_problem* p, int32_t* nchunks);
 int gel_chunk_phase(const gel_problem* p, int32_t* phase /* [nchunks] */);
 /* which form of the fused kernel a launch of B vectors takes: info = {jacobian, D.X on the matrix pipe, split

@@ -158,8 +158,8 @@ def aero_noise_terms(orc, prob, x, spec):
             qq = np.hypot(pos[0], pos[1]) / max(abs(np.cos(lat)), 1e-300)
             dalt = EPS * (qq * (1.0 + C_LAT * abs(lat * np.tan(lat))) + 6.4e6)
             rows.append((a, q, np.sin(a), A, dalt, abs(a2 - a) / 10.0, abs(q2 - q) / 10.0,
-                         np.concatenate([np.abs(xr[xa + k]), np.abs(xv[xa + k]), np.abs(xq[xa + k])])))
-    keys = ("alpha", "q", "sin", "A", "dalt", "dalpha_dalt", "dq_dalt", "xabs")
+                         np.concatenate([np.abs(xr[xa + k]), np.abs(xv[xa + k]), np.abs(xq[xa + k])]), lat_deg))
+    keys = ("alpha", "q", "sin", "A", "dalt", "dalpha_dalt", "dq_dalt", "xabs", "lat_deg")
     return {k: np.array([r[i] for r in rows]) for i, k in enumerate(keys)}
 
 
@@ -213,3 +213,16 @@ def aero_coo_bounds(orc, prob, x, kind, spec, drift_of=None):
         b = aero_bound(terms, kind, lim, dx, position=(var == "position")) + drift
         out[var] = np.concatenate([np.repeat(b[b0:b0 + nk][None, :], w, axis=0).ravel() for b0, nk in blocks]) if w and blocks else np.zeros(0)
     return out
+
+
+def aero_coo_rows(prob, kind, spec):
+    """{var: the constraint row of every gradient entry, in the reference's emission order} (as aero_coo_bounds lays its bounds out)"""
+    nn = [int(v) for v in prob["num_nodes"]]
+    blocks, r0 = [], 0
+    for sp in spec:
+        nk = nn[int(sp[0])] + 1 if int(sp[1]) else 1
+        blocks.append((r0, nk))
+        r0 += nk
+    width = {"position": 3, "velocity": 3, "quaternion": 0 if kind == "q" else 4, "t": 2}
+    return {var: (np.concatenate([np.tile(np.arange(b0, b0 + nk), w) for b0, nk in blocks]) if w and blocks else np.zeros(0, dtype=int))
+            for var, w in width.items()}

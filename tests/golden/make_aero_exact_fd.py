@@ -11,7 +11,7 @@ tests/states.py (all latitudes up to 89.9 degrees in dense air, every atmosphere
 Per case and constrained node: alpha, q, d_alpha [12], d_q [12] = (f_p - f_c)/dx for position xyz, velocity xyz, quaternion wxyz,
 t0, tf.  The t quotients are zero to the working precision: the air-relative velocity does not depend on the Earth angle.
 
-Usage:  python tests/golden/make_aero_exact_fd.py"""
+Usage:  python tests/golden/make_aero_exact_fd.py [--baseline]   (--baseline: mixed-6x64 and one phase of stress-12x128 -> g18b_aero_exact_fd_baseline.npz)"""
 import os
 import sys
 import time
@@ -57,9 +57,23 @@ def state_cases():
         yield name, prob, x, nodes
 
 
+def baseline_cases():
+    """the BASELINE.json workloads themselves: every aerodynamic phase but the last of mixed-6x64, one phase of stress-12x128"""
+    from gelato_amd import con_dynamics, pack_x, problem
+    for name, only in (("mixed-6x64", None), ("stress-12x128", [3])):
+        pdict, unitdict, condition, xdict = problem.make_problem(name)
+        prob = dict(con_dynamics.problem_arrays(pdict, unitdict))
+        x = pack_x(xdict)
+        P = oracle.Problem(prob)
+        prob["tau"] = [P.tau(i) for i in range(P.S)]
+        nodes = [(i, 1) for i in range(P.S - 1) if prob["reference_area"][i] != 0.0 and (only is None or i in only)]
+        yield name, prob, x, nodes
+
+
 def main():
     out = {}
-    for name, prob, x, nodes in list(g9_cases()) + list(state_cases()):
+    baseline = "--baseline" in sys.argv
+    for name, prob, x, nodes in (list(baseline_cases()) if baseline else list(g9_cases()) + list(state_cases())):
         t0 = time.time()
         T = exact_fd.aero_fd_truth(prob, x, nodes)
         out[name + "_x"] = x
@@ -68,7 +82,7 @@ def main():
             out["%s_%s" % (name, k)] = T[k]
         print("%s: %d nodes of phases %s, %.1f s; max |t quotient| %.1e (alpha), %.1e (q)" % (
             name, len(T["alpha"]), [p for p, _ in nodes], time.time() - t0, np.abs(T["d_alpha"][:, 10:]).max(), np.abs(T["d_q"][:, 10:]).max()), flush=True)
-    np.savez_compressed(os.path.join(HERE, "g18_aero_exact_fd.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "g18b_aero_exact_fd_baseline.npz" if baseline else "g18_aero_exact_fd.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ over the sphere at hypersonic speed in thick air, long phases.
 For every aerodynamic phase: f_c [n, 3], and -(f_p - f_c)/dx (tf - to) unit_t / 2 for the mass, position, velocity and
 quaternion sweeps ([n, 3], [n, 3, 3], [n, 3, 3], [n, 3, 4]; last index = perturbed component).
 
-Usage:  python tests/golden/make_exact_fd.py"""
+Usage:  python tests/golden/make_exact_fd.py [--baseline]      (--baseline: the BASELINE.json workloads -> g15b_exact_fd_baseline.npz)"""
 import os
 import sys
 import time
@@ -35,13 +35,24 @@ def example_state():
     return dict(con_dynamics.problem_arrays(pdict, unitdict)), pack_x(xdict)
 
 
+def workload_state(name):
+    from gelato_amd import con_dynamics, pack_x, problem
+    pdict, unitdict, condition, xdict = problem.make_problem(name)
+    return dict(con_dynamics.problem_arrays(pdict, unitdict)), pack_x(xdict)
+
+
 STATES = {"example": example_state, "ragged": states.ragged_state, "polar": states.polar_dense_state,
           "layers": states.all_layers_state, "long": lambda: states.long_state((87, 129, 64)), "breaks": states.layer_break_state}
+# the BASELINE.json workloads themselves (g15b_exact_fd_baseline.npz): every aerodynamic phase of mixed-6x64, and the two
+# aerodynamic phases of stress-12x128 with the densest air (1: KICKTURN) and the highest dynamic pressure (3: ZEROLIFT_END)
+BASELINE_STATES = {"mixed-6x64": lambda: workload_state("mixed-6x64"), "stress-12x128": lambda: workload_state("stress-12x128")}
+BASELINE_PHASES = {"mixed-6x64": None, "stress-12x128": [1, 3]}
 
 
 def main():
     out = {}
-    for name, build in STATES.items():
+    baseline = "--baseline" in sys.argv
+    for name, build in (BASELINE_STATES if baseline else STATES).items():
         prob, x = build()
         P = oracle.Problem(prob)
         prob = dict(prob)
@@ -50,6 +61,8 @@ def main():
         phases = [i for i in range(P.S) if prob["reference_area"][i] != 0.0]
         if name == "example":
             phases = phases[2:4]                          # two of its five aerodynamic phases are enough here
+        if baseline and BASELINE_PHASES[name] is not None:
+            phases = [p for p in BASELINE_PHASES[name] if p in phases]
         out[name + "_phases"] = np.array(phases, dtype=np.int32)
         for ph in phases:
             t0 = time.time()
@@ -58,7 +71,7 @@ def main():
                 out["%s_p%d_%s" % (name, ph, key)] = T[key]
             print("%s phase %d: %d nodes, %.1f s, max |vel/position| %.3g" % (name, ph, len(T["fc"]), time.time() - t0,
                                                                               np.abs(T["position"]).max()), flush=True)
-    np.savez_compressed(os.path.join(HERE, "g15_exact_fd.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "g15b_exact_fd_baseline.npz" if baseline else "g15_exact_fd.npz"), **out)
 
 
 if __name__ == "__main__":

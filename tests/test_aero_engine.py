@@ -35,18 +35,25 @@ def test_aero_pattern_host_only(cname):
         E.aero_configure("alpha", [(3, 1, 0.1), (2, 1, 0.1)])   # phases must increase
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("cname", ["example", "synthetic"])
-def test_aero_values_and_gradients_gpu(cname):
+BENIGN_LAT_DEG, BENIGN_ALPHA_DEG = 55.0, 1.0   # the region the margins table reports separately (moderate latitude, an angle of attack above a degree)
+
+
+def aero_margins(cname, flags=0):
+    """Engine against the REFERENCE's own values (G9) and the oracle, every gradient entry of the three kinds: per (kind, var)
+    the largest difference, the flat allowance of SURVEY 8(c) and how many entries exceed it, the derived allowance
+    (tests/fd_noise.py, two bounds) and the worst excess over it, and the worst flat excess among the rows below
+    BENIGN_LAT_DEG with an angle of attack above BENIGN_ALPHA_DEG -- where the flat tolerance must do on its own.
+    -> table rows; tests/parity_margin.py writes them to profiles/, the test below asserts on them."""
     import oracle
     from gelato_amd import Engine
     g = load_golden("g9_aero_example.npz")
     prob = problem_from_golden(g)
     D, tau = D_tau_from_golden(g, prob)
-    E = Engine(prob, D=D, tau=tau)
+    E = Engine(prob, D=D, tau=tau, flags=flags)
     P = oracle.Problem(prob, D=D, tau=tau)
     x = g["x"]
     X = np.stack([x, x * (1 + 1e-7), x])
+    table = []
     for kind in KINDS:
         spec = spec_from_golden(g, cname, kind)
         E.aero_configure(kind, spec)
@@ -60,15 +67,49 @@ def test_aero_values_and_gradients_gpu(cname):
         for a, b in ((con[0], ref), (con[0], oc), (con[1], P.aero_residual(kind, X[1]))):
             assert np.all(np.abs(a - b) <= CTOL[kind] + 1e-10 * np.abs(b)), (kind, np.abs(a - b).max())
         Jo = P.aero_jacobian(kind, x)
-        bounds = fd_noise.aero_coo_bounds(oracle, dict(prob, tau=tau), x, kind, spec, drift_of={v_: Jo[v_]["coo"][2] for v_ in VARS})
+        pt = dict(prob, tau=tau)
+        bounds = fd_noise.aero_coo_bounds(oracle, pt, x, kind, spec, drift_of={v_: Jo[v_]["coo"][2] for v_ in VARS})
+        terms = fd_noise.aero_noise_terms(oracle, pt, x, spec)
+        rows = fd_noise.aero_coo_rows(pt, kind, spec)
         off = 0
         nrow, nnz = E.aero_dims(kind)
         for v, var in enumerate(VARS):
             vals = jv[0, off:off + nnz[v]]
             off += nnz[v]
-            for rv in (g["%s_%s_jac_%s_vals" % (cname, kind, var)], Jo[var]["coo"][2]):
+            if vals.size == 0:
+                continue
+            lat_ok = np.abs(terms["lat_deg"][rows[var]]) < BENIGN_LAT_DEG
+            a_deg = np.rad2deg(terms["alpha"][rows[var]])
+            benign = lat_ok & (a_deg > BENIGN_ALPHA_DEG)
+            for against, rv in (("reference (G9)", g["%s_%s_jac_%s_vals" % (cname, kind, var)]), ("oracle", Jo[var]["coo"][2])):
                 assert vals.shape == rv.shape
-                assert np.all(np.abs(vals - rv) <= 2.0 * bounds[var] + 1e-9 * np.abs(rv)), (kind, var, np.abs(vals - rv).max())
+                d = np.abs(vals - rv)
+                flat = 1e-5 + 1e-6 * np.abs(rv)
+                derived = 2.0 * bounds[var] + 1e-9 * np.abs(rv)
+                table.append({"fixture": "g9_" + cname, "flags": flags, "kind": kind, "var": var, "against": against, "entries": int(d.size),
+                              "max_abs_diff": float(d.max()), "max_abs_ref": float(np.abs(rv).max()),
+                              "worst_flat_excess": float((d - flat).max()), "entries_needing_derived_allowance": int(np.count_nonzero(d > flat)),
+                              "derived_allowance_max": float(derived[np.isfinite(derived)].max()) if np.isfinite(derived).any() else None,
+                              "worst_derived_excess": float((d - derived)[np.isfinite(derived)].max()) if np.isfinite(derived).any() else None,
+                              "benign_entries": int(benign.sum()),
+                              "worst_flat_excess_benign": float((d - flat)[benign].max()) if benign.any() else None,
+                              # the same figure for other angle-of-attack thresholds (how the benign region was chosen)
+                              "worst_flat_excess_by_alpha_deg": {str(t): (float((d - flat)[lat_ok & (a_deg > t)].max()) if (lat_ok & (a_deg > t)).any() else None)
+                                                                 for t in (0.5, 1.0, 2.0, 5.0, 10.0)},
+                              "min_alpha_deg": float(a_deg.min())})
+    return table
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 8])
+@pytest.mark.parametrize("cname", ["example", "synthetic"])
+def test_aero_values_and_gradients_gpu(cname, flags):
+    for row in aero_margins(cname, flags):
+        what = "%(fixture)s %(kind)s/%(var)s vs %(against)s" % row
+        assert row["worst_derived_excess"] is None or row["worst_derived_excess"] <= 0.0, (what, row["max_abs_diff"])
+        # how many entries lean on the derived allowance (the reference's own noise: q / limit times eps / sin(alpha) / dx for the
+        # q-alpha kind) is on the record: tests/parity_margin.py -> profiles/r04/parity_margins.json; that the DEFAULT engine needs
+        # none of it against the exact quotients at flight-like angles is asserted in tests/test_aero_exact_fd.py
 
 
 @pytest.mark.gpu

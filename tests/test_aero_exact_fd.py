@@ -21,7 +21,8 @@ from test_aero_oracle_golden import KINDS, VARS, spec_from_golden
 
 COLS = {"position": slice(0, 3), "velocity": slice(3, 6), "quaternion": slice(6, 10), "t": slice(10, 12)}
 LIMITS = {"alpha": 0.2, "q": 4.0e4, "qalpha": 5.0e3}
-CASES = ["g9_example", "g9_synthetic", "ragged", "polar", "layers", "breaks"]
+CASES = ["g9_example", "g9_synthetic", "ragged", "polar", "layers", "breaks", "mixed-6x64", "stress-12x128"]
+BASELINE = {"mixed-6x64": None, "stress-12x128": [3]}      # g18b: the BASELINE.json workloads (every aerodynamic phase but the last / one 128-node phase)
 
 
 def case(name):
@@ -33,6 +34,15 @@ def case(name):
         D, tau = D_tau_from_golden(g, prob)
         prob["tau"] = tau
         return prob, D, g["x"], {k: spec_from_golden(g, name[3:], k) for k in KINDS}, g
+    if name in BASELINE:
+        from gelato_amd import con_dynamics, pack_x, problem
+        pdict, unitdict, condition, xdict = problem.make_problem(name)
+        prob, x = dict(con_dynamics.problem_arrays(pdict, unitdict)), pack_x(xdict)
+        P = oracle.Problem(prob)
+        prob["tau"] = [P.tau(i) for i in range(P.S)]
+        specs = {k: np.array([(i, 1, LIMITS[k]) for i in range(P.S - 1) if prob["reference_area"][i] != 0.0 and (BASELINE[name] is None or i in BASELINE[name])])
+                 for k in KINDS}
+        return prob, [P.D(i) for i in range(P.S)], x, specs, None
     build = {"ragged": states.ragged_state, "polar": lambda: states.with_coast_tail(states.polar_dense_state),
              "layers": lambda: states.with_coast_tail(states.all_layers_state),
              "breaks": lambda: states.with_coast_tail(states.layer_break_state)}[name]
@@ -49,7 +59,7 @@ class Truth:
 
     def __init__(self, name, prob, x, kind, spec):
         import oracle
-        G = load_golden("g18_aero_exact_fd.npz")
+        G = load_golden("g18b_aero_exact_fd_baseline.npz" if name in BASELINE else "g18_aero_exact_fd.npz")
         assert np.array_equal(x, G[name + "_x"]), "the state builder no longer reproduces the fixture's decision vector"
         nn = [int(v) for v in prob["num_nodes"]]
         where, i = {}, 0
@@ -74,6 +84,13 @@ class Truth:
         self.terms = fd_noise.aero_noise_terms(oracle, prob, x, spec)
         assert np.allclose(self.terms["alpha"], a, rtol=0, atol=1e-9) and np.allclose(self.terms["q"], q, rtol=1e-9, atol=1e-12)
 
+    def value_bound(self):
+        """per row: what one fp64 evaluation of f = alpha / limit, q / limit or q alpha / limit may be off the exact value (the e_f
+        of tests/fd_noise.py: acos(c) at c -> 1 moves alpha by eps / sin(alpha) per ulp of c) -- beside the flat 1e-11 where the
+        angle of attack is a few 1e-5 rad (the vertical ascent of the BASELINE meshes)"""
+        b = fd_noise.aero_bound(self.terms, self.kind, self.lim, self.dx, position=False) * self.dx / 2.0
+        return np.where(np.isnan(b), 0.0, b)      # inf: the air-relative speed may vanish within the wind table's range (lift-off): alpha is noise there
+
     def coo_order(self, per_row_cols):
         """[R, w] -> the block's values in the reference's emission order: per spec, component-major (con_aero.py:437-463)"""
         return np.concatenate([per_row_cols[r0:r0 + nk].T.ravel() for r0, nk in self.blocks]) if self.blocks else np.zeros(0)
@@ -93,6 +110,7 @@ class Truth:
             ratio = np.where(np.isfinite(bound), err / (bound + 1e-300), 0.0)
         assert ratio.max() <= 1.0, "%s %s/%s: |entry - exact| is %.2f x its bound (err %.3e, |exact| up to %.3g)" % (
             what, self.kind, var, ratio.max(), err[ratio.argmax()], np.abs(exact).max())
+        self.last_flat_excess = err - (1e-5 + 1e-6 * np.abs(self.coo_order(exact)))     # for tests/parity_margin.py
         return ratio.max()
 
 
@@ -109,7 +127,7 @@ def test_oracle_and_reference_within_the_derived_bound_of_the_exact_quotients(na
         P.aero_configure(kind, spec)
         T = Truth(name, prob, x, kind, spec)
         con = P.aero_residual(kind, x)
-        assert np.all(np.abs(con - (1.0 - T.f)) <= 1e-11 + 1e-10 * np.abs(T.f)), (kind, np.abs(con - (1.0 - T.f)).max())
+        assert np.all(np.abs(con - (1.0 - T.f)) <= 1e-11 + 1e-10 * np.abs(T.f) + T.value_bound()), (kind, np.abs(con - (1.0 - T.f)).max())
         J = P.aero_jacobian(kind, x)
         for var in VARS:
             used.append(T.check(var, J[var]["coo"][2], "oracle", with_drift=True))
@@ -133,7 +151,7 @@ def test_engine_within_the_derived_bound_of_the_exact_quotients(name, flags):
         T = Truth(name, prob, x, kind, spec)
         con, jv, rc = E.eval_aero(kind, x[None, :])
         assert rc == 0
-        assert np.all(np.abs(con[0] - (1.0 - T.f)) <= 1e-11 + 1e-10 * np.abs(T.f))
+        assert np.all(np.abs(con[0] - (1.0 - T.f)) <= 1e-11 + 1e-10 * np.abs(T.f) + T.value_bound())
         nrow, nnz = E.aero_dims(kind)
         off = 0
         for v, var in enumerate(VARS):

@@ -58,7 +58,7 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def make_pair(prob, D=None, tau=None, barC20=None):
+def make_pair(prob, D=None, tau=None, barC20=None, flags=0):
     """(engine, oracle problem) on the same static problem and the same D / tau."""
     oracle = _setup()
     from gelato_amd import Engine
@@ -67,7 +67,7 @@ def make_pair(prob, D=None, tau=None, barC20=None):
     if D is None:
         D = [P.D(i) for i in range(P.S)]
         tau = [P.tau(i) for i in range(P.S)]
-    E = Engine(prob, D=D, tau=tau, barC20=bc)
+    E = Engine(prob, D=D, tau=tau, barC20=bc, flags=flags)
     return E, P
 
 
@@ -262,68 +262,99 @@ def test_rhs_shape_errors_like_pybind():
 def reference_noise_per_row(P, prob, x, barC20=None):
     """What the REFERENCE's finite-difference entries of the velocity defect may be off the exact quotient, per residual row
     of the group (tests/fd_noise.py: derived from the arithmetic, checked against exact-arithmetic quotients in
-    tests/test_exact_fd.py): {var: [3N]} -- zero for phases without aerodynamics."""
+    tests/test_exact_fd.py): {var: [3N]} -- zero for phases without aerodynamics; "lat_deg": the node's geodetic latitude
+    (0 where there is no aerodynamics: nothing there needs an allowance)."""
     import fd_noise
     oracle = _setup()
     pr = dict(prob)
     pr["tau"] = [P.tau(i) for i in range(P.S)]
     terms = fd_noise.velocity_noise_terms(oracle, pr, x, barC20)
     N = int(np.sum(prob["num_nodes"]))
-    pos, oth = np.zeros(N), np.zeros(N)
+    pos, oth, lat = np.zeros(N), np.zeros(N), np.zeros(N)
     ua = 0
     for i, n in enumerate(prob["num_nodes"]):
         n = int(n)
         if terms[i] is not None:
             pos[ua:ua + n] = fd_noise.reference_bound(terms[i])
             oth[ua:ua + n] = fd_noise.reference_bound_other(terms[i])
+            lat[ua:ua + n] = np.rad2deg(terms[i]["lat"])
         ua += n
     return {"position": np.repeat(pos, 3), "mass": np.repeat(oth, 3), "velocity": np.repeat(oth, 3),
-            "quaternion": np.repeat(oth, 3), "t": np.repeat(oth, 3)}
+            "quaternion": np.repeat(oth, 3), "t": np.repeat(oth, 3), "lat_deg": np.repeat(lat, 3)}
+
+
+BENIGN_LAT_DEG = 55.0   # the latitude rounds 1-2 kept dense air below; the margins table reports the flat tolerance's excess below it separately
+
+
+def defect_margins(E, P, x, prob=None, barC20=None):
+    """Engine against oracle, every x-dependent Jacobian entry: per block the largest difference, how far it is inside the
+    FLAT tolerance 1e-5 + 1e-6 |ref| of SURVEY 8(c), how many entries need the DERIVED allowance (the reference's own
+    finite-difference noise at that node, velocity group of aerodynamic phases; only when `prob` is given), the largest
+    allowance in use, and the worst flat excess among the rows below BENIGN_LAT_DEG.  -> (rows of the table, res, vals).
+    tests/parity_margin.py writes the table to profiles/; check_against_oracle asserts on it."""
+    oracle = _setup()
+    res, rc = E.eval_residual(x)
+    assert rc == 0
+    vals, rc = E.eval_jacobian(x)
+    assert rc == 0
+    J = E.jac_dicts(vals)
+    var_mask = E.var_mask()
+    noise = reference_noise_per_row(P, prob, x, barC20) if prob is not None else None
+    table, b = [], 0
+    for grp in oracle.GROUPS:
+        Jo = P.jacobian(grp, x)
+        for var in oracle.BLOCK_VARS[grp]:
+            r, c, v = J[grp][var]["coo"]
+            ro, co, vo = Jo[var]["coo"]
+            assert r.dtype == np.int32 and c.dtype == np.int32 and v.dtype == np.float64
+            assert np.array_equal(r, ro) and np.array_equal(c, co), "pattern %s/%s" % (grp, var)
+            assert J[grp][var]["shape"] == Jo[var]["shape"]
+            m = var_mask[E.block_off[b]:E.block_off[b + 1]]
+            assert np.array_equal(v[~m], vo[~m]), "%s/%s constants" % (grp, var)
+            b += 1
+            if not m.any():
+                continue
+            d = np.abs(v - vo)[m]
+            flat = (1e-5 + 1e-6 * np.abs(vo))[m]
+            allow = noise[var][r][m] if (noise is not None and grp == "vel") else np.zeros(d.shape)
+            benign = (np.abs(noise["lat_deg"][r][m]) < BENIGN_LAT_DEG) if (noise is not None and grp == "vel") else np.ones(d.shape, dtype=bool)
+            table.append({"block": "%s/%s" % (grp, var), "entries": int(d.size), "max_abs_diff": float(d.max()),
+                          "max_abs_ref": float(np.abs(vo)[m].max()),
+                          "worst_flat_excess": float((d - flat).max()),           # negative: inside the flat tolerance
+                          "entries_needing_derived_allowance": int(np.count_nonzero(d > flat)),
+                          "derived_allowance_max": float(allow.max()), "worst_total_excess": float((d - flat - allow).max()),
+                          "benign_entries": int(benign.sum()),
+                          "worst_flat_excess_benign": float((d - flat)[benign].max()) if benign.any() else None})
+    return table, res, vals
 
 
 def check_against_oracle(E, P, x, what, prob=None, barC20=None):
     """Engine against oracle: residuals 1e-12 + 1e-10 |ref| (+ the D.X summation bound), constants and pattern bit-exact,
     x-dependent Jacobian entries 1e-5 + 1e-6 |ref| -- plus, for the velocity group of aerodynamic phases when `prob` is given,
     the derived rounding noise of the reference's OWN finite differences at that node (high latitude, dense air: the
-    oracle recomputes like the reference and carries that noise; the engine's exact-difference sweeps do not)."""
+    oracle recomputes like the reference and carries that noise; the engine's exact-difference sweeps do not).  How many
+    entries lean on the allowance is on the record (tests/parity_margin.py -> profiles/r04/parity_margins.json: a handful per
+    extreme state); that the DEFAULT engine needs none of it against the exact quotients is asserted in tests/test_exact_fd.py."""
     oracle = _setup()
-    res, rc = E.eval_residual(x)
-    assert rc == 0
-    vals, rc = E.eval_jacobian(x)
-    assert rc == 0
+    table, res, vals = defect_margins(E, P, x, prob, barC20)
     R = E.split_res(res)
-    J = E.jac_dicts(vals)
-    var_mask = E.var_mask()
     bound = dx_roundoff_bound(E, x)
-    noise = reference_noise_per_row(P, prob, x, barC20) if prob is not None else None
-    b = 0
     for grp in oracle.GROUPS:
         close(R[grp], P.residual(grp, x), atol=1e-12 + bound[grp], what="%s residual %s" % (what, grp))
-        Jo = P.jacobian(grp, x)
-        for var in oracle.BLOCK_VARS[grp]:
-            r, c, v = J[grp][var]["coo"]
-            ro, co, vo = Jo[var]["coo"]
-            assert r.dtype == np.int32 and c.dtype == np.int32 and v.dtype == np.float64
-            assert np.array_equal(r, ro) and np.array_equal(c, co), "%s pattern %s/%s" % (what, grp, var)
-            assert J[grp][var]["shape"] == Jo[var]["shape"]
-            m = var_mask[E.block_off[b]:E.block_off[b + 1]]
-            d = np.abs(v - vo)
-            tol = 1e-5 + 1e-6 * np.abs(vo)
-            if noise is not None and grp == "vel":
-                tol = tol + noise[var][r]
-            assert np.all(d[m] <= tol[m]), "%s %s/%s var max %g (max excess %g)" % (what, grp, var, d[m].max(), (d[m] - tol[m]).max())
-            assert np.array_equal(v[~m], vo[~m]), "%s %s/%s constants" % (what, grp, var)
-            b += 1
+    for row in table:
+        assert row["worst_total_excess"] <= 0.0, "%s %s var max %g (max excess %g)" % (what, row["block"], row["max_abs_diff"], row["worst_total_excess"])
     return res, vals
 
 
+@pytest.mark.parametrize("flags", [0, 8])
 @pytest.mark.parametrize("name", ["example", "3x32", "mixed6x64", "dense6x64", "negarea"])
-def test_residuals_jacobians_vs_golden_and_oracle(name):
+def test_residuals_jacobians_vs_golden_and_oracle(name, flags):
     oracle = _setup()
     g = load_golden("g6_%s.npz" % name)
     prob = problem_from_golden(g)
     D, tau = D_tau_from_golden(g, prob)
-    E, P = make_pair(prob, D, tau, barC20=TW)
+    E, P = make_pair(prob, D, tau, barC20=TW, flags=flags)
+    assert E.flags == flags
     x = g["x"]
     res, vals = check_against_oracle(E, P, x, name)
     R = E.split_res(res)
@@ -345,10 +376,11 @@ def test_residuals_jacobians_vs_golden_and_oracle(name):
                 assert np.all(d <= 1e-5 + 1e-6 * np.abs(ref)), (key, d.max())
 
 
+@pytest.mark.parametrize("flags", [0, 8])
 @pytest.mark.parametrize("name", ["dense-6x64", "mixed-6x64", "stress-12x128"])
-def test_full_size_configs_vs_oracle(name):
+def test_full_size_configs_vs_oracle(name, flags):
     prob, x, _ = named_problem(name)
-    E, P = make_pair(prob)
+    E, P = make_pair(prob, flags=flags)
     check_against_oracle(E, P, x, name)
     if name == "dense-6x64":
         assert E.total_nnz == 745728 and E.algorithmic_bytes == 320072
@@ -792,40 +824,55 @@ def test_unit_shards_compose_to_the_full_evaluation(name, B):
 # --------------------------------------------------------------------------
 # D.X on the matrix pipe (v_mfma_f64_16x16x4_f64) vs wavefront dot-products (VALU)
 # --------------------------------------------------------------------------
-@pytest.mark.parametrize("name,world", [("mixed-6x64", 8), ("mixed-6x64", 3), ("example", 2)])
-def test_unit_shard_exchange_on_one_gpu(name, world):
-    """parallel.UnitShards (what bench.py --mode phase-shard and the gloo test drive) with the ENGINE as the evaluator:
-    every rank's units are evaluated into NaN-filled buffers, the owned entries are packed, the stacked packs stand in
-    for the all-gather, and unpacking must reproduce the unsharded launch bit for bit -- on every rank."""
+@pytest.mark.parametrize("name,world,B", [("mixed-6x64", 8, 5), ("mixed-6x64", 3, 5), ("example", 2, 5), ("stress-12x128", 8, 2),
+                                           ("mixed-6x64", 4, 260), ("ragged", 5, 3)])
+def test_unit_shard_exchange_on_one_gpu(name, world, B):
+    """parallel.UnitShards (what bench.py --mode phase-shard and the gloo tests drive) with the ENGINE writing: every rank's
+    kernel writes the entries of its units STRAIGHT into its slice of a NaN-filled exchange buffer (no pack launch); the
+    buffer with all slices written is what the in-place all-gather leaves on every rank; read through the plan's map -- and
+    through the one-launch device gather -- it must equal the unsharded launch bit for bit (multi-chunk phases, ragged
+    chunks, every phase type; B = 260 compares the unit form with the throughput form of the kernel)."""
     import torch
     from gelato_amd import Engine, parallel, problem
-    prob, x0, _ = named_problem(name)
+    if name == "ragged":
+        from states import ragged_state
+        prob, x0 = ragged_state()
+    else:
+        prob, x0, _ = named_problem(name)
     E = Engine(prob)
-    B = 5
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
-    dX = torch.from_numpy(problem.synthetic_batch(x0, E.M, B, seed=3)).to(dev)
+    X = problem.synthetic_batch(x0, E.M, min(B, 8), seed=3)
+    X = np.tile(X, (B // len(X) + 1, 1))[:B]
+    dX = torch.from_numpy(X).to(dev)
     ref_r = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
     ref_j = torch.empty((B, E.V), dtype=torch.float64, device=dev)
     E.eval_batch_device(B, dX.data_ptr(), ref_r.data_ptr(), ref_j.data_ptr(), s)
     assert E.sync(s) == 0
-    shards = [parallel.UnitShards(E, world, r) for r in range(world)]
-    bufs, packs = [], []
-    for r, sh in enumerate(shards):
-        res = torch.full((B, E.nres), float("nan"), dtype=torch.float64, device=dev)
-        jv = torch.full((B, E.V), float("nan"), dtype=torch.float64, device=dev)
-        u0, cnt = sh.ranges[r]
-        if cnt:
-            E.eval_shard_units_device(B, dX.data_ptr(), res.data_ptr(), jv.data_ptr(), u0, cnt, s)
-        send, _ = sh._buffers(B, res)
-        packs.append(sh.pack(res, jv, send).clone())
-        bufs.append((res, jv))
+    sh = parallel.UnitShards(E, world, 0)
+    out = sh.buffer(B, dev)
+    out.fill_(float("nan"))
+    for r in range(world):                                     # what the ranks do side by side, one after the other here
+        E.eval_shard_packed_device(B, dX.data_ptr(), out.data_ptr(), r, s)
     assert E.sync(s) == 0
-    recv = torch.stack(packs)                                  # what all_gather_into_tensor delivers
-    for r, sh in enumerate(shards):
-        res, jv = sh.unpack(recv, *bufs[r], skip=r)
-        assert torch.equal(res, ref_r) and torch.equal(jv, ref_j), r
-    assert shards[0].bytes_received_per_vector() <= 8 * (E.nres + E.V) * (world - 1) / world * 1.6
+    res, jv = sh.gather(out)
+    assert torch.equal(res, ref_r) and torch.equal(jv, ref_j)
+    # every rank wrote its own slice only, and exactly as many entries as it owns (the padded tail stays NaN)
+    for r in range(world):
+        written = int((~torch.isnan(out[r, 0])).sum())
+        assert written == sum(sh.counts[r]), (r, written, sh.counts[r])
+    r2 = torch.full_like(ref_r, float("nan"))
+    j2 = torch.full_like(ref_j, float("nan"))
+    E.shard_unpack_device(B, out.data_ptr(), r2.data_ptr(), j2.data_ptr(), s)
+    assert E.sync(s) == 0
+    assert torch.equal(r2, ref_r) and torch.equal(j2, ref_j)
+    # the slices are padded to the largest share; the cut balances COST, not bytes: never more than gathering whole buffers, and
+    # within 1.6 x of the ideal (N-1)/N on the 6-phase mesh the mode is meant for
+    assert sh.bytes_received_per_vector() <= 8 * (E.nres + E.V) * (world - 1) + 16 * world
+    if name in ("mixed-6x64", "example"):
+        assert sh.bytes_received_per_vector() <= 8 * (E.nres + E.V) * (world - 1) / world * 1.6 + 16
+    with pytest.raises(Exception):
+        E.eval_shard_packed_device(B, dX.data_ptr(), out.data_ptr(), world, s)
 
 
 @pytest.mark.parametrize("name", ["example", "mixed-6x64", "stress-12x128"])

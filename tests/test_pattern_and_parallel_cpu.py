@@ -154,9 +154,9 @@ E = Engine(prob, D=[P.D(i) for i in range(P.S)], tau=[P.tau(i) for i in range(P.
 x = g["x"]
 
 # ---- phase-shard mode: the SAME object bench.py --mode phase-shard drives (parallel.UnitShards), on the unit partition
-#      of a host-only handle.  The oracle is only the source of the values a rank "computes": the stand-in evaluator
-#      writes exactly the entries its units own (gel_unit_owner) into buffers that are otherwise NaN, so nothing can
-#      lean on a zero fill, and one all-gather must complete them. ----
+#      of a host-only handle.  The oracle is only the source of the values a rank "computes": the stand-in for the kernel
+#      writes exactly the entries its units own (the plan's map, cross-checked against gel_unit_owner) into ITS slice of an
+#      exchange buffer that is otherwise NaN, so nothing can lean on a zero fill, and ONE in-place all-gather completes it. ----
 B = 3
 X = np.tile(x, (B, 1)) * (1 + 1e-7 * np.arange(B))[:, None]
 ores, ovals = P.eval_batch(X)
@@ -165,24 +165,43 @@ ro, jo = E.unit_owner()
 assert ro.min() == 0 and jo.max() < 4 * E.num_chunks()
 sh = parallel.UnitShards(E, world, rank)
 assert len(sh.ranges) == world and sum(c for _, c in sh.ranges) == 4 * E.num_chunks()
+if {empty_rank} >= 0:
+    # a rank without units (more ranks than a cost-balanced cut can feed): its slice is never written, never read
+    ub = sh.unit_begin.copy()
+    ub[{empty_rank} + 1:-1] = np.maximum(ub[{empty_rank} + 1:-1], ub[{empty_rank}])
+    ub[{empty_rank} + 1] = ub[{empty_rank}]
+    sh.ranges = [(int(ub[r]), int(ub[r + 1] - ub[r])) for r in range(world)]
+    sh.unit_begin = ub
+    sh.width, sh.res_pos, sh.jv_pos = E.shard_plan(ub)
+    assert sh.ranges[{empty_rank}][1] == 0
+# the plan agrees with the ownership table: an entry lies in the slice of the rank that holds its unit, and the entries of
+# one unit form one contiguous run
+owner_rank = np.searchsorted(sh.unit_begin, ro, side="right") - 1
+assert np.array_equal(sh.res_pos // sh.width, owner_rank)
+owner_rank_j = np.searchsorted(sh.unit_begin, jo, side="right") - 1
+assert np.array_equal(sh.jv_pos // sh.width, owner_rank_j)
+allpos = np.concatenate([sh.res_pos, sh.jv_pos]); allown = np.concatenate([ro, jo])
+assert len(np.unique(allpos)) == len(allpos)
+for u in np.unique(allown):
+    pu = np.sort(allpos[allown == u])
+    assert pu[-1] - pu[0] + 1 == len(pu), "unit %d is not one contiguous run" % u
 calls = []
 
-def evaluate_units(u0, cnt, res, jvar):
-    calls.append((u0, cnt))
-    mr = torch.from_numpy((ro >= u0) & (ro < u0 + cnt))
-    mj = torch.from_numpy((jo >= u0) & (jo < u0 + cnt))
-    res[:, mr] = torch.from_numpy(ores)[:, mr]
-    jvar[:, mj] = torch.from_numpy(full_jv)[:, mj]
+def evaluate_packed(out, r):
+    calls.append(r)
+    sh.scatter_owned(torch.from_numpy(ores), torch.from_numpy(full_jv), out, r)
 
-res = torch.full((B, E.nres), float("nan"), dtype=torch.float64)
-jv = torch.full((B, E.V), float("nan"), dtype=torch.float64)
-for _ in range(2):                       # twice: the exchange buffers are reused
-    sh.step(evaluate_units, res, jv)
-assert calls == [sh.ranges[rank]] * 2
-assert np.array_equal(res.numpy(), ores), "residual after the all-gather"
-assert np.array_equal(jv.numpy(), full_jv), "jacobian after the all-gather"
+out = sh.buffer(B)
+for it in range(2):                       # twice: the exchange buffer is reused
+    out.fill_(float("nan"))
+    sh.step(evaluate_packed, out)
+    res, jv = sh.gather(out)
+    assert np.array_equal(res.numpy(), ores), "residual after the all-gather"
+    assert np.array_equal(jv.numpy(), full_jv), "jacobian after the all-gather"
+assert calls == ([rank] * 2 if sh.ranges[rank][1] > 0 else [])
 # one collective per step, delivering (world-1)/world of the outputs up to padding to the largest share
-assert sh.bytes_received_per_vector() <= 8 * (E.nres + E.V) * (world - 1) / world * 1.6
+if {empty_rank} < 0:
+    assert sh.bytes_received_per_vector() <= 8 * (E.nres + E.V) * (world - 1) / world * 1.6
 
 # ---- replica mode: vectors split across ranks, slowest rank defines the time ----
 B = 5
@@ -201,16 +220,16 @@ print("WORKER_OK", rank)
 """
 
 
-def test_world_size_2_gloo(tmp_path):
+def run_gloo_world(tmp_path, world, empty_rank=-1):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.replace("{empty_rank}", str(empty_rank)).replace("{root!r}", repr(ROOT)))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
@@ -224,6 +243,14 @@ def test_world_size_2_gloo(tmp_path):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "WORKER_OK %d" % r in out, out[-3000:]
+
+
+def test_world_size_2_gloo(tmp_path):
+    run_gloo_world(tmp_path, 2)
+
+
+def test_world_size_4_gloo_with_a_rank_without_units(tmp_path):
+    run_gloo_world(tmp_path, 4, empty_rank=2)
 
 
 @pytest.mark.parametrize("seed", range(12))

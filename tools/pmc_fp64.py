@@ -54,4 +54,7 @@ if a and b:
     out["fp64_pipe_busy"] = out["valu_busy"] + out["mfma_busy"]
 out["source"] = ("tools/gpu_record.sh -> rocprofv3 --kernel-trace --pmc, two passes (fp64 instruction counters; cycles and busy counters), "
                  "bench.py --steps 4 --warmup 1 --settle-ms 0; profiled passes run at a lower clock than un-profiled ones")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from gelato_amd import _lib  # noqa: E402  (provenance only: which build these counters describe)
+out.update({"build_" + k: v for k, v in _lib.build_info().items()})
 print(json.dumps(out, indent=1))
