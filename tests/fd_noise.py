@@ -170,11 +170,15 @@ def aero_bound(terms, kind, limit, dx, position):
         e_alpha = EPS * (C_ACOS / terms["sin"] + C_DIR * terms["A"])
         e_q = EPS * terms["q"] * (C_Q * (1.0 + terms["A"]) + (C_RHO if position else 0.0))
         e_alpha = np.where(terms["alpha"] > 0.0, e_alpha, np.inf)     # c_alpha > 1 is clamped to 0: not differentiable there
-        e_q = np.where(np.isfinite(e_q), e_q, 0.0)                    # no air: q = 0 in every evaluation
+        e_q = np.where(np.isnan(e_q), 0.0, e_q)                       # no air: q = 0 in every evaluation (0 * inf); q > 0 where the
+                                                                      # air-relative speed may vanish (lift-off): unbounded, not checked
     if position:
         e_alpha = e_alpha + terms["dalpha_dalt"] * terms["dalt"]
         e_q = e_q + terms["dq_dalt"] * terms["dalt"]
-    e_f = {"alpha": e_alpha, "q": e_q, "qalpha": terms["q"] * e_alpha + terms["alpha"] * e_q}[kind]
+    def times(a, e):     # a * e with 0 * inf = 0: a factor that is exactly zero in every evaluation (no air; the clamped angle) carries no noise
+        with np.errstate(invalid="ignore"):
+            return np.where(a == 0.0, 0.0, a * e)
+    e_f = {"alpha": e_alpha, "q": e_q, "qalpha": times(terms["q"], e_alpha) + times(terms["alpha"], e_q)}[kind]
     return 2.0 * e_f / dx / limit
 
 
