@@ -57,7 +57,7 @@ static_assert(kWaveLds - kCoopStageOff >= 64 * 11, "the cooperative hand-over ar
 constexpr int kSlabRowsMax = 68, kPackRows = 36, kParkRes = (PK_LV2 + 1) * 64;
 constexpr int kPipeSlabK = 11;   // k-steps per double-buffered slab of the long-phase form (44 state rows)
 constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack, bool split = false) {
-  return jac ? kWaveLds : (!mfma ? kParkRes : (split ? 64 * kStageLd /* one wavefront's own result tile */ : (pack ? 2 * kPackRows * 11 : (GEL_XLDS_PIPE ? 2 * 4 * kPipeSlabK * 11 : kSlabRowsMax * 11))));
+  return jac ? kWaveLds : (!mfma ? kParkRes : (split ? 64 * kStageLd /* one wavefront's own result tile */ : (pack ? kParkRes + 4 * 64 /* operand image (792), then park + the tile of the transposed residual stores */ : (GEL_XLDS_PIPE ? 2 * 4 * kPipeSlabK * 11 : kSlabRowsMax * 11))));
 }
 static_assert(wave_lds_doubles(false, true, false, true) >= kParkRes, "residual-only split form: park over the result tile");
 static_assert(wave_lds_doubles(false, true, true) >= 64 * 11 && wave_lds_doubles(false, true, false) >= 64 * 11, "hand-over area");
@@ -229,6 +229,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // the others; it reads vector B - 1 and leaves after the hand-over without writing anything
   const int bw = PACK ? b0 + 2 * wv + half : b0 + wv;
   const bool ghost = COOP && bw >= B;
+  const bool pack_full = PACK && __builtin_amdgcn_ballot_w64(ghost) == 0;   // both vectors of this wavefront exist (wave-uniform)
   const int b = COOP ? min(bw, B - 1) : (int)(item - (long long)q * B);
   const int ci = SPLIT ? ((P.unit0 + q) >> 2) : q;
   const int part = SPLIT ? ((P.unit0 + q) & 3) : 0;  // wave-uniform
@@ -360,6 +361,55 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #else
 #define RSTORE(idx, val) rb[idx] = (val)
 #endif
+  // Residual rows as CONTIGUOUS stores.  The reference's layout is node-major ([node][x y z], [node][w x y z]): written lane =
+  // node, a store instruction puts 8 bytes every 24 / 32 bytes -- 24 / 32 partial 64-byte write requests per instruction, three or
+  // four instructions per line.  Measured (round 4, mixed-6x64, B = 65536, same box): the residual rows are 17 % of the stored
+  // bytes and cost 36 % of what all stores cost (3.41 ms; without the residual stores 3.06 ms; without any store 2.43 ms); written
+  // as below: -5 % of the launch (tools/ab_variants.py: 3.487 -> 3.313 ms).  A full
+  // 64-node chunk therefore turns its w values per node through an LDS tile (node-major in, 64-wide rows out: one wavefront's
+  // LDS operations execute in order, no barrier) and writes w contiguous 512-byte segments.  Ragged chunks (lanes past the phase
+  // have left) keep the strided form.  -DGEL_RES_XPOSE=0: the strided form everywhere (A/B).
+#ifndef GEL_RES_XPOSE
+#define GEL_RES_XPOSE 1
+#endif
+  // Two vectors per wavefront (PACK): the tile holds half 0's rows then half 1's ([w * lane + c] does that by itself); row i of
+  // the tile belongs to the vector of half (64 i + lane) / (32 w), so a lane may store the OTHER half's values: only in a
+  // wavefront whose two vectors both exist (no ghost half) and whose phase has exactly 32 nodes.
+  constexpr int kTileOff = JAC ? PK_FP0 * 64 : kParkRes;     // phase A: slots FP0.. are not in use yet (residual-only: behind the park)
+  constexpr bool kCanXpose = (GEL_RES_XPOSE != 0) && (kWL >= kTileOff + 4 * 64);
+  // whole lines, written once and never read by this kernel: non-temporal like the Jacobian values (the strided form's partial
+  // lines want to meet in L2 first: written non-temporally they cost 4 % more HBM writes, round 2)
+#ifndef GEL_RES_NT
+#define GEL_RES_NT 1
+#endif
+#if defined(GEL_ABL_NORES)
+#define RSTORE_LINE(ptr, val) do { if ((val) == 1.2345e300) *(ptr) = (val); } while (0)
+#elif GEL_RES_NT
+#define RSTORE_LINE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define RSTORE_LINE(ptr, val) *(ptr) = (val)
+#endif
+#define xpose (kCanXpose && (PACK ? (cw8 == 256 && pack_full) : cw8 == 512))   /* wave-uniform: every lane holds a node (cw8 = 8 nn is in an SGPR anyway) */
+#define RSTORE_ROWS(tile, w, rs_off, vals)                                                                   \
+  do {                                                                                                       \
+    _Pragma("unroll") for (int c_ = 0; c_ < (w); c_++) GEL_CHK((vals)[c_]);                                  \
+    if (xpose) {                                                                                             \
+      lds_double* t_ = (tile);                                                                               \
+      _Pragma("unroll") for (int c_ = 0; c_ < (w); c_++) t_[(w) * lane + c_] = (vals)[c_];                   \
+      _Pragma("unroll") for (int i_ = 0; i_ < (w); i_++) {                                                   \
+        const double v_ = t_[64 * i_ + lane];                                                                \
+        if (PACK) {                                                                                          \
+          const int e_ = 64 * i_ + lane, h_ = (e_ >= 32 * (w)) ? 1 : 0;                                      \
+          double* rbh_ = res + (size_t)(b0 + 2 * wv + h_) * 11 * N;                                          \
+          RSTORE_LINE(rbh_ + (rs_off) + (w) * ph.ua + (e_ - 32 * (w) * h_), v_);                             \
+        } else {                                                                                             \
+          RSTORE_LINE(rb + (rs_off) + (w) * (gn - lane) + 64 * i_ + lane, v_);                               \
+        }                                                                                                    \
+      }                                                                                                      \
+    } else {                                                                                                 \
+      _Pragma("unroll") for (int c_ = 0; c_ < (w); c_++) RSTORE((rs_off) + (w) * gn + c_, (vals)[c_]);       \
+    }                                                                                                        \
+  } while (0)
   const double inv_uv = wave_uniform(1.0 / P.uv);   // the same for both halves of a two-vector wavefront
 #define FDQ(fp, fc) (((fc) - (fp)) * fds)
 
@@ -830,13 +880,10 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
       double fq[4];
       quat_rate(q, u0, u1, P.uu, fq);
       if (rb) {
+        double cq[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const double rh = fq[c] * (tf - to) * ut / 2.0;
-          const double cq = lq[c] - rh;
-          RSTORE(rs_q + 4 * gn + c, cq);  // ordinary store: the interleaved residual rows are partial lines that
-          GEL_CHK(cq);                   // L2 merges; written non-temporally they cost 4 % more HBM writes (PMC)
-        }
+        for (int c = 0; c < 4; c++) cq[c] = lq[c] - fq[c] * (tf - to) * ut / 2.0;
+        RSTORE_ROWS(wave_lds + kTileOff, 4, rs_q, cq);   // ordinary (not non-temporal) stores: non-temporal ones cost 4 % more HBM writes (PMC, round 2)
       }
       if (JAC && ph.q_fd) {
         double f[4];
@@ -891,20 +938,17 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
       }
       RSTORE(rs_m + gn, cm);
       GEL_CHK(cm);
+      {
+        double cp[3];
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const double rh = ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
-        const double cp = lr[c] - rh;
-        RSTORE(rs_p + 3 * gn + c, cp);
-        GEL_CHK(cp);
+        for (int c = 0; c < 3; c++) cp[c] = lr[c] - ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
+        RSTORE_ROWS(wave_lds + kTileOff, 3, rs_p, cp);
       }
       if (ph.hold) {
+        double cq[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const double cq = q[c] - q0[c];
-          RSTORE(rs_q + 4 * gn + c, cq);
-          GEL_CHK(cq);
-        }
+        for (int c = 0; c < 4; c++) cq[c] = q[c] - q0[c];
+        RSTORE_ROWS(wave_lds + kTileOff, 4, rs_q, cq);
       }
     }
   }
@@ -1018,13 +1062,26 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           GEL_TDC(Tdc);
           accel_parts(Tdc, F, inv_m, pp.g, inv_uv, tm, fc);
         }
-        if (rb) {  // velocity defect (:216-289)
+        if (rb) {  // velocity defect (:216-289); its D.X row leaves slots LV0-2, which then serve as the tile of the transposed store
+#ifndef GEL_RES_XPOSE_VEL_AIR
+#define GEL_RES_XPOSE_VEL_AIR 1   // A/B.  This store sits in the middle of the Jacobian store stream: written contiguously it is worth
+                                  // -4.5 % of the mixed-6x64 launch, -0.5 % dense, -1.1 % 12 x 128 (the other residual groups, all
+                                  // in phase A, together -0.5 %; tools/ab_variants.py, round 4).  The three residuals at once are
+                                  // three more values live at the register peak: the allocator answers by spilling the clamped node
+                                  // index, which is only reloaded on rare paths (a late first need of the Earth angle, the audit sweeps)
+#endif
+          if (!JAC || GEL_RES_XPOSE_VEL_AIR) {
+            double cv[3];
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const double rh = fc[c] * (tf - to) * ut / 2.0;
-            const double cv = PARK_GET(PK_LV0 + c) - rh;
-            RSTORE(rs_v + 3 * gn + c, cv);
-            GEL_CHK(cv);
+            for (int c = 0; c < 3; c++) cv[c] = PARK_GET(PK_LV0 + c) - fc[c] * (tf - to) * ut / 2.0;
+            RSTORE_ROWS(wave_lds + PK_LV0 * 64, 3, rs_v, cv);
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const double cv = PARK_GET(PK_LV0 + c) - fc[c] * (tf - to) * ut / 2.0;
+              RSTORE(rs_v + 3 * gn + c, cv);
+              GEL_CHK(cv);
+            }
           }
         }
         if (JAC) {   // the half-latitude pair and 1/p wait in the slots of the D.X row for the position sweeps
@@ -1255,13 +1312,10 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
       for (int c = 0; c < 3; c++) { tm[c] = Td[c] * inv_m; fc[c] = (tm[c] + gc[c]) * inv_uv; }   // accel_noair(), keeping T d / m
       if (rb) {  // velocity defect (:216-289)
+        double cv[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const double rh = fc[c] * (tf - to) * ut / 2.0;
-          const double cv = PARK_GET(PK_LV0 + c) - rh;
-          RSTORE(rs_v + 3 * gn + c, cv);
-          GEL_CHK(cv);
-        }
+        for (int c = 0; c < 3; c++) cv[c] = PARK_GET(PK_LV0 + c) - fc[c] * (tf - to) * ut / 2.0;
+        RSTORE_ROWS(wave_lds + PK_LV0 * 64, 3, rs_v, cv);
       }
       if (JAC) {
         double f[3];
@@ -1311,6 +1365,9 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #undef GEL_MASS_CLOSED
 #undef EMIT_AT
 #undef RSTORE
+#undef RSTORE_ROWS
+#undef RSTORE_LINE
+#undef xpose
 #undef FDQ
 #undef GEL_CHK
 #undef GEL_UNI

@@ -431,6 +431,9 @@ def test_batch_matches_single_and_oracle():
 
 
 @pytest.mark.parametrize("name,Bs", [("example", (1, 2, 3, 5, 30, 31)), ("mixed-6x64", (45, 46, 47, 257)),
+                                     # 32-node phases, two vectors per wavefront: odd batches leave a wavefront with ONE vector (its
+                                     # residual rows then keep the strided store; full wavefronts write both vectors' rows through the tile)
+                                     ("3x32", (1, 3, 7, 8, 9, 33)),
                                      ("stress-12x128", (11, 13, 37, 70))])   # 37, 70: 10 / 18 vector groups = one / two
                                                                              # blocks of eight plus a short one (launch order)
 def test_cooperative_dx_form_equals_single_vector_calls(name, Bs):
