@@ -272,7 +272,7 @@ def main():
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) / K
 
     # (1) `value`: exactly the contract -- W untimed warm-up steps, then K timed steps.  From an idle GPU these sit inside the
-    # chip's start-up power transient (tools/launch_series.py: first launch fast, a dip ~3 ms later, steady after ~40 ms).
+    # chip's start-up power transient (per-launch durations from an idle GPU: first launch fast, a dip ~3 ms later, steady after ~40 ms).
     # Warm-up: the W untimed steps of the contract -- and, when a step is short, more of them until WARM_MS of launches have
     # gone by (same count on every rank): 5 steps of 0.3 ms end inside the start-up dip of the clock, and the K timed steps
     # would measure the transient, not the kernel (3 x 32 residual-only: 167 M evals/s against 204 M).

@@ -363,12 +363,13 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #endif
   // Residual rows as CONTIGUOUS stores.  The reference's layout is node-major ([node][x y z], [node][w x y z]): written lane =
   // node, a store instruction puts 8 bytes every 24 / 32 bytes -- 24 / 32 partial 64-byte write requests per instruction, three or
-  // four instructions per line.  Measured (round 4, mixed-6x64, B = 65536, same box): the residual rows are 17 % of the stored
-  // bytes and cost 36 % of what all stores cost (3.41 ms; without the residual stores 3.06 ms; without any store 2.43 ms); written
-  // as below: -5 % of the launch (tools/ab_variants.py: 3.487 -> 3.313 ms).  A full
-  // 64-node chunk therefore turns its w values per node through an LDS tile (node-major in, 64-wide rows out: one wavefront's
-  // LDS operations execute in order, no barrier) and writes w contiguous 512-byte segments.  Ragged chunks (lanes past the phase
-  // have left) keep the strided form.  -DGEL_RES_XPOSE=0: the strided form everywhere (A/B).
+  // four instructions per line.  A full 64-node chunk instead turns its w values per node through an LDS tile (node-major in,
+  // 64-wide rows out: one wavefront's LDS operations execute in order, no barrier) and writes w contiguous 512-byte segments:
+  // L1 -> L2 write requests per evaluation 4,070 -> 3,200 at mixed-6x64.  What it buys in TIME is inside the noise of where the
+  // driver places a process's 14 GB of buffers (+-3 % between processes of one build; pooled A/B of round 4: +-1 % against the
+  // strided form) -- the launch is bound by package power, and the bytes are the same.  Measured on the way (same box, round 4):
+  // the residual rows are 17 % of the stored bytes and, removed entirely, 9-10 % of the launch (3.41 -> 3.06 ms; without any store
+  // 2.43 ms).  Ragged chunks (lanes past the phase have left) keep the strided form.  -DGEL_RES_XPOSE=0: strided everywhere (A/B).
 #ifndef GEL_RES_XPOSE
 #define GEL_RES_XPOSE 1
 #endif
@@ -1064,11 +1065,10 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         }
         if (rb) {  // velocity defect (:216-289); its D.X row leaves slots LV0-2, which then serve as the tile of the transposed store
 #ifndef GEL_RES_XPOSE_VEL_AIR
-#define GEL_RES_XPOSE_VEL_AIR 1   // A/B.  This store sits in the middle of the Jacobian store stream: written contiguously it is worth
-                                  // -4.5 % of the mixed-6x64 launch, -0.5 % dense, -1.1 % 12 x 128 (the other residual groups, all
-                                  // in phase A, together -0.5 %; tools/ab_variants.py, round 4).  The three residuals at once are
-                                  // three more values live at the register peak: the allocator answers by spilling the clamped node
-                                  // index, which is only reloaded on rare paths (a late first need of the Earth angle, the audit sweeps)
+#define GEL_RES_XPOSE_VEL_AIR 0   // with derivatives this store keeps the strided form: the three residuals at once are three more values
+                                  // live at the register peak of the kernel, and the allocator answers with reloads inside the light
+                                  // sweeps (20 B of scratch against 12 B whose reloads sit on rare paths only).  Pooled A/B (three
+                                  // processes per build, 1-s turns): within +-1 % of the tile form on mixed / dense / 12 x 128
 #endif
           if (!JAC || GEL_RES_XPOSE_VEL_AIR) {
             double cv[3];
