@@ -141,7 +141,7 @@ def with_coast_tail(build, n_tail=2):
                                  quat, np.tile(quat[-4:], rep), u, np.zeros(2 * n_tail), t, [t[-1] + 0.01]])
 
 
-def layer_break_state():
+def layer_break_state(n_max=None):
     """One aerodynamic phase whose nodes sit within a few centimetres of the breaks of the atmosphere layers (geopotential 11, 20, 32, 47,
     51, 71 km), of the geopotential branch (86 km geometric) and of the wind table's pieces (1, 3, 11, 15, 16, 23 km): the position
     step of a sweep (dx * unit = 6.4 cm) carries some of them across -- what the exact-difference forms hand back to the recomputing
@@ -152,6 +152,8 @@ def layer_break_state():
     breaks_h = [11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0, 1000.0, 3000.0, 15000.0, 16000.0, 23000.0]
     alt = [r0 * h / (r0 - h) + off for h in breaks_h for off in (-0.04, -0.004, 0.004, 0.04)] + [86000.0 + off for off in (-0.04, -0.004, 0.004, 0.04)]
     alt = np.array(alt + [5000.0])
+    if n_max is not None:            # a phase that fits two-vectors-per-wavefront launches: the first n_max + 1 of them
+        alt = alt[:n_max + 1]
     n = len(alt) - 1
     prob["num_nodes"] = np.array([n], dtype=np.int32)
     for k, v in [("thrust", 420000.0), ("massflow", 140.9), ("reference_area", 2.21), ("nozzle_area", 0.68)]:

@@ -1140,3 +1140,36 @@ def test_path_sincos_and_log_accuracy():
     ul = np.abs(out[:, 4] - ref) / np.spacing(np.maximum(np.abs(ref), 1e-300))
     assert ul[inside].max() <= 2.0
     assert np.array_equal(out[~inside, 4], out[~inside, 5])
+
+
+def test_position_sweep_entries_do_not_depend_on_wavefront_neighbours():
+    """A node within centimetres of an atmosphere-layer or wind-table break sends its WAVEFRONT through the recomputing fallback
+    of the position sweeps.  A covered lane must write the same bits whether or not a neighbour did that -- in a two-vectors-per-
+    wavefront launch the neighbour is another decision vector (round 3 took density, pressure and 1/a from the
+    difference form but wind and the latitude pair from the recomputation inside the fallback).  Vector `xb` (nodes on the breaks)
+    and vector `xc` (the same nodes 50 m higher: no fallback) in every pairing inside one launch."""
+    import torch
+    import states
+    from gelato_amd import Engine
+    prob, xb = states.layer_break_state(n_max=32)
+    E = Engine(prob, flags=1)                     # matrix pipe: two vectors per wavefront (one 32-node phase)
+    M = E.M
+    xc = xb.copy()
+    pos = xc[M:4 * M].reshape(-1, 3)
+    pos *= (1.0 + 50.0 / (np.linalg.norm(pos, axis=1, keepdims=True) * prob["units"][1]))
+    B = 1024                                      # the cooperative form (a handful of vectors would take the split form)
+    assert E.launch_info(B)[4] == 1 and E.launch_info(B)[2] == 0
+    pat = [xb, xc, xc, xb, xb, xb, xc, xc]        # (xb, xc), (xc, xb), (xb, xb), (xc, xc): the four pairings of one workgroup
+    X = np.stack([pat[i % 8] for i in range(B)])
+    res, jv, rc = E.eval_batch(X)
+    assert rc == 0
+    ib = [i for i in range(B) if pat[i % 8] is xb]
+    ic = [i for i in range(B) if pat[i % 8] is xc]
+    for idx in (ib, ic):
+        assert all(np.array_equal(jv[idx[0]], jv[i]) for i in idx[1:]), "a vector's Jacobian bits depend on its wavefront neighbour"
+        assert all(np.array_equal(res[idx[0]], res[i]) for i in idx[1:])
+    assert not np.array_equal(jv[ib[0]], jv[ic[0]])
+    # and the one-vector-per-wavefront form gives the same bits for both
+    E1 = Engine(prob, flags=1 | 4)
+    r1, j1, rc = E1.eval_batch(np.stack([xb, xc, xb, xc]))
+    assert rc == 0 and np.array_equal(j1[0], jv[ib[0]]) and np.array_equal(j1[1], jv[ic[0]])

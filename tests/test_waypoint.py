@@ -416,3 +416,24 @@ def test_device_downrange_rows_vs_reference_golden(cname):
                 for a_, b_ in zip(got, pos3 + [tval]):
                     assert abs(a_ - b_) <= tol + 1e-6 * abs(b_), (base, ir, a_, b_, tol)
             assert not rp and not rt
+
+
+@pytest.mark.gpu
+def test_one_row_groups_return_fresh_jacobian_arrays():
+    """A group with exactly ONE row: `jfn[a:a+1, 0:3]` is contiguous, so ravel() is a view of the engine's buffer, which the next
+    callback overwrites.  The values returned for the first decision vector must still be there after a second one
+    has been evaluated."""
+    from gelato_amd import con_waypoint as cw
+    cond = {"waypoint": {"SEIG": {"altitude": {"exact": 1.0e5}, "lat_IIP": {"min": 20.0}}},
+            "antenna": {"ANT": {"lon": 143.45659, "lat": 42.50587, "altitude": 50.0, "elevation_min": {"SECO": 0.0}}}}
+    pdict, unitdict, condition, xdict = example(cond, device=None)
+    x2 = {k: v * (1.0 + 1e-3) if k in ("position", "velocity") else v.copy() for k, v in xdict.items()}
+    for jf in (cw.equality_jac_posLLH, cw.inequality_jac_IIP, cw.inequality_jac_antenna):
+        first = jf(xdict, pdict, unitdict, condition)
+        keep = {var: blk["coo"][2].copy() for var, blk in first.items()}
+        assert all(len(v) in (1, 3) for v in keep.values())            # one row: three position / velocity values, one t value
+        second = jf(x2, pdict, unitdict, condition)
+        for var in keep:
+            assert np.array_equal(first[var]["coo"][2], keep[var]), (jf.__name__, var, "the first call's values changed under the second")
+            assert not np.shares_memory(first[var]["coo"][2], second[var]["coo"][2])
+        assert any(not np.array_equal(second[var]["coo"][2], keep[var]) for var in keep)
