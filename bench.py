@@ -351,6 +351,8 @@ def main():
     traffic = None if tdata is None else tdata.get("hbm_bytes_per_launch")
     info = E.launch_info(B, True, not a.residual_only)   # which instantiation the launcher picked
     kname = "gel::eval_kernel<%s, %s, %s, %s>" % tuple("true" if v else "false" for v in (info[0], info[1], info[2], info[4]))
+    if shard:   # a unit range always runs the split (latency) form, one decision vector per wavefront
+        kname = "gel::eval_kernel<true, %s, true, false>" % ("true" if info[1] else "false")
     out = {
         "metric": "residual+Jacobian evals/sec (and ms/eval), 6-phase x 64-node LGR mesh",
         "value": evals / T, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
