@@ -1173,3 +1173,28 @@ def test_position_sweep_entries_do_not_depend_on_wavefront_neighbours():
     E1 = Engine(prob, flags=1 | 4)
     r1, j1, rc = E1.eval_batch(np.stack([xb, xc, xb, xc]))
     assert rc == 0 and np.array_equal(j1[0], jv[ib[0]]) and np.array_equal(j1[1], jv[ic[0]])
+
+
+def test_packed_unit_shards_with_the_recomputing_form():
+    """GEL_FLAG_FD_RECOMPUTE changes the slot layout of a node (separate t0 / tf and finite-difference quaternion slots: 62 / 50 / 42
+    per node); the packed exchange layout follows it: every rank's slice through the plan's map equals the unsharded launch."""
+    import torch
+    from gelato_amd import Engine, parallel, problem
+    prob, x0, _ = named_problem("mixed-6x64")
+    E = Engine(prob, flags=8)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    B = 3
+    dX = torch.from_numpy(problem.synthetic_batch(x0, E.M, B, seed=9)).to(dev)
+    ref_r = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    ref_j = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    E.eval_batch_device(B, dX.data_ptr(), ref_r.data_ptr(), ref_j.data_ptr(), s)
+    assert E.sync(s) == 0
+    sh = parallel.UnitShards(E, 8, 0)
+    out = sh.buffer(B, dev)
+    out.fill_(float("nan"))
+    for r in range(8):
+        E.eval_shard_packed_device(B, dX.data_ptr(), out.data_ptr(), r, s)
+    assert E.sync(s) == 0
+    res, jv = sh.gather(out)
+    assert torch.equal(res, ref_r) and torch.equal(jv, ref_j)
