@@ -68,6 +68,29 @@ int main(int argc, char** argv) {
       CHECK(r[k] >= 0 && r[k] < dm.block_shape[b][0] && c[k] >= 0 && c[k] < dm.block_shape[b][1]);
     free(r); free(c);
   }
+  {
+    /* the packed unit-shard exchange layout is a host computation: three ranks over the 12 units (3 work items x 4 parts) */
+    const int32_t ub[4] = {0, 3, 6, 12};
+    int64_t width = 0;
+    int64_t* rpos = malloc(sizeof(int64_t) * 11 * dm.N);
+    int64_t* jpos = malloc(sizeof(int64_t) * dm.num_var_entries);
+    int32_t* rown = malloc(sizeof(int32_t) * 11 * dm.N);
+    int32_t* jown = malloc(sizeof(int32_t) * dm.num_var_entries);
+    CHECK(gel_shard_plan(p, 3, ub, &width, rpos, jpos) == GEL_OK && width > 0 && width % 2 == 0);
+    CHECK(gel_unit_owner(p, rown, jown) == GEL_OK);
+    char* seen = calloc((size_t)(3 * width), 1);
+    for (int64_t i = 0; i < 11 * dm.N + dm.num_var_entries; i++) {
+      const int64_t ps = i < 11 * dm.N ? rpos[i] : jpos[i - 11 * dm.N];
+      const int32_t un = i < 11 * dm.N ? rown[i] : jown[i - 11 * dm.N];
+      CHECK(ps >= 0 && ps < 3 * width && !seen[ps]);            /* every entry has a place of its own ... */
+      seen[ps] = 1;
+      CHECK(ps / width == (un < 3 ? 0 : (un < 6 ? 1 : 2)));       /* ... in the slice of the rank that holds its unit */
+    }
+    const int32_t bad[4] = {0, 3, 2, 12};
+    CHECK(gel_shard_plan(p, 3, bad, &width, NULL, NULL) == GEL_ERR_ARG);          /* ranges must be ordered and cover every unit */
+    CHECK(gel_shard_plan(p, 3, ub, &width, NULL, NULL) == GEL_OK);
+    free(seen); free(rpos); free(jpos); free(rown); free(jown);
+  }
   double D5[5 * 6], tau5[5];
   CHECK(gel_problem_D(p, 0, D5) == GEL_OK && gel_problem_tau(p, 0, tau5) == GEL_OK && tau5[4] == 1.0);
   for (int j = 0; j < 5; j++) { double s = 0; for (int i = 0; i < 6; i++) s += D5[j * 6 + i]; CHECK(fabs(s) < 1e-12); }
@@ -77,6 +100,7 @@ int main(int argc, char** argv) {
   double* vals = malloc(sizeof(double) * dm.total_nnz);
   if (!gpu) {
     CHECK(gel_eval_residual(p, x, res) == GEL_ERR_HIP); /* host-only handles never evaluate */
+    CHECK(gel_eval_shard_packed_device(p, 1, x, res, 0, NULL) == GEL_ERR_HIP);
     {
       static double tx[77], table[77 * GEL_OUTPUT_COLUMNS];
       CHECK(gel_output_table(p, x, tx, 42.5, 143.4, table) == GEL_ERR_HIP);

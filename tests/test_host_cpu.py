@@ -204,3 +204,20 @@ def test_jac_fd_of_a_user_function_matches_reference_loop(tmp_path, monkeypatch)
     assert con_user.inequality_jac_user(xd, pdict, unitdict, None) is None
     sys.modules.pop("user_constraints", None)
     monkeypatch.setattr(con_user, "_mod", None)
+
+
+def test_static_counter_files_name_their_build():
+    """profiles/traffic_*.json / fp64_*.json (what bench.py reads into roofline.traffic / roofline.fp64) carry the sha256 of the
+    library they were recorded with, and the four BASELINE workloads are on record for ONE build: bench.py reports them only for
+    that library (`null` + the reason otherwise)."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "fp64_*.json")))
+    assert len(files) == 8
+    shas = set()
+    for f in files:
+        d = json.load(open(f))
+        assert isinstance(d.get("build_so_sha256"), str) and len(d["build_so_sha256"]) == 64, f
+        assert "workload" in d and "batch" in d, f
+        shas.add(d["build_so_sha256"])
+    assert len(shas) == 1
