@@ -365,7 +365,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
   // node, a store instruction puts 8 bytes every 24 / 32 bytes -- 24 / 32 partial 64-byte write requests per instruction, three or
   // four instructions per line.  A full 64-node chunk instead turns its w values per node through an LDS tile (node-major in,
   // 64-wide rows out: one wavefront's LDS operations execute in order, no barrier) and writes w contiguous 512-byte segments:
-  // L1 -> L2 write requests per evaluation 4,070 -> 3,200 at mixed-6x64.  What it buys in TIME is inside the noise of where the
+  // L1 -> L2 write requests per evaluation 3,367 -> 3,047 at mixed-6x64 (TCP_TCC_WRITE_REQ).  What it buys in TIME is inside the noise of where the
   // driver places a process's 14 GB of buffers (+-3 % between processes of one build; pooled A/B of round 4: +-1 % against the
   // strided form) -- the launch is bound by package power, and the bytes are the same.  Measured on the way (same box, round 4):
   // the residual rows are 17 % of the stored bytes and, removed entirely, 9-10 % of the launch (3.41 -> 3.06 ms; without any store
