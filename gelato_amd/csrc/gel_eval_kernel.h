@@ -467,8 +467,6 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           xoff[ct] = PACK ? (vb >> 1) * kWL + (vb & 1) * kPackRows * 11 + col + kq * 11 : vb * kWL + col + kq * 11;
         }
         gel_double4 acc[3];
-#pragma unroll
-        for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
         const double* ap = P.Dst + (size_t)dsw * 4 + (PACK ? (wv & 1) : wv) * 64 + lane;
         const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4) <= kSlabK: the phase is one slab
         // Every load of phase A is REQUESTED before anything waits: the A slabs first (they do not depend on x: L2), then the
@@ -487,7 +485,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         }
         // State rows: lane = row for rows 0 .. 63 (eleven loads, addresses clamped into the phase: no branch around a load);
         // the few rows behind them (64 .. 67; two vectors per wavefront: 64 .. 71) element by element, lane e -> row e / 11,
-        // column e % 11 (one or two loads).  Rows past the phase meet zero columns of D: written as zeros.
+        // column e % 11 (one or two loads).  Rows past the phase meet zero columns of D.
         constexpr int kRowsStaged = PACK ? 2 * kPackRows : kSlabRows, kExtra = (kRowsStaged - 64) * 11;
         double st[11], sx[(kExtra + 63) / 64];
         {
@@ -512,18 +510,16 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
             sx[i] = xe[off];
           }
           // ---- first wait of the wavefront ----
-          const bool in = k <= n;
+          // A row past the phase (k > n) was fetched from the clamped address, i.e. it holds a copy of row n: it meets a zero
+          // column of D, and 0 * (a finite value) adds nothing -- as in the split form, which clamps the same way.  (If row n is not
+          // finite the product is not either, with or without the copies: row n has non-zero entries of D in every node's row.)
           lds_double* dst = wave_lds + lane * 11;
 #pragma unroll
-          for (int c = 0; c < 11; c++) dst[c] = in ? st[c] : 0.0;
+          for (int c = 0; c < 11; c++) dst[c] = st[c];
 #pragma unroll
           for (int i = 0; i < (kExtra + 63) / 64; i++) {
             const int e = lane + 64 * i;
-            if (e < kExtra) {
-              const int rr = 64 + e / 11;
-              const int kx = PACK ? rr - kPackRows * (rr / kPackRows) : rr;
-              wave_lds[64 * 11 + e] = (kx <= n) ? sx[i] : 0.0;
-            }
+            if (e < kExtra) wave_lds[64 * 11 + e] = sx[i];
           }
         }
         stage_tables_commit(P, lds, tab_mine);
@@ -537,16 +533,21 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         if (kAAll) {
 #pragma unroll
           for (int ks = 0; ks < kAllN; ks++) {
-            if (ks < klast) {   // wave-uniform
+            if (ks == 0 || ks < klast) {   // wave-uniform; a phase has at least one k-step (the no-D.X ablation multiplies one, too)
               const int ro = ks * 44;                                        // 4 rows of 11 columns per k-step
               const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
-              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl0, acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl1, acc[1], 0, 0, 0);
-              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl2, acc[2], 0, 0, 0);
+              // the first k-step takes the constant 0 as its C operand (an inline operand of the instruction) instead of
+              // accumulators that twenty-four v_mov have cleared
+              const gel_double4 zero4 = gel_double4{0.0, 0.0, 0.0, 0.0};
+              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl0, ks ? acc[0] : zero4, 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl1, ks ? acc[1] : zero4, 0, 0, 0);
+              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl2, ks ? acc[2] : zero4, 0, 0, 0);
             }
           }
         } else {
           // k-steps of A slabs in flight ahead of the matrix pipe (an L2 round trip each; the first ones requested before the barrier)
+#pragma unroll
+          for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
           for (int ks = 0; ks < klast; ks += kAPF) {
 #pragma unroll
             for (int i = 0; i < kAPF; i++) {
