@@ -251,7 +251,12 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   const int xj = ph.xa + 1 + jc;  // its state row (x-node j+1)
   const int M = P.M, N = P.N;
 
+#ifdef GEL_ABL_XWRAP   // experiment (tools/build_variants.sh): every decision vector is read from one of the first GEL_ABL_XWRAP
+  // vectors of x -- the state rows come from L2 / the Infinity Cache: what a perfect prefetch of x would buy
+  const double* xb = x + (size_t)(b & (GEL_ABL_XWRAP - 1)) * P.nvars;
+#else
   const double* xb = x + (size_t)b * P.nvars;
+#endif
   const double* xm = xb;
   const double* xr = xb + M;
   const double* xv = xb + 4 * M;
