@@ -21,6 +21,7 @@ struct PhaseDev {
   int32_t toff;       // offset of tau
   int64_t voff;       // offset of this phase in the compact Jacobian vector
   double thrust, massflow, area, nozzle;
+  double mf_um;       // -massflow / unit_mass, divided on the host (the same IEEE division the kernel used to repeat in every lane)
 };
 
 #ifdef __HIPCC__
@@ -40,7 +41,7 @@ __device__ __forceinline__ PhaseDev load_phase(const PhaseDev* g) {
   q.s_vv = load_const(&g->s_vv); q.s_vq = load_const(&g->s_vq); q.s_vt = load_const(&g->s_vt); q.s_qq = load_const(&g->s_qq);
   q.doff = load_const(&g->doff); q.toff = load_const(&g->toff); q.voff = load_const(&g->voff);
   q.thrust = load_const(&g->thrust); q.massflow = load_const(&g->massflow); q.area = load_const(&g->area);
-  q.nozzle = load_const(&g->nozzle);
+  q.nozzle = load_const(&g->nozzle); q.mf_um = load_const(&g->mf_um);
   return q;
 }
 #endif
@@ -95,6 +96,12 @@ struct ProblemDev {
   const double* tables;      // atm[77] (gel_physics.h kAtmDoubles) | wind[Kw*3] | ca[Kc*2]
   int32_t* flag;             // non-finite flag
   double um, up, uv, uu, ut, dx, barC20;
+  // wave-uniform quotients formed once on the host instead of by a division sequence (12 instructions) per lane and use:
+  // 1 / unit_v and 1 / dx (bit-identical to the device division), and unit_v unit_t / 2 / unit_p -- the factor of the position
+  // defect's right-hand side and of its t columns (lib/con_dynamics.py:146-152,196-210), which the reference multiplies out per
+  // element: v kpt differs from ((v unit_v) unit_t / 2) / unit_p by <= 2 ulp
+  double inv_uv, inv_dx, kpt;
+  double hT;   // unit_t / 2 (exact)
 };
 
 }  // namespace gel

@@ -274,7 +274,10 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   const double to_ld = xt[sec], tf_ld = xt[sec + 1];
   double to = 0.0, tf = 0.0, fds = 0.0, fdt = 0.0;
   const double dx = P.dx, ut = P.ut;
-  const double inv_dx = 1.0 / dx;
+  // unit_t / 2 (exact): v * unit_t / 2.0 as the reference writes it is round(v unit_t) / 2 = round(v (unit_t / 2)) -- scaling by a power
+  // of two commutes with the rounding -- so `v * hT` has the same bits with one multiplication less per value
+  const double hT = P.hT;
+  const double inv_dx = P.inv_dx;
   // Jacobian entry from a perturbed/centre pair: -(f_p - f_c)/dx*(tf-to)*unit_t/2  (con_dynamics.py:372),
   // as (f_c - f_p) times the wave-uniform scale (tf-to)*unit_t/2/dx
 #define GEL_TAKE_KNOT_TIMES()                                   \
@@ -417,7 +420,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
       _Pragma("unroll") for (int c_ = 0; c_ < (w); c_++) RSTORE((rs_off) + (w) * gn + c_, (vals)[c_]);       \
     }                                                                                                        \
   } while (0)
-  const double inv_uv = wave_uniform(1.0 / P.uv);   // the same for both halves of a two-vector wavefront
+  const double inv_uv = P.inv_uv;   // 1 / unit_v, divided on the host
 #define FDQ(fp, fc) (((fc) - (fp)) * fds)
 
   // ======================= phase A: every global load =======================
@@ -880,9 +883,9 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
     //      position Jacobian entries, the whole quaternion group (:155-213, :499-632) ----
     if (JAC && lead) {
       // pos/velocity diagonal (:190-196): the same value for every node and component -> one scalar per phase
-      if (j == 0) EMIT_AT(packed ? (ph.K - sub_hi) * cw8 : ph.K * n * 8, -P.uv * (tf - to) * ut / 2.0 / P.up);   // behind all chunks' blocks of the phase (packed: behind the unit's slots)
+      if (j == 0) EMIT_AT(packed ? (ph.K - sub_hi) * cw8 : ph.K * n * 8, -(P.kpt * (tf - to)));   // behind all chunks' blocks of the phase (packed: behind the unit's slots)
 #pragma unroll
-      for (int c = 0; c < 3; c++) EMIT(kSlotPT + c, ve[c] * P.uv * ut / 2.0 / P.up);  // t0 column; tf = its negative
+      for (int c = 0; c < 3; c++) EMIT(kSlotPT + c, ve[c] * P.kpt);  // t0 column; tf = its negative
     }
     if (!ph.hold && lead) {
       double fq[4];
@@ -890,7 +893,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
       if (rb) {
         double cq[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) cq[c] = lq[c] - fq[c] * (tf - to) * ut / 2.0;
+        for (int c = 0; c < 4; c++) cq[c] = lq[c] - fq[c] * (tf - to) * hT;
         RSTORE_ROWS(wave_lds + kTileOff, 4, rs_q, cq);   // ordinary (not non-temporal) stores: non-temporal ones cost 4 % more HBM writes (PMC, round 2)
       }
       if (JAC && ph.q_fd) {
@@ -916,7 +919,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 8 + 4 * k + c, FDQ(f[c], fq[c]));
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 16 + c, fq[c] * ut / 2.0);  // t0 column; tf = its negative
+        for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 16 + c, fq[c] * hT);  // t0 column; tf = its negative
       } else if (JAC) {
         // dq = q (x) (0, 0, omega_y, omega_z) / 2 is linear in q and in u (src/pybind_dynamics.cpp:94-106), so the reference's
         // difference quotients ARE its partial derivatives up to the rounding of two evaluations (1e-8 of |dq|): the sixteen
@@ -932,14 +935,14 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         EMIT(ph.s_qq + 4, kq * q[2]);
         EMIT(ph.s_qq + 5, kq * q[3]);
 #pragma unroll
-        for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 6 + c, fq[c] * ut / 2.0);  // t0 column; tf = its negative
+        for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 6 + c, fq[c] * hT);  // t0 column; tf = its negative
       }
     }
     if (rb) {
       // ---- mass, position (and hold-type quaternion) defects (:34-63,116-152,521-522) ----
       double cm;
       if (ph.engine_on) {
-        const double rh = -ph.massflow / P.um * (tf - to) * ut / 2.0;
+        const double rh = ph.mf_um * (tf - to) * ut / 2.0;
         cm = lm - rh;
       } else {
         cm = me - m0;
@@ -948,8 +951,9 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
       GEL_CHK(cm);
       {
         double cp[3];
+        const double kpos = P.kpt * (tf - to);   // unit_v (tf - to) unit_t / 2 / unit_p, wave-uniform
 #pragma unroll
-        for (int c = 0; c < 3; c++) cp[c] = lr[c] - ve[c] * P.uv * (tf - to) * ut / 2.0 / P.up;
+        for (int c = 0; c < 3; c++) cp[c] = lr[c] - ve[c] * kpos;
         RSTORE_ROWS(wave_lds + kTileOff, 3, rs_p, cp);
       }
       if (ph.hold) {
@@ -1080,12 +1084,12 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           if (!JAC || GEL_RES_XPOSE_VEL_AIR) {
             double cv[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) cv[c] = PARK_GET(PK_LV0 + c) - fc[c] * (tf - to) * ut / 2.0;
+            for (int c = 0; c < 3; c++) cv[c] = PARK_GET(PK_LV0 + c) - fc[c] * (tf - to) * hT;
             RSTORE_ROWS(wave_lds + PK_LV0 * 64, 3, rs_v, cv);
           } else {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-              const double cv = PARK_GET(PK_LV0 + c) - fc[c] * (tf - to) * ut / 2.0;
+              const double cv = PARK_GET(PK_LV0 + c) - fc[c] * (tf - to) * hT;
               RSTORE(rs_v + 3 * gn + c, cv);
               GEL_CHK(cv);
             }
@@ -1155,7 +1159,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           // uses for the phases without aerodynamics (:478-480); GEL_FLAG_FD_RECOMPUTE keeps the two sweeps (below).
           if (!ph.t_fd) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * ut / 2.0);  // t0 column; tf = its negative
+            for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * hT);  // t0 column; tf = its negative
           }
         }
         if (JAC) {   // quaternion and D[j][j+1] are no longer needed: their slots take f_c and the thrust direction
@@ -1321,7 +1325,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
       if (rb) {  // velocity defect (:216-289)
         double cv[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) cv[c] = PARK_GET(PK_LV0 + c) - fc[c] * (tf - to) * ut / 2.0;
+        for (int c = 0; c < 3; c++) cv[c] = PARK_GET(PK_LV0 + c) - fc[c] * (tf - to) * hT;
         RSTORE_ROWS(wave_lds + PK_LV0 * 64, 3, rs_v, cv);
       }
       if (JAC) {
@@ -1361,7 +1365,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           }
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * ut / 2.0);  // t0 column; tf = its negative
+        for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * hT);  // t0 column; tf = its negative
       }
     }
   }

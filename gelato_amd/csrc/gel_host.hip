@@ -751,6 +751,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     q.K = h.K; q.s_vv = h.s_vv; q.s_vq = h.s_vq; q.s_vt = h.s_vt; q.s_qq = h.s_qq;
     q.doff = (int32_t)Dt.size(); q.toff = (int32_t)tau.size(); q.voff = h.voff;
     q.thrust = h.thrust; q.massflow = h.massflow; q.area = h.area; q.nozzle = h.nozzle;
+    q.mf_um = -h.massflow / p->um;
     for (int c = 0; c <= h.n; c++)
       for (int j = 0; j < h.n; j++) Dt.push_back(h.D[(size_t)j * (h.n + 1) + c]);
     tau.insert(tau.end(), h.tau.begin(), h.tau.end());
@@ -866,6 +867,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     dv.vmajor = (nmax <= 32 && !(d->flags & GEL_FLAG_ITEM_MAJOR)) ? 1 : 0;
   }
   dv.um = p->um; dv.up = p->up; dv.uv = p->uv; dv.uu = p->uu; dv.ut = p->ut; dv.dx = p->dx; dv.barC20 = p->barC20;
+  dv.inv_uv = 1.0 / p->uv; dv.inv_dx = 1.0 / p->dx; dv.kpt = p->uv * p->ut / 2.0 / p->up; dv.hT = p->ut * 0.5;
   *out = p;
   return GEL_OK;
 }

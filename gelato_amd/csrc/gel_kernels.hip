@@ -493,7 +493,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     for (int c = 0; c < 3; c++) { AP_SET(AP_W + c, w[c]); AP_SET(AP_A0 + c, a0[c]); AP_SET(AP_DIR + c, dir[c]); }
     AP_SET(AP_RHO, pp.rho); AP_SET(AP_NV2, nv2);
   }
-  const double inv_dx = 1.0 / dx;
+  const double inv_dx = P.inv_dx;   // 1 / dx, divided on the host (same bits)
   // One gradient entry of every kind that has this node, jac = -(f_p - f_c)/dx (con_aero.py:437-463), from the perturbed point's
   // air velocity a (squared norm nv2), body axis d (1/|d| = ind) and density: alpha_p - alpha_c in exact-difference form
   // (aero_dalpha; a wavefront with a lane it does not cover takes two acos like the reference), q_p - q_c as it is, and

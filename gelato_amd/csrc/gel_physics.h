@@ -250,12 +250,12 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
     o.T = Tmb + Lmb * (h - Hb);
   } else if (h <= 110000.0) {
     const double Tc = 263.1905, A = -76.3232, a = -19942.9;
-    o.T = Tc + A * sqrt(1.0 - (h - 91000.0) * (h - 91000.0) / a / a);
+    o.T = Tc + A * fsqrt(1.0 - fdiv(fdiv((h - 91000.0) * (h - 91000.0), a), a));   // fdiv: the compiler's division without its range guards, same bits
   } else if (h <= 120000.0) {
     o.T = Tmb + Lmb * (h - Hb);
   } else {
     const double Tinf = 1000.0;
-    const double xi = (h - Hb) * (r0 + Hb) / (r0 + h);
+    const double xi = fdiv((h - Hb) * (r0 + Hb), r0 + h);
     o.T = Tinf - (Tinf - Tmb) * exp(-0.01875e-3 * xi);
   }
   // pressure: src/Air.cpp:90-98
