@@ -144,6 +144,9 @@ template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, int SPLITB
 __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const double* __restrict__ x, double* __restrict__ res,
                                           double* __restrict__ jvar, const unsigned vblk) {
   extern __shared__ double lds[];
+  // the matrix-pipe forms are only launched when residual rows are asked for (eval_form(): mfma = use_mfma && want_res): knowing
+  // that, the compiler drops the `if (rb)` tests of the cooperative forms and the thirty zero-initialisations in front of them
+  if (MFMA) __builtin_assume(res != nullptr);
 #ifdef GEL_STAMP  // diagnostic build only (tools/stamp_phases.py): where a wavefront's lifetime goes, in shader cycles
 #define GEL_STAMP_AT(i) do { if ((threadIdx.x & 63) == 0) gel_stamps[(((size_t)vblk * 4 + (threadIdx.x >> 6)) & ((1u << 18) - 1)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
