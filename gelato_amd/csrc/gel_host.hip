@@ -1725,8 +1725,8 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
 }
 
 int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux, int32_t aux_rows, double* out) {
-  static const int nin[14] = {1, 3, 3, 6, 7, 1, 1, 2, 2, 8, 8, 8, 7, 4}, nout[14] = {5, 3, 3, 3, 3, 3, 1, 4, 6, 8, 16, 4, 3, 7};
-  if (kind < 0 || kind > 13 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
+  static const int nin[15] = {1, 3, 3, 6, 7, 1, 1, 2, 2, 8, 8, 8, 7, 4, 1}, nout[15] = {5, 3, 3, 3, 3, 3, 1, 4, 6, 8, 16, 4, 3, 7, 2};
+  if (kind < 0 || kind > 14 || n < 0 || !in || !out) return fail(GEL_ERR_ARG, "bad argument");
   if (n == 0) return GEL_OK;
   int rc = need_device();
   if (rc) return rc;

@@ -300,6 +300,7 @@ __global__ void point_kernel(int kind, int n, const double* in, const double* au
       thrust_dir(q, d);
       for (int c = 0; c < 3; c++) out[7 * i + 4 + c] = d[c];
     } break;
+    case 14: out[2 * i] = fexp(in[i]); out[2 * i + 1] = exp(in[i]); break;   // the path's exp beside the library's, for the bit-identity test
     default: break;
   }
 }

@@ -170,6 +170,36 @@ GEL_DEV double horner(double p, double w, double c) {
 GEL_DEV double horner(double p, double w, double c) { return __builtin_fma(p, w, c); }
 #endif
 
+// exp(x) for the arguments of this path (pressure ratios: |x| <= 40; the thermosphere's temperature law: -3 < x <= 0).  The library's own
+// algorithm (ocml expD: n = rint(x log2 e), t = x - n ln 2 in two parts, degree-11 polynomial, ldexp) with its coefficients as scalar
+// operands (horner()) and without the overflow / underflow selects that cannot act for |x| < 700: the same operations in the same
+// order -- the library's bits (tests/test_gpu_parity.py) -- in 24 vector instructions instead of 45.  A wavefront with a lane
+// outside (-700, 700) takes the library's.
+GEL_DEV double fexp(double x) {
+#ifndef GEL_STD_MATH
+#define GEL_F64(bits) __builtin_bit_cast(double, (unsigned long long)(bits))   // the library's constants, bit for bit
+  if (__builtin_amdgcn_ballot_w64(!(fabs(x) < 700.0)) == 0) {
+    const double n = __builtin_rint(x * GEL_F64(0x3ff71547652b82feULL));     // log2 e
+    double t = __builtin_fma(n, GEL_F64(0xbfe62e42fefa39efULL), x);          // - ln 2, high part
+    t = __builtin_fma(n, GEL_F64(0xbc7abc9e3b39803fULL), t);                 // - ln 2, low part
+    double p = __builtin_fma(t, GEL_F64(0x3e5ade156a5dcb37ULL), GEL_F64(0x3e928af3fca7ab0cULL));
+    p = horner(p, t, GEL_F64(0x3ec71dee623fde64ULL));
+    p = horner(p, t, GEL_F64(0x3efa01997c89e6b0ULL));
+    p = horner(p, t, GEL_F64(0x3f2a01a014761f6eULL));
+    p = horner(p, t, GEL_F64(0x3f56c16c1852b7b0ULL));
+    p = horner(p, t, GEL_F64(0x3f81111111122322ULL));
+    p = horner(p, t, GEL_F64(0x3fa55555555502a1ULL));
+    p = horner(p, t, GEL_F64(0x3fc5555555555511ULL));
+    p = horner(p, t, GEL_F64(0x3fe000000000000bULL));
+    p = __builtin_fma(t, p, 1.0);
+    p = __builtin_fma(t, p, 1.0);
+    return __builtin_ldexp(p, (int)n);
+  }
+#undef GEL_F64
+#endif
+  return exp(x);
+}
+
 GEL_DEV double flog_ratio(double x) {
 #ifndef GEL_STD_MATH
   if (x > 0.5 && x < 2.0) {
@@ -256,7 +286,7 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
   } else {
     const double Tinf = 1000.0;
     const double xi = fdiv((h - Hb) * (r0 + Hb), r0 + h);
-    o.T = Tinf - (Tinf - Tmb) * exp(-0.01875e-3 * xi);
+    o.T = Tinf - (Tinf - Tmb) * fexp(-0.01875e-3 * xi);
   }
   // pressure: src/Air.cpp:90-98
   if (fabs(Lmb) > 1.0e-6) {
@@ -268,10 +298,10 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
 #else
     // the temperature ratio by the tabulated 1/Tmb (<= 1 ulp from the division; amplified by the exponent, |y| <= 35,
     // that stays inside the exp(y log x) budget above)
-    o.P = Pb * exp(atm[44 + k] * flog_ratio((Tmb + Lmb * (h - Hb)) * atm[77 + k]));
+    o.P = Pb * fexp(atm[44 + k] * flog_ratio((Tmb + Lmb * (h - Hb)) * atm[77 + k]));
 #endif
   } else {
-    o.P = Pb * exp((atm[55 + k] * (Hb - h)) * atm[77 + k]);           // g0/R and 1/Tmb from the table
+    o.P = Pb * fexp((atm[55 + k] * (Hb - h)) * atm[77 + k]);           // g0/R and 1/Tmb from the table
   }
   o.rho = fdiv(o.P, R * o.T);     // src/Air.cpp:100-105 (P/R/T)
   fsqrt_rsqrt(1.4 * R * o.T, o.a, o.inv_a);   // src/Air.cpp:107-111; 1/a for the Mach number

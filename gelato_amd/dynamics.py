@@ -53,8 +53,8 @@ def dynamics_quaternion(quat_eci2body, u_e, unit_u):
 
 def point_eval(kind, x, aux=None):
     """Device point functions (include/gelato_amd.h: gel_point_eval)."""
-    nin = [1, 3, 3, 6, 7, 1, 1, 2, 2, 8, 8, 8, 7, 4][kind]
-    nout = [5, 3, 3, 3, 3, 3, 1, 4, 6, 8, 16, 4, 3, 7][kind]
+    nin = [1, 3, 3, 6, 7, 1, 1, 2, 2, 8, 8, 8, 7, 4, 1][kind]
+    nout = [5, 3, 3, 3, 3, 3, 1, 4, 6, 8, 16, 4, 3, 7, 2][kind]
     x = _f(x).reshape(-1, nin)
     n = x.shape[0]
     out = np.zeros((n, nout))

@@ -330,6 +330,7 @@ int gel_dynamics_quaternion(int32_t n, const double* quat_eci2body, const double
  *  kind 12: (q, v)       -> quatrot(q, v) = vec(conj(q) (0, v) q)  in [n][7]  out [n][3]  (:70-78)
  *  kind 13: q            -> [conj(q), thrust direction quatrot(conj(q), (1, 0, 0))]  in [n][4]  out [n][7]  (:59-61,
  *           src/pybind_dynamics.cpp:62-63)
+ *  kind 14: x            -> [fexp(x), exp(x)]                    in [n][1]   out [n][2]  self-check of the path's exp
  */
 int gel_point_eval(int32_t kind, int32_t n, const double* in, const double* aux, int32_t aux_rows, double* out);
 

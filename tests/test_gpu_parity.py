@@ -967,6 +967,24 @@ def test_benchmark_batch_against_oracle_in_full():
 
 
 # --------------------------------------------------------------------------
+# the path's exp (the library's algorithm with scalar coefficient operands, csrc/gel_physics.h fexp) gives the library's bits
+# --------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_path_exp_bit_identical_to_the_library():
+    _setup()
+    from gelato_amd import dynamics
+    rng = np.random.default_rng(78)
+    x = np.concatenate([rng.uniform(-40.0, 40.0, 1 << 17), rng.uniform(-3.0, 0.0, 1 << 16), rng.uniform(-699.0, 699.0, 1 << 16),
+                        [0.0, -0.0, 1e-300, -1e-300, 1.0, -1.0, 699.999, -699.999],
+                        # wavefronts with a lane outside (-700, 700) take the library's: same bits trivially, results 0 / inf / nan included
+                        [750.0, -750.0, 1e4, -1e4, np.inf, -np.inf, np.nan, 5.0]])
+    out = dynamics.point_eval(14, x)
+    assert np.array_equal(out[:, 0], out[:, 1], equal_nan=True)
+    fin = np.isfinite(x) & (np.abs(x) < 700)
+    assert np.max(np.abs(out[fin, 0] / np.exp(x[fin]) - 1.0)) < 4.5e-16      # and the library's is within 2 ulp of the host's
+
+
+# --------------------------------------------------------------------------
 # the path's guard-free fp64 sqrt / division (csrc/gel_physics.h) give the compiler's bits
 # --------------------------------------------------------------------------
 def test_guard_free_sqrt_and_division_bit_identical():
