@@ -379,6 +379,10 @@ struct AeroOut {
 // evaluated by wavefronts that have an alpha or q-alpha row.  Consecutive lanes are consecutive nodes of a spec, so every
 // store of a gradient block is one contiguous segment (which is what lets the B = 1 callback write straight into pinned
 // host memory).  Four wavefronts (four tiles) per workgroup.
+#ifndef GEL_AERO_UNROLL
+#define GEL_AERO_UNROLL 1   // the position / velocity / quaternion sweeps of the aero rows as copies of their loop bodies (constant columns and
+                            // directions): 164 VGPRs, -1.5 % launch time at B = 16384 (three alternating runs each)
+#endif
 constexpr int kAeroWaves = 4;
 // air-relative velocity in ECI (wrapper_utils.hpp:93-100) and its SQUARED norm (q needs no root; alpha takes the reciprocal root)
 GEL_DEV double aero_vair2(const double r[3], const double v[3], const double w[3], double a[3]) {
@@ -564,7 +568,11 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     const unsigned mine = ROLES ? ((sw == 0) ? 0u : (1u << (sw - 1))) : 7u;   // this wavefront's position sweeps
     unsigned todo = P.fd_recompute ? mine : 0u;   // sweeps with a lane the difference form does not cover (wave-uniform)
     if (!P.fd_recompute) {
+#if GEL_AERO_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
       for (int c = 0; c < 3; c++) {
         if (!((mine >> c) & 1u)) continue;
         asm volatile("" ::: "memory");
@@ -594,7 +602,11 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
 #undef GEL_AERO_POS_TAIL
     asm volatile("" ::: "memory");   // the light sweeps read their inputs again
     // ---- velocity sweeps: only the air-relative velocity changes
+#if GEL_AERO_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int c = (ROLES && sw != 0) ? 3 : 0; c < 3; c++) {
       double vp[3], a[3];
       const double r[3] = {xb[M + 3 * xi] * P.up, xb[M + 3 * xi + 1] * P.up, xb[M + 3 * xi + 2] * P.up};
@@ -607,7 +619,11 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     }
     // ---- quaternion sweeps: only the body axis changes
     if (need_alpha && !(ROLES && sw != 0)) {
+#if GEL_AERO_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
       for (int c = 0; c < 4; c++) {
         double qp[4], dp[3];
 #pragma unroll

@@ -155,24 +155,41 @@ GEL_DEV void pos_centre_tail(const PosCentreTail& t, double rho, double P, const
 // or sits too close to the polar axis for the series: the caller then recomputes the wavefront's sweep in full.
 // ---------------------------------------------------------------------------
 GEL_DEV bool pos_delta(const double r[3], int kk, double dlt, const PosPart& c, const PosCentre& pc, const Tables& tb, PosPart& o) {
-  const double dz = (kk == 2) ? dlt : 0.0;
-  const double xs = (kk == 0) ? r[0] : r[1];
-  const double dp2 = (kk == 2) ? 0.0 : dlt * __builtin_fma(2.0, xs, dlt);
-  const double u = dp2 * c.inv_p * c.inv_p;
-  const double dp = (0.5 * dp2 * c.inv_p) * (1.0 + u * (-0.25 + 0.125 * u));
-  o.inv_p = c.inv_p * (1.0 + u * (-0.5 + 0.375 * u));
-  // Bowring's auxiliary angle (src/Earth.cpp:53-55)
+  // kk is a constant where the sweeps are unrolled (wave-uniform otherwise): a step along z leaves p alone, a step along x or y
+  // leaves z alone, and the terms that the other direction would contribute -- products with an exact zero, sums with it -- are
+  // not formed (same values; only the sign of an exact zero can differ)
+  const bool along_z = kk == 2;
   const double a = r[2] * kRa, b = pc.p * kRb;
-  const double da = dz * kRa, db = dp * kRb;
-  const double dh2 = da * __builtin_fma(2.0, a, da) + db * __builtin_fma(2.0, b, db);
-  const double uh = dh2 * pc.ih * pc.ih;
-  const double dih = pc.ih * (uh * (-0.5 + 0.375 * uh));
-  const double ih1 = pc.ih + dih;
+  double u = 0.0, dp = 0.0, dh2, dst, dct, dih, ih1;
+  o.inv_p = c.inv_p;
+  if (!along_z) {
+    const double xs = (kk == 0) ? r[0] : r[1];
+    const double dp2 = dlt * __builtin_fma(2.0, xs, dlt);
+    u = dp2 * c.inv_p * c.inv_p;
+    dp = (0.5 * dp2 * c.inv_p) * (1.0 + u * (-0.25 + 0.125 * u));
+    o.inv_p = c.inv_p * (1.0 + u * (-0.5 + 0.375 * u));
+    // Bowring's auxiliary angle (src/Earth.cpp:53-55)
+    const double db = dp * kRb;
+    dh2 = db * __builtin_fma(2.0, b, db);
+    const double uh = dh2 * pc.ih * pc.ih;
+    dih = pc.ih * (uh * (-0.5 + 0.375 * uh));
+    ih1 = pc.ih + dih;
+    dst = a * dih;
+    dct = db * ih1 + b * dih;
+  } else {
+    const double da = dlt * kRa;
+    dh2 = da * __builtin_fma(2.0, a, da);
+    const double uh = dh2 * pc.ih * pc.ih;
+    dih = pc.ih * (uh * (-0.5 + 0.375 * uh));
+    ih1 = pc.ih + dih;
+    dst = da * ih1 + a * dih;
+    dct = b * dih;
+  }
   const double st = a * pc.ih, ct = b * pc.ih;
-  const double dst = da * ih1 + a * dih, dct = db * ih1 + b * dih;
   const double dst3 = dst * (3.0 * st * (st + dst) + dst * dst);
   const double dct3 = dct * (3.0 * ct * (ct + dct) + dct * dct);
-  const double dzz = dz + (kEp2 * kRb) * dst3, dpp = dp - (kE2 * kRa) * dct3;
+  const double dzz = along_z ? dlt + (kEp2 * kRb) * dst3 : (kEp2 * kRb) * dst3;
+  const double dpp = along_z ? -((kE2 * kRa) * dct3) : dp - (kE2 * kRa) * dct3;
   // latitude: tan(lat' - lat) = (dzz pp - zz dpp)/(zz zz' + pp pp'), with (zz, pp)/hypot = (sin, cos) lat
   const double e = (pc.cl * dpp + pc.sl * dzz) * pc.ihy;
   const double dlat = ((dzz * pc.cl - dpp * pc.sl) * pc.ihy) * (1.0 + e * (e - 1.0));
