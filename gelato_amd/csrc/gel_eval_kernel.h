@@ -1354,7 +1354,11 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
           for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
         }
+#if GEL_POS_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int k = 0; k < 3; k++) {
           double r[3], gp[3];
 #pragma unroll
