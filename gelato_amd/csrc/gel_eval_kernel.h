@@ -502,8 +502,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           for (int i = 0; i < kAPF; i++) a_ring[i] = ap[min(i, ksteps - 1) * 256];
         }
         // State rows: lane = row for rows 0 .. 63 (eleven loads, addresses clamped into the phase: no branch around a load);
-        // the few rows behind them (64 .. 67; two vectors per wavefront: 64 .. 71) element by element, lane e -> row e / 11,
-        // column e % 11 (one or two loads).  Rows past the phase meet zero columns of D.
+        // the few rows behind them (64 .. 67; two vectors per wavefront: 64 .. 71) element by element (one or two loads).  Rows past the phase meet zero columns of D.
         constexpr int kRowsStaged = PACK ? 2 * kPackRows : kSlabRows, kExtra = (kRowsStaged - 64) * 11;
         double st[11], sx[(kExtra + 63) / 64];
         {
@@ -516,13 +515,17 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           for (int c = 0; c < 3; c++) { st[1 + c] = xs[M + 3 * xk + c]; st[4 + c] = xs[4 * M + 3 * xk + c]; }
 #pragma unroll
           for (int c = 0; c < 4; c++) st[7 + c] = xs[7 * M + 4 * xk + c];
+          // the rows behind them: element e = lane + 64 i is row 64 + (e mod kER) (kER = 4 or 8 rows: a power of two), column e / kER --
+          // shifts and masks instead of divisions by 11 and by the rows of a half; with two vectors per wavefront these rows all
+          // belong to the second vector (rows 36 .. 71 of the image)
+          constexpr int kER = kRowsStaged - 64, kERs = (kER == 8) ? 3 : 2;
+          static_assert(kER == (1 << kERs) && (!PACK || 64 >= kPackRows), "extra rows: a power of two, all in the second half");
 #pragma unroll
           for (int i = 0; i < (kExtra + 63) / 64; i++) {
             const int e = min(lane + 64 * i, kExtra - 1);
-            const int rr = 64 + e / 11, c = e - 11 * (e / 11);
-            const int hx = PACK ? rr / kPackRows : 0;
-            const int kx = min(PACK ? rr - kPackRows * hx : rr, n);
-            const double* xe = PACK ? x + (size_t)min(b0 + 2 * wv + hx, B - 1) * P.nvars : xb;
+            const int rr = 64 + (e & (kER - 1)), c = e >> kERs;
+            const int kx = min(PACK ? rr - kPackRows : rr, n);
+            const double* xe = PACK ? x + (size_t)min(b0 + 2 * wv + 1, B - 1) * P.nvars : xb;
             const int xr_ = ph.xa + kx;
             const int off = (c == 0) ? xr_ : ((c < 4) ? M + 3 * xr_ + (c - 1) : ((c < 7) ? 4 * M + 3 * xr_ + (c - 4) : 7 * M + 4 * xr_ + (c - 7)));
             sx[i] = xe[off];
@@ -537,7 +540,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
           for (int i = 0; i < (kExtra + 63) / 64; i++) {
             const int e = lane + 64 * i;
-            if (e < kExtra) wave_lds[64 * 11 + e] = sx[i];
+            if (e < kExtra) wave_lds[(64 + (e & (kER - 1))) * 11 + (e >> kERs)] = sx[i];
           }
         }
         stage_tables_commit(P, lds, tab_mine);
