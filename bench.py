@@ -174,7 +174,13 @@ def main():
                          "ranks, one RCCL all-gather of the owned entries per step (strong scaling; BASELINE.json config 4)")
     ap.add_argument("--residual-only", action="store_true", dest="residual_only",
                     help="RHS + defect residuals only, no Jacobian (BASELINE.json configs[1]: 3x32 residual only vs CPU)")
+    ap.add_argument("--flags", type=int, default=0,
+                    help="engine creation flags (include/gelato_amd.h): 8 = GEL_FLAG_FD_RECOMPUTE, the reference-literal form that "
+                         "re-runs the RHS chain on every perturbed column (lib/con_dynamics.py:353-480,580-604); 1 / 2 force D.X onto "
+                         "the matrix pipe / the vector unit; 4 = never two vectors per wavefront")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs of the other BASELINE.json configurations (key `other_configs`; --no-extras skips them too)")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational full-COO and B=1 legs")
     ap.add_argument("--dry-launcher", action="store_true", help="print the N-rank launcher command and exit (no GPU touched)")
     a = ap.parse_args()
@@ -217,7 +223,7 @@ def main():
     ps = pdict["ps_params"]
     D = [ps.D(i) for i in range(S)]
     tau = [ps.tau(i) for i in range(S)]
-    E = Engine(prob, D=D, tau=tau, device=local)
+    E = Engine(prob, D=D, tau=tau, device=local, flags=a.flags)
     B, K, W = a.batch, a.steps, a.warmup
 
     x0 = pack_x(xdict)
@@ -240,7 +246,7 @@ def main():
         dout = shards.buffer(B, dev)
 
         def evaluate(out_t, r):
-            E.eval_shard_packed_device(B, dX.data_ptr(), out_t.data_ptr(), r, stream)
+            E.eval_shard_packed_device(B, dX.data_ptr(), out_t.data_ptr(), r, stream, plan=shards.plan)
 
         def step():
             shards.step(evaluate, dout)
@@ -277,12 +283,21 @@ def main():
     # gone by (same count on every rank): 5 steps of 0.3 ms end inside the start-up dip of the clock, and the K timed steps
     # would measure the transient, not the kernel (3 x 32 residual-only: 167 M evals/s against 204 M).
     WARM_MS = 40.0
-    t0 = time.perf_counter()
     for _ in range(W):
         step()
     torch.cuda.synchronize()
-    per_step_ms = 1e3 * (time.perf_counter() - t0) / max(W, 1)
-    w_extra = 0 if W == 0 else max(0, min(4000, int(WARM_MS / max(per_step_ms, 1e-3)) - W))
+    # The step's length is measured on ONE more untimed step, after the W steps have absorbed the one-time costs (module load,
+    # first launch, the lazy RCCL communicator of the first all-gather): timed over the W steps themselves those costs made
+    # a 0.3-ms step look like tens of milliseconds and the extra warm-up came out as zero.
+    w_probe = 0
+    per_step_ms = WARM_MS
+    if W > 0:
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        per_step_ms = 1e3 * (time.perf_counter() - t0)
+        w_probe = 1
+    w_extra = 0 if W == 0 else max(0, min(4000, int(WARM_MS / max(per_step_ms, 1e-3)) - W - w_probe))
     if use_dist:
         we = torch.tensor([w_extra], dtype=torch.int64, device=dev)
         dist.all_reduce(we, op=dist.ReduceOp.MAX)
@@ -327,14 +342,14 @@ def main():
     a_min = 8 * (E.nvars + E.nres) if a.residual_only else E.algorithmic_bytes
     abytes = a_min * B
     achieved = abytes / (kern_ms * 1e-3) / 1e9
-    wl_tag = a.workload + ("_resonly" if a.residual_only else "")
+    wl_tag = a.workload + ("_resonly" if a.residual_only else "") + ("_flags%d" % a.flags if a.flags else "")
     from gelato_amd import _lib
     build = _lib.build_info()
 
-    def static_counters(kind):
+    def static_counters(kind, tag=None, batch=None):
         """profiles/<kind>_<workload>_B<batch>.json (separate rocprofv3 --pmc passes of this command, tools/gpu_record.sh) --
         only if it was recorded with THE library that is loaded now (build_so_sha256); -> (dict or None, why not)"""
-        path = os.path.join(ROOT, "profiles", "%s_%s_B%d.json" % (kind, wl_tag, B))
+        path = os.path.join(ROOT, "profiles", "%s_%s_B%d.json" % (kind, tag or wl_tag, batch or B))
         if not os.path.exists(path):
             return None, "no profiles/%s on record for this workload and batch" % os.path.basename(path)
         try:
@@ -357,13 +372,13 @@ def main():
         "metric": "residual+Jacobian evals/sec (and ms/eval), 6-phase x 64-node LGR mesh",
         "value": evals / T, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "world_size": world, "collective_backend": ("nccl (RCCL over xGMI)" if use_dist else None),
-        "warmup_steps_run": W + w_extra,
+        "warmup_steps_run": W + w_probe + w_extra,
         "ms_per_step": 1e3 * T / K, "ms_per_eval": 1e3 * T / (B * K), "higher_is_better": True,
         "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         # informational: the same K steps in the settled power state (config.settle_launches_before_second_timing untimed
         # launches + W warm-ups before them); `value` is the contract's W warm-ups + K timed steps from an idle GPU
         "value_settled": evals / T_settled, "ms_per_step_settled": 1e3 * T_settled / K,
-        "config": {"workload": a.workload + (" (residual only)" if a.residual_only else ""), "phases": int(S),
+        "config": {"workload": a.workload + (" (residual only)" if a.residual_only else ""), "engine_flags": int(a.flags), "phases": int(S),
                    "nodes_per_phase": [int(n) for n in prob["num_nodes"]],
                    "batch_per_gpu": B, "settle_launches_before_second_timing": n_settle, "decision_vars": E.nvars, "residual_rows": E.nres,
                    "jacobian_values_per_eval": 0 if a.residual_only else E.V, "coo_nnz": E.total_nnz,
@@ -537,6 +552,72 @@ def main():
             del dcon, djac
         except Exception as ex:  # noqa: BLE001
             out["aero_constraints"] = {"error": str(ex)}
+
+    if not a.no_other_configs and not a.no_extras and not shard and not a.residual_only and a.workload == "mixed-6x64" and a.flags == 0:
+        # The other BASELINE.json configurations in front of the driver, after the headline's timed region:
+        # configs[1] 3 x 32 residual-only, configs[4] stress-12x128, dense-6x64 (maximum work), and the headline mesh in the
+        # reference-literal form that re-runs the RHS chain on every perturbed column (GEL_FLAG_FD_RECOMPUTE).  Each leg: its own
+        # engine, LEG_DISTINCT distinct synthetic vectors tiled to the batch on the device, >= 40 ms of untimed
+        # launches, then LEG_K launches under HIP events.  `frac` = SURVEY 8(d)'s A_min x B / kernel time / 8 TB/s;
+        # `frac_of_bytes_moved` from the PMC passes on record for the loaded build (null otherwise).
+        LEG_DISTINCT, LEG_K = 256, 8
+        legs = [("3x32_resonly", "3x32", True, 65536, 0), ("stress-12x128", "stress-12x128", False, 16384, 0),
+                ("dense-6x64", "dense-6x64", False, 65536, 0), ("mixed-6x64_fd_recompute", "mixed-6x64", False, 65536, 8)]
+        oc = {}
+        t_legs = time.perf_counter()
+        for key, wl, resonly, Bl, fl in legs:
+            try:
+                if wl == a.workload:
+                    pd_l, ud_l, xd_l, prob_l, D_l, tau_l = pdict, unitdict, xdict, prob, D, tau
+                else:
+                    pd_l, ud_l, _c, xd_l = problem.make_problem(wl)
+                    prob_l = con_dynamics.problem_arrays(pd_l, ud_l)
+                    ps_l = pd_l["ps_params"]
+                    D_l = [ps_l.D(i) for i in range(pd_l["num_sections"])]
+                    tau_l = [ps_l.tau(i) for i in range(pd_l["num_sections"])]
+                El = Engine(prob_l, D=D_l, tau=tau_l, device=local, flags=fl)
+                Xl = problem.synthetic_batch(pack_x(xd_l), El.M, LEG_DISTINCT)
+                dXl = torch.from_numpy(Xl).to(dev).repeat(Bl // LEG_DISTINCT, 1).contiguous()
+                dresl = torch.empty((Bl, El.nres), dtype=torch.float64, device=dev)
+                djvl = None if resonly else torch.empty((Bl, El.V), dtype=torch.float64, device=dev)
+                jp = 0 if djvl is None else djvl.data_ptr()
+
+                def leg_step():
+                    El.eval_batch_device(Bl, dXl.data_ptr(), dresl.data_ptr(), jp, stream)
+                leg_step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                leg_step()
+                torch.cuda.synchronize()
+                one_ms = 1e3 * (time.perf_counter() - t0)
+                for _ in range(max(2, min(2000, int(WARM_MS / max(one_ms, 1e-3))))):
+                    leg_step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(LEG_K):
+                    leg_step()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / LEG_K
+                st_l = El.sync(stream)
+                amin_l = 8 * (El.nvars + El.nres) if resonly else El.algorithmic_bytes
+                tag_l = wl + ("_resonly" if resonly else "") + ("_flags%d" % fl if fl else "")
+                td_l, _why = static_counters("traffic", tag_l, Bl)
+                moved = None if td_l is None else td_l.get("hbm_bytes_per_launch")
+                inf_l = El.launch_info(Bl, True, not resonly)
+                oc[key] = {"workload": wl + (" (residual only)" if resonly else ""), "engine_flags": fl, "batch": Bl,
+                           "value": Bl / (ms * 1e-3), "unit": "evals/s", "kernel_ms": ms,
+                           "algorithmic_bytes_per_eval": amin_l, "frac": amin_l * Bl / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "frac_of_bytes_moved": None if moved is None else moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "kernel": "gel::eval_kernel<%s, %s, %s, %s>" % tuple("true" if v else "false" for v in (inf_l[0], inf_l[1], inf_l[2], inf_l[4])),
+                           "status": int(st_l)}
+                El.close()
+                del dXl, dresl, djvl, El
+            except Exception as ex:  # noqa: BLE001
+                oc[key] = {"error": str(ex)[:300]}
+        oc["note"] = ("%d distinct synthetic vectors tiled to the batch on the device; >= 40 ms of untimed launches, then %d launches under "
+                      "HIP events; after the headline's timed region; %.1f s in all" % (LEG_DISTINCT, LEG_K, time.perf_counter() - t_legs))
+        out["other_configs"] = oc
 
     if not a.no_cpu_baseline:   # rank 0, at every N
         out["cpu_baseline"] = cpu_baseline(prob, D, tau, X, gpu_first, residual_only=a.residual_only)

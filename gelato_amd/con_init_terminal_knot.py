@@ -143,6 +143,7 @@ class _Rows:
         self.jac["tineq"] = {"t": _coo(rows, cols, vals, (len(lin) - k0, S + 1))}
 
         # ---- lib/con_trajectory.py, more rows of the same kind ----
+        self.missing_stage_events = None
         # inequality_mass (con_trajectory.py:33-60): a stage cannot burn more than its propellant; Jacobian :63-103
         k0 = len(lin)
         rows, cols, vals = [], [], []
@@ -159,10 +160,11 @@ class _Rows:
                 import warnings
                 warnings.warn("inequality_mass: stage without its ignition_at / cutoff_at events (%r, %r) in the event list: "
                               "no propellant limit row for it" % (stage.get("ignition_at"), stage.get("cutoff_at")), stacklevel=2)
-            else:
-                # the reference looks the two events up by name and indexes the empty match list (lib/con_trajectory.py:40-49)
-                raise IndexError("inequality_mass: RocketStage events %r / %r are not section names (lib/con_trajectory.py:40-49 "
-                                 "raises IndexError too)" % (stage.get("ignition_at"), stage.get("cutoff_at")))
+            elif self.missing_stage_events is None:
+                # the reference looks the two events up by name and indexes the empty match list INSIDE inequality_mass /
+                # inequality_jac_mass (lib/con_trajectory.py:40-49) -- and only there: every other group of this shared table
+                # (knot, terminal, waypoint, user rows) works on such a pdict.  Recorded here, raised by those two functions.
+                self.missing_stage_events = (stage.get("ignition_at"), stage.get("cutoff_at"))
         self.slices["imass"] = (k0, len(lin))
         self.jac["imass"] = {"mass": _coo(rows, cols, vals, (len(lin) - k0, M))}
         # inequality_kickturn (:106-125): the pitch rate of a kick-turn section is not positive; Jacobian :128-160

@@ -7,12 +7,23 @@ callback's one device round trip; their Jacobians are constants laid out in the 
 from . import con_init_terminal_knot as _rows
 
 
+def _need_stage_events(pdict, unitdict, condition):
+    """the reference indexes an empty match list when a RocketStage's ignition_at / cutoff_at events are not section names
+    (lib/con_trajectory.py:40-49): IndexError, from these two functions only"""
+    miss = _rows.rows_of(pdict, unitdict, condition).missing_stage_events
+    if miss is not None:
+        raise IndexError("inequality_mass: RocketStage events %r / %r are not section names (lib/con_trajectory.py:40-49 "
+                         "raises IndexError too)" % miss)
+
+
 def inequality_mass(xdict, pdict, unitdict, condition):
     """Inequality constraint about the propellant a stage may burn (a list, like the reference returns)."""
+    _need_stage_events(pdict, unitdict, condition)
     return list(_rows._values(xdict, pdict, unitdict, condition, "imass"))
 
 
 def inequality_jac_mass(xdict, pdict, unitdict, condition):
+    _need_stage_events(pdict, unitdict, condition)
     return _rows._const_jac(pdict, unitdict, condition, "imass")
 
 

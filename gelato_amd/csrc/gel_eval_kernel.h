@@ -96,9 +96,6 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_DX_PF_RES 4
 #endif
 
-#ifndef GEL_WIND_CACHE
-#define GEL_WIND_CACHE 1  // likewise the altitude interval of the wind table across a node's position sweeps
-#endif
 #ifndef GEL_CA_CACHE
 #define GEL_CA_CACHE 1  // the Mach interval of a node's first CA lookup serves its other aerodynamic-force evaluations
 #endif
@@ -116,15 +113,6 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_PACK_A_PRELOAD 1  // two vectors per wavefront: all (<= 9) A slabs of D.X requested before the operand barrier
 #endif
 
-#ifndef GEL_POS_UNROLL
-#define GEL_POS_UNROLL 1   // the three position sweeps as three copies of the loop body: constant slots and directions (no selects, no slot
-#endif                     // arithmetic): -49 vector instructions per wavefront, 125 VGPRs; pooled A/B mixed -1.7 %, dense -3.9 % launch time
-#ifndef GEL_VEL_UNROLL
-#define GEL_VEL_UNROLL 1   // likewise the three velocity sweeps: -45 more, same registers; pooled A/B -0.3 % (mixed), -0.7 % (dense) on top
-#endif
-#ifndef GEL_PRIO_PHASE_A
-#define GEL_PRIO_PHASE_A 0   // s_setprio level of a wavefront until its D.X rows are in registers
-#endif
 
 #ifndef GEL_COOP_XLDS
 #define GEL_COOP_XLDS 1  // cooperative D.X: state rows staged in LDS (1) or fetched per k-step from global memory (0)
@@ -159,9 +147,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #define GEL_STAMP_AT(i) do {} while (0)
 #endif
   GEL_STAMP_AT(0);
-#if GEL_PRIO_PHASE_A
-  if (MFMA && !SPLIT && JAC) __builtin_amdgcn_s_setprio(GEL_PRIO_PHASE_A);
-#endif
   const int park_off = P.park_off;
   // the cooperative forms meet at a barrier (operand image / hand-over) before any table lookup: no barrier of its own
   constexpr bool kSplitStage = MFMA && !SPLIT;   // cooperative forms: table entry requested now, written before their first barrier
@@ -261,12 +246,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   const int xj = ph.xa + 1 + jc;  // its state row (x-node j+1)
   const int M = P.M, N = P.N;
 
-#ifdef GEL_ABL_XWRAP   // experiment (tools/build_variants.sh): every decision vector is read from one of the first GEL_ABL_XWRAP
-  // vectors of x -- the state rows come from L2 / the Infinity Cache: what a perfect prefetch of x would buy
-  const double* xb = x + (size_t)(b & (GEL_ABL_XWRAP - 1)) * P.nvars;
-#else
   const double* xb = x + (size_t)b * P.nvars;
-#endif
   const double* xm = xb;
   const double* xr = xb + M;
   const double* xv = xb + 4 * M;
@@ -275,9 +255,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   const double* xt = xb + 11 * M + 2 * N;
   // wave-uniform scalars live in SGPRs (two decision vectors per wavefront: per half, so they stay vector values there)
 #define GEL_UNI(v) (PACK ? (v) : wave_uniform(v))
-#ifndef GEL_FRONT_EARLY_T
-#define GEL_FRONT_EARLY_T 0   // A/B: 1 = round 3's order (the knot times are waited for before the state rows are requested)
-#endif
   // The phase's two knot times: requested here, TAKEN (v_readfirstlane: the first wait of the wavefront) only once every other
   // load of phase A has been requested -- one HBM round trip instead of two in a row in front of the D.X product.
   const double to_ld = xt[sec], tf_ld = xt[sec + 1];
@@ -295,11 +272,13 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     fds = GEL_UNI(inv_dx * (tf - to) * ut / 2.0);               \
     fdt = GEL_UNI(inv_dx * ut / 2.0);                           \
   } while (0)
-#if GEL_FRONT_EARLY_T
-  GEL_TAKE_KNOT_TIMES();
-#endif
   // NaN / Inf detector: lanes that wrote a non-finite value, accumulated on the scalar unit (a running per-lane sum would hold
-  // two VGPRs for the whole kernel)
+  // two VGPRs for the whole kernel).  What is tested: every residual row a wavefront writes -- D is dense, so a non-finite state
+  // column reaches every row of its phase, and mass, thrust, force and gravity reach the velocity rows through f_c -- and, in a
+  // wavefront that writes no residual rows (Jacobian-only calls, the split-off position sweeps of the latency form), every Jacobian
+  // value.  The fused launch used to test all 63 stored values of a node as well: 49 compares + 49 scalar ORs per wavefront for
+  // values that are differences and products of numbers the residual rows already vouch for (the reference tests nothing:
+  // Trajectory_Optimization.py:240,311 hard-code fail = False).
   unsigned long long bad = 0;
 #define GEL_CHK(v) (bad |= __builtin_amdgcn_ballot_w64(!(fabs(v) <= 1.79769313486231570815e308)))
 
@@ -321,16 +300,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   const int gn = packed ? lane : g;                       // node index inside a residual group
   const int rs_m = packed ? pk_nj : 0, rs_p = packed ? pk_nj + nn : N, rs_v = packed ? pk_nj + 4 * nn : 4 * N,
             rs_q = packed ? pk_nj + 7 * nn : 7 * N;
-#ifdef GEL_ABL_NOSTORE  // ablation (tools/variant.sh): everything computed, (almost) nothing stored
-  double* jb = JAC ? jvar + (size_t)b * P.V + ph.voff + (size_t)j0 * ph.K + (j - j0) : nullptr;
-  const int cw8 = nn * 8;
-#define EMIT_AT(byteoff, val)                             \
-  do {                                                    \
-    const double _v = (val);                              \
-    if (_v == 1.2345e300) jb[(byteoff) / 8] = _v;         \
-    GEL_CHK(_v);                                            \
-  } while (0)
-#else
   // Buffer store: wave-uniform resource (base = this wavefront's first value), lane offset in a VGPR, slot offset
   // on the scalar unit -- no vector address arithmetic at all (69 v_lshl_add_u64 gone, 4 VGPRs less).  Streamed
   // once and never re-read by this kernel: non-temporal.  Measured: nt over plain stores -2..4 % in round 1; with the
@@ -338,13 +307,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // sc1+nt +25..45 % slower); buffer form over global_store another -1.8 %.
   typedef unsigned gel_u2 __attribute__((ext_vector_type(2)));
   const __amdgpu_buffer_rsrc_t jrs =
-#ifdef GEL_ABL_SAMEADDR  // ablation: every vector writes over vector 0's values (same instructions, L2-resident target)
-      __builtin_amdgcn_make_buffer_rsrc(JAC ? (void*)(jvar + ph.voff + j0) : (void*)nullptr, 0, -1, 0x00020000);
-#else
       // a phase's node values are laid out [64-node chunk][slot][node of the chunk]: this wavefront's block starts at j0 * K
       __builtin_amdgcn_make_buffer_rsrc(JAC ? (packed ? (void*)pk_out : (void*)(jvar + (size_t)(PACK ? min(b0 + 2 * wv, B - 1) : b) * P.V + ph.voff + (size_t)j0 * ph.K)) : (void*)nullptr,
                                         0, -1, 0x00020000);
-#endif
   const int jvo = PACK ? (half * (int)P.V + j) * 8 : lane * 8;
   const int cw8 = nn * 8;   // bytes between two slots of this wavefront's block
 #define EMIT_AT(byteoff, val)                                                           \
@@ -353,32 +318,10 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     gel_u2 _d;                                                                          \
     __builtin_memcpy(&_d, &_v, 8);                                                      \
     __builtin_amdgcn_raw_buffer_store_b64(_d, jrs, jvo, (byteoff), GEL_STORE_AUX);      \
-    GEL_CHK(_v);                                                                          \
+    if (!rb) GEL_CHK(_v);                                                                 \
   } while (0)
-#endif
-#ifdef GEL_ABL_PAIR   // timing experiment (wrong values): even slots write 16 B per lane over their own and the next slot's bytes, odd slots nothing
-typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
-#define EMIT(slot, val)                                                                                      \
-  do {                                                                                                       \
-    const double _v = (val);                                                                                 \
-    if (((slot) & 1) == 0 && (int)(slot) + 1 >= (int)ph.K) {                                                 \
-      EMIT_AT((int)(slot) * cw8, _v);                                                                        \
-    } else if (((slot) & 1) == 0) {                                                                          \
-      const double _p[2] = {_v, _v};                                                                         \
-      gel_u4 _d;                                                                                             \
-      __builtin_memcpy(&_d, _p, 16);                                                                         \
-      __builtin_amdgcn_raw_buffer_store_b128(_d, jrs, 2 * jvo, (int)(slot) * cw8, GEL_STORE_AUX);            \
-    }                                                                                                        \
-    GEL_CHK(_v);                                                                                             \
-  } while (0)
-#else
 #define EMIT(slot, val) EMIT_AT(((int)(slot) - (SPLIT ? (((int)(slot) >= kSlotVP) ? sub_hi : sub_lo) : 0)) * cw8, val)
-#endif
-#ifdef GEL_ABL_NORES  // ablation: residual rows computed, not stored
-#define RSTORE(idx, val) do { if ((val) == 1.2345e300) rb[idx] = (val); } while (0)
-#else
 #define RSTORE(idx, val) rb[idx] = (val)
-#endif
   // Residual rows as CONTIGUOUS stores.  The reference's layout is node-major ([node][x y z], [node][w x y z]): written lane =
   // node, a store instruction puts 8 bytes every 24 / 32 bytes -- 24 / 32 partial 64-byte write requests per instruction, three or
   // four instructions per line.  A full 64-node chunk instead turns its w values per node through an LDS tile (node-major in,
@@ -398,16 +341,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
   constexpr bool kCanXpose = (GEL_RES_XPOSE != 0) && (kWL >= kTileOff + 4 * 64);
   // whole lines, written once and never read by this kernel: non-temporal like the Jacobian values (the strided form's partial
   // lines want to meet in L2 first: written non-temporally they cost 4 % more HBM writes, round 2)
-#ifndef GEL_RES_NT
-#define GEL_RES_NT 1
-#endif
-#if defined(GEL_ABL_NORES)
-#define RSTORE_LINE(ptr, val) do { if ((val) == 1.2345e300) *(ptr) = (val); } while (0)
-#elif GEL_RES_NT
 #define RSTORE_LINE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
-#define RSTORE_LINE(ptr, val) *(ptr) = (val)
-#endif
 #define xpose (kCanXpose && (PACK ? (cw8 == 256 && pack_full) : cw8 == 512))   /* wave-uniform: every lane holds a node (cw8 = 8 nn is in an SGPR anyway) */
 #define RSTORE_ROWS(tile, w, rs_off, vals)                                                                   \
   do {                                                                                                       \
@@ -453,6 +387,32 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
     double u0 = 0.0, u1 = 0.0;
     if (!ph.hold) { u0 = xu[2 * (ph.ua + jc)]; u1 = xu[2 * (ph.ua + jc) + 1]; }
     const double djj = JAC ? P.Dt[ph.doff + (size_t)(jc + 1) * n + jc] : 0.0;  // D[j][j+1]
+    // The LAST state row of a phase on the vector unit.  A phase has n + 1 state rows; with n a multiple of four (every mesh of
+    // BASELINE.json, the usual case) the matrix pipe's last k-step would multiply ONE real row and three rows of zeros: three
+    // v_mfma_f64_16x16x4_f64 (192 cycles of the fp64 datapath) for what twelve v_fma_f64 (48 cycles) do on the accumulators as
+    // they lie (cooperative forms: C[row (l>>4) + 4i][col l&15] += D[row][n] X[n][col] -- four loads from D's last column, three
+    // broadcast reads of the row; latency form: after the transpose, lane = node, eleven fused operations).  Every matrix-pipe form
+    // adds rows 0 .. n - 1 by k-steps in ascending order and then row n by one fused operation: bit-identical to one another.
+    const bool tail1 = MFMA && ((n + 1) & 3) == 1 && n >= 4;   // wave-uniform
+    const int ksteps = tail1 ? (n >> 2) : ((n + 4) >> 2);      // k-steps of the matrix pipe: ceil((n+1)/4), or n/4 + the tail row
+    const double* const dcol = P.Dt + ph.doff + (size_t)n * n; // D[.][n]
+    double dl4[4] = {0, 0, 0, 0};                               // cooperative forms: D[row][n] of this lane's four accumulator rows
+    if (COOP && tail1) {
+      const int rt = PACK ? (wv & 1) : wv;
+#pragma unroll
+      for (int i = 0; i < 4; i++) dl4[i] = dcol[min(16 * rt + (lane >> 4) + 4 * i, n - 1)];
+    }
+    const double dlast = (SPLIT && tail1) ? dcol[jc] : 0.0;     // latency form: D[j][n]
+    double xl[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // latency form: state row n
+#define GEL_DX_TAIL_ACC(xn_of_ct)                                                                   \
+  do {                                                                                              \
+    if (tail1) {                                                                                    \
+      _Pragma("unroll") for (int ct = 0; ct < 3; ct++) {                                            \
+        const double xn_ = (xn_of_ct);                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) acc[ct][i] = __builtin_fma(dl4[i], xn_, acc[ct][i]); \
+      }                                                                                             \
+    }                                                                                               \
+  } while (0)
 
     // the reference rows of engine-off / hold phases (state row 0 of the phase): from the LDS image of the state rows where a
     // form stages one (no load at all), else fetched after the product
@@ -486,7 +446,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         }
         gel_double4 acc[3];
         const double* ap = P.Dst + (size_t)dsw * 4 + (PACK ? (wv & 1) : wv) * 64 + lane;
-        const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4) <= kSlabK: the phase is one slab
+        // ksteps <= kSlabK: the phase is one slab
         // Every load of phase A is REQUESTED before anything waits: the A slabs first (they do not depend on x: L2), then the
         // state rows (HBM), and only then the first s_waitcnt of the wavefront.  A slabs: all k-steps of the phase at once
         // (kAAll), or a ring of kAPF in flight.
@@ -546,11 +506,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         stage_tables_commit(P, lds, tab_mine);
         __syncthreads();
         GEL_STAMP_AT(2);
-#ifdef GEL_ABL_NODX
-        const int klast = 0;
-#else
         const int klast = ksteps;
-#endif
         if (kAAll) {
 #pragma unroll
           for (int ks = 0; ks < kAllN; ks++) {
@@ -583,6 +539,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
             }
           }
         }
+        GEL_DX_TAIL_ACC(regions[xoff[ct] + (n - kq) * 11]);   // row n of this lane's column (xoff points at row kq)
         GEL_STAMP_AT(3);
         {
           // the node's own state row comes from the same image (after the product: nothing of it is live across the loop)
@@ -646,7 +603,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
         const double* ap = P.Dst + (size_t)dsw * 4 + wv * 64 + lane;
-        const int ksteps = (n + 4) >> 2, nslab = (ksteps + kPipeK - 1) / kPipeK;
+        const int nslab = (((n + 4) >> 2) + kPipeK - 1) / kPipeK;   // slabs that hold rows 0 .. n (the tail row and the last node's own row included)
         const int own = jc + 1;
         double st[11];
         const bool stager = lane < kPipeRows;
@@ -695,6 +652,8 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
               for (int c = 0; c < 4; c++) q[c] = src[7 + c];
             }
           }
+          if (n >= sl * kPipeRows && n < (sl + 1) * kPipeRows)      // wave-uniform: the tail row lies in this slab's image
+            GEL_DX_TAIL_ACC(regions[xoff[ct] + bo + (n - sl * kPipeRows - kq) * 11]);
           if (sl + 1 < nslab) GEL_PIPE_WRITE((sl + 1) & 1);
           __syncthreads();                                // slab sl is consumed everywhere, slab sl + 1 is in place
         }
@@ -747,8 +706,12 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
         // columns past n hold zeros in Dst, so B is only clamped, never masked
         const double* ap = P.Dst + (size_t)dsw * 4 + wv * 64 + lane;
-        const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4)
         const unsigned un = (unsigned)n;
+        double xn3[3] = {0, 0, 0};
+        if (tail1) {
+#pragma unroll
+          for (int ct = 0; ct < 3; ct++) xn3[ct] = bp[ct][un * bs[ct]];
+        }
         // Software pipeline: the operands of k-step ks + kPF are requested while k-step ks multiplies.  Without
         // it every k-step waits a full memory latency (x comes from HBM on first touch) before its three MFMAs.
         // Requests past the last k-step repeat it (valid addresses, results unused).
@@ -765,11 +728,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
   } while (0)
 #pragma unroll
         for (int i = 0; i < kPF; i++) GEL_DX_LOAD(i, i);
-#ifdef GEL_ABL_NODX  // ablation (tools/build_variants.sh): no D.X product
-        for (int ks = 0; ks < 0; ks += kPF) {
-#else
         for (int ks = 0; ks < ksteps; ks += kPF) {
-#endif
 #pragma unroll
           for (int i = 0; i < kPF; i++) {
             if (ks + i < ksteps) {  // wave-uniform
@@ -781,6 +740,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
           }
         }
 #undef GEL_DX_LOAD
+        GEL_DX_TAIL_ACC(xn3[ct]);
         stage_tables_commit(P, lds, tab_mine);
         // hand-over: the rows of vector vb go to wavefront vb's own region ([node][11] behind its early park slots)
         lds_double* wg_lds = (lds_double*)lds + park_off + kHO;
@@ -819,8 +779,14 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         // A operands come pre-arranged (ProblemDev::Dsw): one 32-byte access per lane and k-step fetches the
         // values of all four row tiles; columns past n hold zeros there, so B is only clamped, never masked.
         const gel_double4* ap = reinterpret_cast<const gel_double4*>(P.Dsw) + (size_t)dsw * 1 + lane;
-        const int ksteps = (n + 4) >> 2;  // ceil((n+1)/4)
         const unsigned un = (unsigned)n, ubs = (unsigned)bs;
+        if (tail1) {   // wave-uniform addresses
+          xl[0] = xm[ph.xa + n];
+#pragma unroll
+          for (int c = 0; c < 3; c++) { xl[1 + c] = xr[3 * (ph.xa + n) + c]; xl[4 + c] = xv[3 * (ph.xa + n) + c]; }
+#pragma unroll
+          for (int c = 0; c < 4; c++) xl[7 + c] = xq[4 * (ph.xa + n) + c];
+        }
         // Latency form: the round trips are what counts (B = 1: x sits in pinned HOST memory, a load is a PCIe read).  The state
         // column of the first kSplitB k-steps (a 64-node phase: all 17) is requested at once, the A operands run kSplitA
         // k-steps ahead (L2), instead of one dependent round trip per k-step; longer phases go on in blocks of kSplitB k-steps.
@@ -872,9 +838,15 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         }
       }
     }
-#if !GEL_FRONT_EARLY_T
     GEL_TAKE_KNOT_TIMES();
-#endif
+#undef GEL_DX_TAIL_ACC
+    if (SPLIT && tail1 && rb) {   // latency form, D.X: row n of the phase (see tail1 above)
+      lm = __builtin_fma(dlast, xl[0], lm);
+#pragma unroll
+      for (int c = 0; c < 3; c++) { lr[c] = __builtin_fma(dlast, xl[1 + c], lr[c]); lv[c] = __builtin_fma(dlast, xl[4 + c], lv[c]); }
+#pragma unroll
+      for (int c = 0; c < 4; c++) lq[c] = __builtin_fma(dlast, xl[7 + c], lq[c]);
+    }
     if (MFMA && !active) return;  // ragged tail: nothing to write
     // the staging tile has been consumed: the region now becomes the park of what the velocity group
     // needs late (its sweeps re-read quaternion, velocity and D[j][j+1]; its defect needs the D.X row)
@@ -977,9 +949,6 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
     }
   }
   GEL_STAMP_AT(5);
-#if GEL_PRIO_PHASE_A
-  if (MFMA && !SPLIT && JAC) __builtin_amdgcn_s_setprio(0);
-#endif
   // ======================= from here on: no global loads =======================
   // compiler barrier: parked values are re-read from LDS below, not forwarded through VGPRs
   asm volatile("" ::: "memory");
@@ -1113,21 +1082,11 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         }
         if (JAC && lead) {
           double f[3];
-#ifndef GEL_ABL_NOQM
           if (!P.fd_recompute) GEL_MASS_CLOSED(tm);   // first: (T d + F) / m dies here
-#endif
           // velocity sweeps: only the aerodynamic force changes
-#ifdef GEL_ABL_NOVEL   // ablation (tools/build_variants.sh): the velocity sweeps left out
-          if (ph.air_fd && dx == 1.2345e300) {
-#else
           if (ph.air_fd) {
-#endif
             const double djj = PARK_GET(PK_DJJ);
-#if GEL_VEL_UNROLL
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
             for (int k = 0; k < 3; k++) {
               double vp[3], Fp[3];
 #pragma unroll
@@ -1142,11 +1101,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
             }
           }
           // quaternion sweeps: only the thrust direction changes; mass sweep: only the division by mass
-#ifdef GEL_ABL_NOQM
-          if (dx == 1.2345e300) {
-#else
           if (!P.fd_recompute) {
-#endif
             GEL_QUAT_CLOSED(GEL_T);
           } else if (P.fd_recompute) {
             const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
@@ -1189,7 +1144,6 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
       }
       GEL_STAMP_AT(6);
       // position sweeps (lib/con_dynamics.py:381-400); SPLIT: this wavefront's one
-#ifndef GEL_ABL_NOPOS
       if (JAC && (!SPLIT || part)) {
         const int k0 = SPLIT ? part - 1 : 0, k1 = SPLIT ? part : 3;
         // the tail of a sweep, given the position part at the perturbed point: the perturbed RHS value f_
@@ -1223,11 +1177,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
         if (P.fd_recompute) {
           todo = ((1u << k1) - 1u) & ~((1u << k0) - 1u);
         } else {
-#if GEL_POS_UNROLL
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
           for (int k = k0; k < k1; k++) {
             asm volatile("" ::: "memory");   // PosCentre is read from the park inside every trip
             GEL_LOAD_POS_CENTRE(pc, pcv);
@@ -1252,7 +1202,6 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
             if (ok) GEL_POS_SWEEP_EMIT(k, f);
           }
         }
-#ifndef GEL_EXP_NOFALLBACK
         if (todo) {
           // the chain once more on the perturbed position, for the lanes the difference form does not cover (all lanes of a
           // problem created with GEL_FLAG_FD_RECOMPUTE)
@@ -1278,14 +1227,11 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
             if (!ok) GEL_POS_SWEEP_EMIT(k, f);
           }
         }
-#endif
 #undef GEL_LOAD_POS_CENTRE
 #undef GEL_NEED_EARTH_ANGLE
 #undef GEL_POS_SWEEP_F
 #undef GEL_POS_SWEEP_EMIT
       }
-#endif
-#ifndef GEL_EXP_NOTFD
       if (JAC && lead && ph.t_fd) {
         // GEL_FLAG_FD_RECOMPUTE: the t0 / tf sweeps (con_dynamics.py:452-480); only the Earth angle changes.  This form is for
         // audits, not for speed: the position part of the centre is formed once more (bit-identical) and parked, so that only
@@ -1324,7 +1270,6 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
             EMIT(ph.s_vt + 3 * k + c, (fcc[c] * (tf - to) - f[c] * (tf_p - to_p)) * fdt);
         }
       }
-#endif
     } else {
       // NoAir (reference_area == 0): thrust + gravity only (src/pybind_dynamics.cpp:73-92)
       const double T = ph.thrust;
@@ -1357,11 +1302,7 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
           for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, FDQ(f[c], fc[c]));
         }
-#if GEL_POS_UNROLL
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
         for (int k = 0; k < 3; k++) {
           double r[3], gp[3];
 #pragma unroll
@@ -1395,7 +1336,6 @@ typedef unsigned gel_u4 __attribute__((ext_vector_type(4)));
   }
 #undef EMIT
 #undef GEL_CA_BRACKET
-#undef GEL_WIND_BRACKET
 #undef GEL_QUAT_CLOSED
 #undef GEL_MASS_CLOSED
 #undef EMIT_AT

@@ -1133,10 +1133,21 @@ int gel_shard_plan(gel_problem* p, int32_t nranks, const int32_t* unit_begin, in
   return GEL_OK;
 }
 
-int gel_eval_shard_packed_device(gel_problem* p, int32_t B, const double* d_x, double* d_out, int32_t rank, void* stream) {
+// The plan is state of the handle and the next gel_shard_plan call replaces it, so the caller states the plan its buffer was sized
+// for (nranks, width): a buffer allocated as [old nranks][B][old width] must never be written with the new plan's offsets.
+static int check_plan(const gel_problem* p, int32_t nranks, int64_t width) {
+  if (p->shard_width <= 0) return fail(GEL_ERR_ARG, "gel_shard_plan has not been called on this handle");
+  if (nranks != (int32_t)p->shard_begin.size() - 1 || width != p->shard_width)
+    return fail(GEL_ERR_ARG, "the handle's shard plan is not the one this buffer was sized for (gel_shard_plan was called again: plan once more, or use one handle per plan)");
+  return GEL_OK;
+}
+
+int gel_eval_shard_packed_device(gel_problem* p, int32_t B, const double* d_x, double* d_out, int32_t rank, int32_t nranks_expected,
+                                 int64_t width_expected, void* stream) {
   if (!p || !d_x || !d_out || B < 1) return fail(GEL_ERR_ARG, "bad argument");
   NEED_DEVICE(p);
-  if (p->shard_width <= 0 || !p->d_unit_base) return fail(GEL_ERR_ARG, "gel_shard_plan has not been called on this handle");
+  if (int rc = check_plan(p, nranks_expected, width_expected)) return rc;
+  if (!p->d_unit_base) return fail(GEL_ERR_ARG, "gel_shard_plan has not been called on this handle");
   const int nranks = (int)p->shard_begin.size() - 1;
   if (rank < 0 || rank >= nranks) return fail(GEL_ERR_ARG, "rank outside the plan");
   const int32_t u0 = p->shard_begin[rank], cnt = p->shard_begin[rank + 1] - u0;
@@ -1153,10 +1164,12 @@ int gel_eval_shard_packed_device(gel_problem* p, int32_t B, const double* d_x, d
   return GEL_OK;
 }
 
-int gel_shard_unpack_device(gel_problem* p, int32_t B, const double* d_out, double* d_res, double* d_jvar, void* stream) {
+int gel_shard_unpack_device(gel_problem* p, int32_t B, const double* d_out, double* d_res, double* d_jvar, int32_t nranks_expected,
+                            int64_t width_expected, void* stream) {
   if (!p || !d_out || B < 1 || (!d_res && !d_jvar)) return fail(GEL_ERR_ARG, "bad argument");
   NEED_DEVICE(p);
-  if (p->shard_width <= 0 || !p->d_shard_pos) return fail(GEL_ERR_ARG, "gel_shard_plan has not been called on this handle");
+  if (int rc = check_plan(p, nranks_expected, width_expected)) return rc;
+  if (!p->d_shard_pos) return fail(GEL_ERR_ARG, "gel_shard_plan has not been called on this handle");
   HIPCHK(gel::launch_shard_unpack(11 * p->dims.N, p->dims.num_var_entries, p->shard_width, B, p->d_shard_pos, d_out, d_res, d_jvar,
                                   stream ? (hipStream_t)stream : p->stream));
   return GEL_OK;

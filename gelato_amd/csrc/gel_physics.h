@@ -293,13 +293,9 @@ GEL_DEV Air atmosphere(double h, const double* atm) {
     // (T/Tmb)^(-g0/Lmb/R), exponent from the table.  Inside a layer the base lies in (0.65, 1.3) and the exponent
     // is a per-layer constant of magnitude <= 35, so exp(y*log(x)) is within ~|y log x| ulp (<= 10) of pow(x, y)
     // at a quarter of its cost (piece_time.hip: pow 336 ns, exp(y*log x) 201 ns, with flog_ratio 95 ns).
-#ifdef GEL_AB_POW  // A/B switch for tools/variant.sh only
-    o.P = Pb * pow((Tmb + Lmb * (h - Hb)) / Tmb, atm[44 + k]);
-#else
     // the temperature ratio by the tabulated 1/Tmb (<= 1 ulp from the division; amplified by the exponent, |y| <= 35,
     // that stays inside the exp(y log x) budget above)
     o.P = Pb * fexp(atm[44 + k] * flog_ratio((Tmb + Lmb * (h - Hb)) * atm[77 + k]));
-#endif
   } else {
     o.P = Pb * fexp((atm[55 + k] * (Hb - h)) * atm[77 + k]);           // g0/R and 1/Tmb from the table
   }

@@ -78,20 +78,11 @@ GEL_DEV PosPart pos_part(const double r[3], const Tables& tb, double barC20, Bra
   PosPart o;
   // the reference feeds the ECI position to ecef2geodetic for altitude (src/pybind_dynamics.cpp:43)
   double p, sl, cl;
-#ifdef GEL_AB_LATRT  // A/B switch: latitude by atan2, then sincos (rounds 1-2)
-  {
-    double lat, ih = 0.0, ihy = 0.0;
-    geodetic_lat_p(r[0], r[1], r[2], lat, p, o.inv_p, &ih, &ihy);
-    fsincos(lat, &sl, &cl);
-    if (CENTRE) { sink.put(PCS_IH, ih); sink.put(PCS_IHY, ihy); sink.put(PCS_P, p); }
-  }
-#else
   if (CENTRE) {
     double ih, ihy;
     geodetic_sincos_p(r[0], r[1], r[2], sl, cl, p, o.inv_p, &ih, &ihy);
     sink.put(PCS_IH, ih); sink.put(PCS_IHY, ihy); sink.put(PCS_P, p);
   } else geodetic_sincos_p(r[0], r[1], r[2], sl, cl, p, o.inv_p);
-#endif
   // half-angle pair of the NED quaternion (src/Coordinate.cpp:89-90): cos(lat/2) = sqrt((1+cos lat)/2)
   // (cos lat >= 0), sin(lat/2) = sin lat / (2 cos(lat/2)); root and reciprocal root from one iteration
   {

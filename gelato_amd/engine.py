@@ -273,15 +273,20 @@ class Engine:
         _lp = C.POINTER(C.c_int64)
         check(lib().gel_shard_plan(self._h, len(ub) - 1, ub.ctypes.data_as(_ip), C.byref(width), rp.ctypes.data_as(_lp),
                                    jp.ctypes.data_as(_lp)))
+        self.shard_plan_key = (len(ub) - 1, int(width.value), ub.tobytes())   # the plan the handle holds NOW (the next call replaces it)
         return int(width.value), rp, jp
 
-    def eval_shard_packed_device(self, B, d_x, d_out, rank, stream=0):
-        """rank `rank`'s units of all B vectors straight into its slice of the exchange buffer d_out [nranks][B][width]"""
-        check(lib().gel_eval_shard_packed_device(self._h, B, d_x, d_out, int(rank), stream or None))
+    def eval_shard_packed_device(self, B, d_x, d_out, rank, stream=0, plan=None):
+        """rank `rank`'s units of all B vectors straight into its slice of the exchange buffer d_out [nranks][B][width].
+        plan = (nranks, width) the buffer was sized for (default: the handle's current plan); the call fails if the handle
+        holds another plan by now."""
+        nr, w = plan if plan is not None else self.shard_plan_key[:2]
+        check(lib().gel_eval_shard_packed_device(self._h, B, d_x, d_out, int(rank), int(nr), int(w), stream or None))
 
-    def shard_unpack_device(self, B, d_out, d_res, d_jvar, stream=0):
+    def shard_unpack_device(self, B, d_out, d_res, d_jvar, stream=0, plan=None):
         """exchange buffer -> the ordinary res [B][11N] / jvar [B][V] layouts (one gather launch; either may be 0)"""
-        check(lib().gel_shard_unpack_device(self._h, B, d_out, d_res or None, d_jvar or None, stream or None))
+        nr, w = plan if plan is not None else self.shard_plan_key[:2]
+        check(lib().gel_shard_unpack_device(self._h, B, d_out, d_res or None, d_jvar or None, int(nr), int(w), stream or None))
 
     def jac_fd(self, group, x):
         gi = GROUPS.index(group)

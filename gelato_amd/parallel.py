@@ -78,7 +78,11 @@ class UnitShards:
         self.world, self.rank = int(world), int(rank)
         self.ranges = shard_chunks(unit_costs(engine), world)
         self.unit_begin = np.array([r[0] for r in self.ranges] + [self.ranges[-1][0] + self.ranges[-1][1]], dtype=np.int32)
+        self.engine = engine
+        import os
+        self.inplace = os.environ.get("GELATO_AMD_ALLGATHER_COPY", "0") in ("", "0")
         self.width, self.res_pos, self.jv_pos = engine.shard_plan(self.unit_begin)
+        self.plan_key = engine.shard_plan_key
         self.nres, self.V = engine.nres, engine.V
         # entries per rank (what a rank really contributes; the slices are padded to the largest share)
         self.counts = [(int(np.count_nonzero(self.res_pos // self.width == r)), int(np.count_nonzero(self.jv_pos // self.width == r)))
@@ -90,9 +94,22 @@ class UnitShards:
         """what the one collective delivers to a rank per decision vector, padding included"""
         return 8 * self.width * (self.world - 1)
 
+    def check_current(self):
+        """The plan lives in the engine's handle and a later UnitShards(engine, ...) replaces it: this object's width and maps
+        then describe a layout the device no longer writes.  Raises instead of letting a stale object size a buffer."""
+        if getattr(self.engine, "shard_plan_key", None) != self.plan_key:
+            raise RuntimeError("UnitShards: the engine's shard plan was replaced by a later gel_shard_plan call "
+                               "(one Engine holds one plan: build the other UnitShards on its own Engine, or re-create this one)")
+
+    @property
+    def plan(self):
+        """(nranks, width): what Engine.eval_shard_packed_device / shard_unpack_device check the handle's plan against"""
+        return (self.world, self.width)
+
     def buffer(self, B, device=None, dtype=None):
         """the exchange buffer out [world][B][width] (never zero-filled: every entry that is read has an owner)"""
         import torch
+        self.check_current()
         return torch.empty((self.world, int(B), self.width), dtype=dtype or torch.float64, device=device)
 
     def step(self, evaluate_packed, out, group=None):
@@ -100,10 +117,20 @@ class UnitShards:
         (Engine.eval_shard_packed_device on a GPU); then ONE all-gather, in place: send = out[rank], receive = out.
         Afterwards every rank holds every entry."""
         import torch.distributed as dist
+        self.check_current()
+        if tuple(out.shape[::2]) != (self.world, self.width):
+            raise ValueError("UnitShards.step: out is %s, the plan needs [%d][B][%d]" % (tuple(out.shape), self.world, self.width))
         if self.ranges[self.rank][1] > 0:
             evaluate_packed(out, self.rank)
         if self.world > 1:
-            dist.all_gather_into_tensor(out.view(-1), out[self.rank].view(-1), group=group)
+            send = out[self.rank].view(-1)
+            if not self.inplace:
+                # the non-aliased form: the send buffer is a copy of the slice (one device copy of width * B doubles).  The in-place
+                # form (send = a view of the receive buffer at this rank's offset) is what NCCL / RCCL document for all-gather and
+                # what gloo executes as a memcpy with src == dst; it has never run on RCCL with more than one rank from this
+                # repository (gpurun boxes have one GPU), so GELATO_AMD_ALLGATHER_COPY=1 keeps a way out (ADVICE r4)
+                send = send.clone()
+            dist.all_gather_into_tensor(out.view(-1), send, group=group)
         return out
 
     def flat_index(self, B):

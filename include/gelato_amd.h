@@ -182,13 +182,15 @@ int gel_unit_owner(const gel_problem* p, int32_t* res_owner, int32_t* jvar_owner
  * entries STRAIGHT into its slice out[rank] (all B vectors), so an in-place all-gather over the slices (send = out[rank],
  * receive = out) completes the buffer on every rank; a consumer reads it through the map, or asks
  * gel_shard_unpack_device for the ordinary layouts (one gather launch; d_res or d_jvar may be NULL).  A host-only handle can plan
- * (the CPU tests do); the plan is per handle and replaced by the next call.
+ * (the CPU tests do); the plan is per handle and replaced by the next call -- which is why the two device calls take the
+ * (nranks, width) the caller's buffer was sized for and return GEL_ERR_ARG when the handle holds another plan by now.
  * (lib/con_dynamics.py:46,132,237,320,512,554: per-phase independence; :381-400: independent forward-difference columns.) */
 int gel_shard_plan(gel_problem* p, int32_t nranks, const int32_t* unit_begin /* [nranks + 1] */, int64_t* width,
                    int64_t* res_pos /* [11N] or NULL */, int64_t* jvar_pos /* [V] or NULL */);
 int gel_eval_shard_packed_device(gel_problem* p, int32_t B, const double* d_x, double* d_out /* [nranks][B][width] */, int32_t rank,
-                                 void* stream);
-int gel_shard_unpack_device(gel_problem* p, int32_t B, const double* d_out, double* d_res, double* d_jvar, void* stream);
+                                 int32_t nranks, int64_t width, void* stream);
+int gel_shard_unpack_device(gel_problem* p, int32_t B, const double* d_out, double* d_res, double* d_jvar, int32_t nranks,
+                            int64_t width, void* stream);
 int gel_num_chunks(const gel_problem* p, int32_t* nchunks);
 int gel_chunk_phase(const gel_problem* p, int32_t* phase /* [nchunks] */);
 /* which form of the fused kernel a launch of B vectors takes: info = {jacobian, D.X on the matrix pipe, split

@@ -100,7 +100,7 @@ int main(int argc, char** argv) {
   double* vals = malloc(sizeof(double) * dm.total_nnz);
   if (!gpu) {
     CHECK(gel_eval_residual(p, x, res) == GEL_ERR_HIP); /* host-only handles never evaluate */
-    CHECK(gel_eval_shard_packed_device(p, 1, x, res, 0, NULL) == GEL_ERR_HIP);
+    CHECK(gel_eval_shard_packed_device(p, 1, x, res, 0, 1, 2, NULL) == GEL_ERR_HIP);
     {
       static double tx[77], table[77 * GEL_OUTPUT_COLUMNS];
       CHECK(gel_output_table(p, x, tx, 42.5, 143.4, table) == GEL_ERR_HIP);

@@ -230,3 +230,36 @@ def aero_coo_rows(prob, kind, spec):
     width = {"position": 3, "velocity": 3, "quaternion": 0 if kind == "q" else 4, "t": 2}
     return {var: (np.concatenate([np.tile(np.arange(b0, b0 + nk), w) for b0, nk in blocks]) if w and blocks else np.zeros(0, dtype=int))
             for var, w in width.items()}
+
+
+def aero_row_limits(prob, spec):
+    """per constraint row: the limit (units[3] of lib/con_aero.py) of its spec"""
+    nn = [int(v) for v in prob["num_nodes"]]
+    return np.concatenate([[float(sp[2])] * (nn[int(sp[0])] + 1 if int(sp[1]) else 1) for sp in spec]) if len(spec) else np.zeros(0)
+
+
+def aero_stated_tolerance(bound, ref):
+    """THE stated tolerance of SURVEY row f-1, per gradient entry, two fp64 implementations of the reference's
+    forward difference against each other:
+
+        |e_a - e_b|  <=  1e-5 + 1e-6 |e_ref|  +  2 K / (dx limit)
+
+    flat part: SURVEY 8(c)'s FD tolerance; K: what ONE evaluation of the row's function is off (aero_bound above, closed form
+    in the node's alpha, q, A = (|v| + omega |r| + |w|) / |v_air| and the altitude rounding; constants C_ACOS = C_DIR = 8,
+    C_Q = 4, C_RHO = 64, C_LAT = 2), doubled for the two evaluations of a difference, doubled again for two implementations.
+    `bound` = aero_coo_bounds(...)[var] already holds 2 K / (dx limit) (+ the reference's in-place drift)."""
+    return 1e-5 + 1e-6 * np.abs(ref) + 2.0 * bound
+
+
+def aero_first_order_truncation(terms, rows, limit, kind, t, dx):
+    """What the engine's entries would move by if its alpha-difference (gel_kernels.hip aero_dalpha: t = t0 (1 - x + 2 x^2 - x^3),
+    x = cot(alpha_c) t0 / 2) were cut after its first term, t = t0, given the true differences t = alpha_p - alpha_c of every entry
+    (from the oracle's alpha rows of the same nodes): the alpha part of an entry -- -t / (dx L) for the alpha kind, -q t / (dx L) for
+    the q-alpha kind (q_p = q_c to first order) -- grows by the factor x.  q kind: zero."""
+    if kind == "q":
+        return np.zeros_like(t)
+    a, q = terms["alpha"][rows], terms["q"][rows]
+    with np.errstate(all="ignore"):
+        x = np.where(np.sin(a) > 0.0, np.cos(a) / (2.0 * np.sin(a)) * t, 0.0)
+        d = x * (-t / (dx * limit)) * (1.0 if kind == "alpha" else q)
+    return np.where(np.isfinite(d), d, 0.0)

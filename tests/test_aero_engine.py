@@ -35,6 +35,8 @@ def test_aero_pattern_host_only(cname):
         E.aero_configure("alpha", [(3, 1, 0.1), (2, 1, 0.1)])   # phases must increase
 
 
+EXPECTED_UNBOUNDED = {"example": 0, "synthetic": 0}     # entries whose derived bound is not finite, per block (filled from the first GPU run)
+MIN_CAUGHT = {"example": 10, "synthetic": 5}            # entries a first-order truncation of the alpha difference must push out of tolerance
 BENIGN_LAT_DEG, BENIGN_ALPHA_DEG = 55.0, 1.0   # the region the margins table reports separately (moderate latitude, an angle of attack above a degree)
 
 
@@ -71,6 +73,14 @@ def aero_margins(cname, flags=0):
         bounds = fd_noise.aero_coo_bounds(oracle, pt, x, kind, spec, drift_of={v_: Jo[v_]["coo"][2] for v_ in VARS})
         terms = fd_noise.aero_noise_terms(oracle, pt, x, spec)
         rows = fd_noise.aero_coo_rows(pt, kind, spec)
+        lim = fd_noise.aero_row_limits(pt, spec)
+        # the true differences alpha_p - alpha_c of every entry: the oracle's alpha rows on THIS kind's nodes (limit 1)
+        t_true = {v_: np.zeros(0) for v_ in VARS}
+        if kind != "q":
+            P.aero_configure("alpha", np.array([(sp[0], sp[1], 1.0) for sp in spec]))
+            Ja = P.aero_jacobian("alpha", x)
+            t_true = {v_: -Ja[v_]["coo"][2] * float(prob["dx"]) for v_ in VARS}
+            P.aero_configure("alpha", spec_from_golden(g, cname, "alpha"))
         off = 0
         nrow, nnz = E.aero_dims(kind)
         for v, var in enumerate(VARS):
@@ -81,16 +91,36 @@ def aero_margins(cname, flags=0):
             lat_ok = np.abs(terms["lat_deg"][rows[var]]) < BENIGN_LAT_DEG
             a_deg = np.rad2deg(terms["alpha"][rows[var]])
             benign = lat_ok & (a_deg > BENIGN_ALPHA_DEG)
+            # the domain on which the FLAT tolerance of SURVEY 8(c) is asserted ("f-1"): dynamic-pressure rows
+            # everywhere; angle-of-attack rows at moderate latitude above a degree; q-alpha rows there too, with the flat term
+            # scaled by the row's factor q / limit (the row is that factor times the angle, so its noise floor is the angle's
+            # times the factor)
+            q_over_l = terms["q"][rows[var]] / lim[rows[var]]
+            flat_dom = np.ones(vals.shape, dtype=bool) if kind == "q" else benign
+            flat_scale = (1.0 + q_over_l) if kind == "qalpha" else np.ones(vals.shape)
             for against, rv in (("reference (G9)", g["%s_%s_jac_%s_vals" % (cname, kind, var)]), ("oracle", Jo[var]["coo"][2])):
                 assert vals.shape == rv.shape
                 d = np.abs(vals - rv)
                 flat = 1e-5 + 1e-6 * np.abs(rv)
                 derived = 2.0 * bounds[var] + 1e-9 * np.abs(rv)
+                stated = fd_noise.aero_stated_tolerance(bounds[var], rv)
+                flat_d = 1e-5 * flat_scale + 1e-6 * np.abs(rv)
+                # teeth: the same comparison with the engine's alpha-difference cut after its first term
+                # (t = t0 instead of t0 (1 - x + 2 x^2 - x^3), x = cot(alpha) t0 / 2: entries of the alpha and q-alpha kinds
+                # move by x times their alpha part) -- how many entries the stated tolerance would then reject
+                mut = vals if kind == "q" else vals + fd_noise.aero_first_order_truncation(terms, rows[var], lim[rows[var]], kind, t_true[var], float(prob["dx"]))
+                with np.errstate(invalid="ignore"):
+                    caught = int(np.count_nonzero(np.isfinite(stated) & (np.abs(mut - rv) > stated)))
                 table.append({"fixture": "g9_" + cname, "flags": flags, "kind": kind, "var": var, "against": against, "entries": int(d.size),
                               "max_abs_diff": float(d.max()), "max_abs_ref": float(np.abs(rv).max()),
                               "worst_flat_excess": float((d - flat).max()), "entries_needing_derived_allowance": int(np.count_nonzero(d > flat)),
                               "derived_allowance_max": float(derived[np.isfinite(derived)].max()) if np.isfinite(derived).any() else None,
                               "worst_derived_excess": float((d - derived)[np.isfinite(derived)].max()) if np.isfinite(derived).any() else None,
+                              "worst_stated_excess": float((d - stated)[np.isfinite(stated)].max()) if np.isfinite(stated).any() else None,
+                              "entries_without_finite_bound": int(np.count_nonzero(~np.isfinite(stated))),
+                              "flat_domain_entries": int(flat_dom.sum()),
+                              "worst_flat_domain_excess": float((d - flat_d)[flat_dom].max()) if flat_dom.any() else None,
+                              "first_order_truncation_caught": caught,
                               "benign_entries": int(benign.sum()),
                               "worst_flat_excess_benign": float((d - flat)[benign].max()) if benign.any() else None,
                               # the same figure for other angle-of-attack thresholds (how the benign region was chosen)
@@ -104,9 +134,21 @@ def aero_margins(cname, flags=0):
 @pytest.mark.parametrize("flags", [0, 8])
 @pytest.mark.parametrize("cname", ["example", "synthetic"])
 def test_aero_values_and_gradients_gpu(cname, flags):
-    for row in aero_margins(cname, flags):
+    table = aero_margins(cname, flags)
+    for row in table:
         what = "%(fixture)s %(kind)s/%(var)s vs %(against)s" % row
         assert row["worst_derived_excess"] is None or row["worst_derived_excess"] <= 0.0, (what, row["max_abs_diff"])
+        # (1) the STATED tolerance of row f-1: 1e-5 + 1e-6 |ref| + 2 K_f / (dx limit), closed form, constants fixed
+        assert row["worst_stated_excess"] is None or row["worst_stated_excess"] <= 0.0, (what, row["worst_stated_excess"])
+        # (2) the FLAT tolerance of SURVEY 8(c) where it holds: every dynamic-pressure entry; angle-of-attack entries below
+        #     55 deg of latitude above 1 deg of angle of attack; q-alpha entries there with the flat term times (1 + q / limit)
+        assert row["worst_flat_domain_excess"] is None or row["worst_flat_domain_excess"] <= 0.0, (what, row["worst_flat_domain_excess"])
+        # entries without a finite bound (the air-relative speed may vanish: lift-off inside the wind table) are counted, not hidden
+        assert row["entries_without_finite_bound"] <= EXPECTED_UNBOUNDED[cname], (what, row["entries_without_finite_bound"])
+    # (3) the tolerance has teeth: with the alpha-difference series cut after its first term the same assertion (1) fails
+    for against in ("reference (G9)", "oracle"):
+        caught = sum(r["first_order_truncation_caught"] for r in table if r["against"] == against and r["kind"] != "q")
+        assert caught >= MIN_CAUGHT[cname], (cname, against, caught)
         # how many entries lean on the derived allowance (the reference's own noise: q / limit times eps / sin(alpha) / dx for the
         # q-alpha kind) is on the record: tests/parity_margin.py -> profiles/r04/parity_margins.json; that the DEFAULT engine needs
         # none of it against the exact quotients at flight-like angles is asserted in tests/test_aero_exact_fd.py

@@ -876,6 +876,25 @@ def test_unit_shard_exchange_on_one_gpu(name, world, B):
         assert sh.bytes_received_per_vector() <= 8 * (E.nres + E.V) * (world - 1) / world * 1.6 + 16
     with pytest.raises(Exception):
         E.eval_shard_packed_device(B, dX.data_ptr(), out.data_ptr(), world, s)
+    # the plan is state of the handle.  A second UnitShards on the same Engine replaces it; the first object must not size
+    # buffers or launch with its stale width any more, and the C-ABI refuses a launch for a plan the handle no longer holds
+    from gelato_amd._lib import GelatoAmdError
+    world2 = 3 if world != 3 else 5
+    sh2 = parallel.UnitShards(E, world2, 0)
+    with pytest.raises(RuntimeError, match="replaced"):
+        sh.buffer(B, dev)
+    with pytest.raises(RuntimeError, match="replaced"):
+        sh.step(lambda o, r: None, out)
+    with pytest.raises(GelatoAmdError):
+        E.eval_shard_packed_device(B, dX.data_ptr(), out.data_ptr(), 0, s, plan=sh.plan)
+    with pytest.raises(GelatoAmdError):
+        E.shard_unpack_device(B, out.data_ptr(), r2.data_ptr(), j2.data_ptr(), s, plan=sh.plan)
+    out2 = sh2.buffer(B, dev)
+    for r in range(world2):
+        E.eval_shard_packed_device(B, dX.data_ptr(), out2.data_ptr(), r, s, plan=sh2.plan)
+    assert E.sync(s) == 0
+    res2, jv2 = sh2.gather(out2)
+    assert torch.equal(res2, ref_r) and torch.equal(jv2, ref_j)
 
 
 @pytest.mark.parametrize("name", ["example", "mixed-6x64", "stress-12x128"])

@@ -221,3 +221,26 @@ def test_static_counter_files_name_their_build():
         assert "workload" in d and "batch" in d, f
         shas.add(d["build_so_sha256"])
     assert len(shas) == 1
+
+
+def test_a_replaced_shard_plan_is_refused_not_used():
+    """gel_shard_plan is state of the handle; a second plan on the same Engine makes the first UnitShards stale.  The
+    stale object refuses to size a buffer or run a step (host-only handle: no GPU needed for the plan)."""
+    from gelato_amd import Engine, parallel
+    pdict, unitdict, _c, _x = problem.make_problem("mixed-6x64")
+    E = Engine(con_dynamics.problem_arrays(pdict, unitdict), device=-1)
+    sh2 = parallel.UnitShards(E, 2, 0)
+    assert sh2.plan == (2, sh2.width) and E.shard_plan_key[:2] == sh2.plan
+    sh2.check_current()
+    sh8 = parallel.UnitShards(E, 8, 3)
+    assert sh8.width != sh2.width
+    sh8.check_current()
+    with pytest.raises(RuntimeError, match="replaced"):
+        sh2.check_current()
+    with pytest.raises(RuntimeError, match="replaced"):
+        sh2.buffer(4)
+    # the same plan again is the same key: an object built from it is current, the older twin as well
+    sh2b = parallel.UnitShards(E, 2, 1)
+    sh2b.check_current(); sh2.check_current()
+    with pytest.raises(RuntimeError, match="replaced"):
+        sh8.check_current()

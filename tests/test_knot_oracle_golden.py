@@ -179,11 +179,19 @@ def test_inequality_mass_raises_like_the_reference_when_a_stage_event_is_missing
     pdict["RocketStage"] = {k: dict(v) for k, v in pdict["RocketStage"].items()}
     first = next(iter(pdict["RocketStage"].values()))
     first["cutoff_at"] = "NO_SUCH_EVENT"
-    with pytest.raises(IndexError, match="NO_SUCH_EVENT"):
-        ck2.rows_of(pdict, unitdict, condition)
+    # raised where the reference raises -- inside inequality_mass / inequality_jac_mass -- and nowhere else: the shared row
+    # table is built, and every other group of it (knot, terminal, time ...) works on such a pdict
+    from gelato_amd import con_trajectory as ct
+    T = ck2.rows_of(pdict, unitdict, condition)
+    assert T.missing_stage_events == (first["ignition_at"], "NO_SUCH_EVENT")
+    assert T.slices["knot"][1] > T.slices["knot"][0] and "t" in T.jac["tineq"]
+    for fn in (ct.inequality_mass, ct.inequality_jac_mass):
+        with pytest.raises(IndexError, match="NO_SUCH_EVENT"):
+            fn({}, pdict, unitdict, condition)
+    assert ct.equality_length_6DoF_rate({}, pdict, unitdict, condition) > 0
     assert pb.make_problem("mixed-6x64")[0]["gelato_amd_allow_missing_stage_events"]
     pdict["gelato_amd_allow_missing_stage_events"] = True
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        ck2.rows_of(pdict, unitdict, condition)
+        assert ck2.rows_of(pdict, unitdict, dict(condition)).missing_stage_events is None     # a new condition object: the table is rebuilt
     assert any("inequality_mass" in str(x.message) for x in w)

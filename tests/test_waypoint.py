@@ -164,17 +164,6 @@ def test_row_abi_validation():
 
 
 # ------------------------------------------------------------------ the "downrange" rows (G13b)
-def _dr_bounds(rows, grp, cond):
-    """(min, max) of the group's downrange `max` rows, by row index (the reference scales that row's t entry by max)"""
-    out = {}
-    mine = [r for r in rows if r[0] == grp]
-    names = None
-    for ir, r in enumerate(mine):
-        if r[3] == "dr" and r[5] == "max":
-            out[ir] = r
-    return out
-
-
 @pytest.mark.parametrize("cname", ["dr", "dronly"])
 @pytest.mark.parametrize("xname", ["init", "moved"])
 def test_oracle_downrange_rows_vs_reference_golden(xname, cname):

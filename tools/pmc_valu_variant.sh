@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; LIBV="$1"; BA="$2"
 export TMPDIR=/tmp; cd /tmp; OUT=/tmp/pmcv; rm -rf $OUT
 [ -n "$LIBV" ] && export GELATO_AMD_LIB=$R/$LIBV
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 --output-format csv -d $OUT -o p -- python3 $R/bench.py --steps 4 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-extras $BA > /dev/null 2> $OUT.err
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 --output-format csv -d $OUT -o p -- python3 $R/bench.py --steps 4 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-extras --no-other-configs $BA > /dev/null 2> $OUT.err
 python3 - $OUT <<'PY'
 import csv, glob, sys
 per = {}

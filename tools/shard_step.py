@@ -45,17 +45,17 @@ for world in (2, 4, 8):
         dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
         djv = torch.empty((B, E.V), dtype=torch.float64, device=dev)
         reps = 200 if B <= 64 else 50
-        k_us = [timed(lambda r=r: E.eval_shard_packed_device(B, dX.data_ptr(), dout.data_ptr(), r, s), reps) if sh.ranges[r][1] else 0.0
+        k_us = [timed(lambda r=r: E.eval_shard_packed_device(B, dX.data_ptr(), dout.data_ptr(), r, s, plan=sh.plan), reps) if sh.ranges[r][1] else 0.0
                 for r in range(world)]
         copy_us = timed(lambda: recv[1:].copy_(dout[1:]), reps)
-        unpack_us = timed(lambda: E.shard_unpack_device(B, dout.data_ptr(), dres.data_ptr(), djv.data_ptr(), s), reps)
+        unpack_us = timed(lambda: E.shard_unpack_device(B, dout.data_ptr(), dres.data_ptr(), djv.data_ptr(), s, plan=sh.plan), reps)
         fused_us = timed(lambda: E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), s), reps)
         # wall time of one rank's step as the host sees it: launch + (stand-in) exchange + synchronise
         import time
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            E.eval_shard_packed_device(B, dX.data_ptr(), dout.data_ptr(), 0, s)
+            E.eval_shard_packed_device(B, dX.data_ptr(), dout.data_ptr(), 0, s, plan=sh.plan)
             recv[1:].copy_(dout[1:])
             torch.cuda.synchronize()
         wall_us = 1e6 * (time.perf_counter() - t0) / reps
