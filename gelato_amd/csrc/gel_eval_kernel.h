@@ -400,7 +400,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     if (COOP && tail1) {
       const int rt = PACK ? (wv & 1) : wv;
 #pragma unroll
-      for (int i = 0; i < 4; i++) dl4[i] = dcol[min(16 * rt + (lane >> 4) + 4 * i, n - 1)];
+      for (int i = 0; i < 4; i++) dl4[i] = dcol[min(j0 + 16 * rt + (lane >> 4) + 4 * i, n - 1)];   // j0: this work item's chunk of the phase
     }
     const double dlast = (SPLIT && tail1) ? dcol[jc] : 0.0;     // latency form: D[j][n]
     double xl[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // latency form: state row n
