@@ -162,6 +162,8 @@ struct gel_problem {
   double* d_tables = nullptr;
   double* d_cval = nullptr;
   int32_t* d_src = nullptr;
+  int32_t *d_vdst = nullptr, *d_vsrc = nullptr;   // the x-dependent entries of the gather map: destination (ascending), signed source
+  int32_t nvar_entries = 0;
   int32_t* d_flag = nullptr;
   // B = 1 / small-batch working set
   int capB = 0;
@@ -805,6 +807,16 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     return rc;
   }
   {
+    std::vector<int32_t> vdst, vsrc;
+    for (size_t i = 0; i < p->src.size(); i++)
+      if (p->src[i] != -1) { vdst.push_back((int32_t)i); vsrc.push_back(p->src[i]); }
+    p->nvar_entries = (int32_t)vdst.size();
+    if (!vdst.empty() && ((rc = upload(&p->d_vdst, vdst)) || (rc = upload(&p->d_vsrc, vsrc)))) {
+      gel_problem_destroy(p);
+      return rc;
+    }
+  }
+  {
     // one-phase sub-problems for the phase-by-phase forward difference (gel_jac_fd)
     std::vector<gel::PhaseDev> sub = dph;
     std::vector<int4> subchunks = chunks;
@@ -878,6 +890,7 @@ int gel_problem_destroy(gel_problem* p) {
   hipSetDevice(p->device);
   if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
   hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dsw); hipFree(p->d_Dst); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
+  hipFree(p->d_vdst); hipFree(p->d_vsrc);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag); hipFree(p->d_unit_base); hipFree(p->d_shard_pos);
   hipFree(p->d_aero_nodes); hipFree(p->d_aero_x); hipFree(p->d_aero_out);
   free_slots(p);
@@ -1172,6 +1185,21 @@ int gel_shard_unpack_device(gel_problem* p, int32_t B, const double* d_out, doub
   if (!p->d_shard_pos) return fail(GEL_ERR_ARG, "gel_shard_plan has not been called on this handle");
   HIPCHK(gel::launch_shard_unpack(11 * p->dims.N, p->dims.num_var_entries, p->shard_width, B, p->d_shard_pos, d_out, d_res, d_jvar,
                                   stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
+int gel_fill_full_device(gel_problem* p, int32_t B, double* d_jfull, void* stream) {
+  if (!p || !d_jfull || B < 1) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  HIPCHK(gel::launch_fill_full(p->dims.total_nnz, B, p->d_cval, d_jfull, stream ? (hipStream_t)stream : p->stream));
+  return GEL_OK;
+}
+
+int gel_update_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream) {
+  if (!p || !d_jvar || !d_jfull || B < 1) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  HIPCHK(gel::launch_update_full(p->dims.total_nnz, p->dims.num_var_entries, p->nvar_entries, B, p->d_vdst, p->d_vsrc, d_jvar, d_jfull,
+                                 stream ? (hipStream_t)stream : p->stream));
   return GEL_OK;
 }
 

@@ -109,6 +109,33 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(long long nnz, long long
 }
 
 // ---------------------------------------------------------------------------
+// Update of a full COO value buffer that already holds the constants: only the x-dependent
+// entries are written -- full[b][vdst[i]] = +-jvar[b][|vsrc[i]|] for the nvar entries the gather map takes from the compact
+// vector (26 k of the 607 k at mixed-6x64), vdst ascending, so the runs that are contiguous in the reference's emission order
+// (the [node][xyz] blocks: four fifths of the entries) are coalesced stores and the rest (the diagonal of the dense velocity
+// blocks, the pairs of the quaternion blocks) are single 8 / 16-byte writes.  4 % of the bytes expand_kernel writes.
+// fill_full_kernel lays the constant template down once (or again whenever the buffer is re-used for other data).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void update_full_kernel(long long nnz, long long V, int nvar, int B, const int32_t* __restrict__ vdst,
+                                                             const int32_t* __restrict__ vsrc, const double* __restrict__ jvar,
+                                                             double* __restrict__ full) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nvar) return;
+  const int d = vdst[i], s = vsrc[i];
+  const int g = (s >= 0) ? s : -2 - s;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const double v = jvar[(size_t)b * V + g];
+    full[(size_t)b * nnz + d] = (s >= 0) ? v : -v;
+  }
+}
+__global__ __launch_bounds__(kBlock) void fill_full_kernel(long long nnz, int B, const double* __restrict__ cval, double* __restrict__ full) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (long long)gridDim.x * kBlock) {
+    const double c = cval[i];
+    for (int b = blockIdx.y; b < B; b += gridDim.y) __builtin_nontemporal_store(c, full + (size_t)b * nnz + i);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // generic column-batched forward difference (lib/jac_fd.py:29-62) of the four defect residuals, PHASE BY PHASE.
 // The residual rows of a phase depend only on the 13 n + 13 columns of that phase (its state and control nodes and its
 // two knot times; lib/con_dynamics.py:46,132,237,512 are loops over phases with no cross-phase data): every other
@@ -1178,6 +1205,23 @@ hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, 
     hipLaunchKernelGGL(expand_kernel, dim3(gx, (nb + kExpandGroup - 1) / kExpandGroup), dim3(kBlock), 0, s, nnz, V, nb,
                        cval, src, d_jvar + (size_t)b0 * V, d_full + (size_t)b0 * nnz);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_update_full(long long nnz, long long V, int nvar, int B, const int32_t* vdst, const int32_t* vsrc,
+                              const double* d_jvar, double* d_full, hipStream_t s) {
+  if (B <= 0 || nvar <= 0) return hipSuccess;
+  const unsigned gx = (unsigned)((nvar + kBlock - 1) / kBlock);
+  // enough workgroups to fill the chip whatever the batch; every workgroup strides over the vectors
+  const unsigned gy = (unsigned)std::min<long long>(B, std::max<long long>(1, 8192 / gx));
+  hipLaunchKernelGGL(update_full_kernel, dim3(gx, gy), dim3(kBlock), 0, s, nnz, V, nvar, B, vdst, vsrc, d_jvar, d_full);
+  return hipGetLastError();
+}
+hipError_t launch_fill_full(long long nnz, int B, const double* cval, double* d_full, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  unsigned gx = (unsigned)((nnz + kBlock - 1) / kBlock);
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(fill_full_kernel, dim3(gx, (unsigned)std::min(B, 16)), dim3(kBlock), 0, s, nnz, B, cval, d_full);
   return hipGetLastError();
 }
 

@@ -15,6 +15,10 @@ EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac);
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s);
 hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, const int32_t* src,
                          const double* d_jvar, double* d_full, hipStream_t s);
+// x-dependent entries only, into a full COO buffer that holds the constants (launch_fill_full lays them down)
+hipError_t launch_update_full(long long nnz, long long V, int nvar, int B, const int32_t* vdst, const int32_t* vsrc,
+                              const double* d_jvar, double* d_full, hipStream_t s);
+hipError_t launch_fill_full(long long nnz, int B, const double* cval, double* d_full, hipStream_t s);
 // packed unit-shard exchange buffer [nranks][B][width] -> the ordinary res [B][nres] / jvar [B][V] layouts (either may be null)
 hipError_t launch_shard_unpack(long long nres, long long V, long long width, int B, const int64_t* pos, const double* out,
                                double* d_res, double* d_jvar, hipStream_t s);

@@ -231,6 +231,14 @@ class Engine:
     def expand_full_device(self, B, d_jvar, d_jfull, stream=0):
         check(lib().gel_expand_full_device(self._h, B, d_jvar, d_jfull, stream or None))
 
+    def fill_full_device(self, B, d_jfull, stream=0):
+        """the constant template into d_jfull [B][total_nnz], once (then update_full_device after every evaluation)"""
+        check(lib().gel_fill_full_device(self._h, B, d_jfull, stream or None))
+
+    def update_full_device(self, B, d_jvar, d_jfull, stream=0):
+        """only the x-dependent entries of d_jfull [B][total_nnz] from d_jvar [B][V] (the buffer holds the constants already)"""
+        check(lib().gel_update_full_device(self._h, B, d_jvar, d_jfull, stream or None))
+
     def launch_info(self, B, want_res=True, want_jac=True):
         """-> [jacobian, mfma, split, wavefronts, pack] of the kernel form a launch of B vectors takes"""
         info = (C.c_int32 * 5)()

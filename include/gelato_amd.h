@@ -161,6 +161,12 @@ int gel_eval_batch_device(gel_problem* p, int32_t B, const double* d_x, double* 
 /* materialise every COO value like the reference does: d_jfull [B][total_nnz],
  * from d_jvar [B][V] (compact -> full expansion kernel). */
 int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream);
+/* The same result without rewriting the constants (the reference rebuilds every COO value per call,
+ * lib/con_dynamics.py:108-111,491-494,627-630): gel_fill_full_device lays the constant template into d_jfull [B][total_nnz]
+ * ONCE, gel_update_full_device then writes only the x-dependent entries (4 % of the values at 6 x 64) from d_jvar [B][V] after
+ * every evaluation.  Bit-identical to gel_expand_full_device as long as nothing else writes the buffer. */
+int gel_fill_full_device(gel_problem* p, int32_t B, double* d_jfull, void* stream);
+int gel_update_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream);
 /* multi-GPU sharding of ONE batch (the defect path is block-diagonal per phase, lib/con_dynamics.py:46,132,237,320,512,554,
  * and its forward-difference columns are independent).  A work item = one 64-node chunk of one phase;
  * unit = 4 * work_item + part, part 0 = everything of the work item except its three position

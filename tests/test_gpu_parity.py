@@ -625,6 +625,25 @@ def test_device_pointer_api_and_full_expansion():
     res, jv, _ = E.eval_batch(X)
     assert np.array_equal(dres.cpu().numpy(), res) and np.array_equal(djv.cpu().numpy(), jv)
     assert np.array_equal(dfull.cpu().numpy(), E.expand(jv))
+    # the update-in-place mode: constants laid down once, then only the x-dependent entries per evaluation --
+    # the same bits as the full rewrite, also after the buffer has served another batch, for one vector and for a ragged batch
+    for Bu in (1, B, 37):
+        Xu = problem.synthetic_batch(x0, E.M, Bu, seed=77)
+        dXu = torch.from_numpy(Xu).to(dev)
+        dr = torch.empty((Bu, E.nres), dtype=torch.float64, device=dev)
+        dj = torch.empty((Bu, E.V), dtype=torch.float64, device=dev)
+        dupd = torch.full((Bu, E.total_nnz), float("nan"), dtype=torch.float64, device=dev)
+        dref = torch.empty((Bu, E.total_nnz), dtype=torch.float64, device=dev)
+        E.fill_full_device(Bu, dupd.data_ptr(), s)
+        assert E.sync(s) == 0
+        assert np.array_equal(dupd[Bu - 1].cpu().numpy()[~E.var_mask()], E.const_values()[~E.var_mask()])
+        for scale in (1.0, 1.0 + 3e-7):      # two different batches through the same buffer
+            dXs = dXu * scale
+            E.eval_batch_device(Bu, dXs.data_ptr(), dr.data_ptr(), dj.data_ptr(), s)
+            E.update_full_device(Bu, dj.data_ptr(), dupd.data_ptr(), s)
+            E.expand_full_device(Bu, dj.data_ptr(), dref.data_ptr(), s)
+            assert E.sync(s) == 0
+            assert torch.equal(dupd, dref)
 
 
 def test_nonfinite_input_sets_status():
