@@ -102,6 +102,10 @@ struct ProblemDev {
   // element: v kpt differs from ((v unit_v) unit_t / 2) / unit_p by <= 2 ulp
   double inv_uv, inv_dx, kpt;
   double hT;   // unit_t / 2 (exact)
+  // COO-direct output of the latency form (gel_eval_kernel.h): the full COO value array (pinned host memory, constants in place)
+  // and, per phase, the first entry of the eight groups of runs in it; null: the compact layout
+  double* coo_full;
+  const int32_t* coo;   // [8 * S]
 };
 
 }  // namespace gel

@@ -365,6 +365,51 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   } while (0)
   const double inv_uv = P.inv_uv;   // 1 / unit_v, divided on the host
 #define FDQ(fp, fc) (((fc) - (fp)) * fds)
+  // COO-DIRECT output (latency form, the optimiser's B = 1 callback: gel_host.hip run_host / gel_eval_callback).  The blocks of the
+  // reference's COO value vector whose entries are ALL x-dependent -- pos/velocity, pos/t, vel/mass, vel/position, vel/quaternion,
+  // vel/t, quat/u, quat/t (lib/con_dynamics.py:180-195,373-400,431-449,482-489,600-625: runs of [node][xyz] or [node][wxyz]) -- are
+  // written straight to their places in a FULL value array in pinned host memory (P.coo_full; the constants lie there already),
+  // each group of W slots of a node as W coalesced stores through an LDS tile, a negated twin run (the tf column of a t0 column)
+  // W n entries behind.  What is left for the host to scatter are the entries that sit alone between constants (the diagonal of the
+  // dense velocity block, the pairs of the dense quaternion block): 11 slots per node instead of 49.  P.coo[8 * phase + g]: first
+  // entry of group g's run in the full array (g: 0 pos/velocity, 1 pos/t, 2 vel/mass, 3 vel/position (+ 3 n k), 4 vel/quaternion
+  // (+ 3 n k), 5 vel/t, 6 quat/u (+ 4 n k), 7 quat/t).
+  const bool coo = SPLIT && !packed && P.coo_full != nullptr;   // wave-uniform
+  enum { CG_PV = 0, CG_PT, CG_VM, CG_VP, CG_VQ, CG_VT, CG_QU, CG_QT };
+#define GEL_COO_BASE(g) ((size_t)load_const(P.coo + 8 * sec + (g)))
+#define GEL_COO_EMIT(W, base_, vals_, okl_, twin_)                                                                     \
+  do {                                                                                                                 \
+    double* d_ = P.coo_full + (base_) + (size_t)(W) * j0;                                                              \
+    const unsigned long long okm_ = __builtin_amdgcn_ballot_w64(okl_);                                                 \
+    _Pragma("unroll") for (int c_ = 0; c_ < (W); c_++) if (!rb) GEL_CHK((vals_)[c_]);                                  \
+    if (cw8 == 512) {   /* a full chunk: every lane holds a node, the tile turns [node][W] into W rows of 64 */      \
+      lds_double* t_ = wave_lds + kTileOff;                                                                            \
+      _Pragma("unroll") for (int c_ = 0; c_ < (W); c_++) t_[(W) * lane + c_] = (vals_)[c_];                            \
+      _Pragma("unroll") for (int i_ = 0; i_ < (W); i_++) {                                                             \
+        const int e_ = 64 * i_ + lane;                                                                                 \
+        const double v_ = t_[e_];                                                                                      \
+        const int ln_ = ((W) == 4) ? (e_ >> 2) : ((e_ * 171) >> 9);   /* the lane (node) that owns entry e_ */          \
+        if ((okm_ >> ln_) & 1ull) {                                                                                    \
+          d_[e_] = v_;                                                                                                 \
+          if (twin_) d_[e_ + (W) * n] = -v_;                                                                           \
+        }                                                                                                              \
+      }                                                                                                                \
+    } else if (okl_) {   /* ragged chunk (lanes past the phase have left): every lane writes its own W entries */      \
+      _Pragma("unroll") for (int c_ = 0; c_ < (W); c_++) {                                                             \
+        d_[(W) * lane + c_] = (vals_)[c_];                                                                             \
+        if (twin_) d_[(W) * (n + lane) + c_] = -(vals_)[c_];                                                           \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+  // W consecutive compact slots of this node that are one [node][W] run of a COO block (group g, k-th run of the group)
+#define EMIT_GROUP(W, slot0, vals_, g, k, twin_, okl_)                                                                 \
+  do {                                                                                                                 \
+    if (coo) {                                                                                                         \
+      GEL_COO_EMIT(W, GEL_COO_BASE(g) + (size_t)(W) * n * (k), vals_, okl_, twin_);                                    \
+    } else if (okl_) {                                                                                                 \
+      _Pragma("unroll") for (int c_ = 0; c_ < (W); c_++) EMIT((slot0) + c_, (vals_)[c_]);                              \
+    }                                                                                                                  \
+  } while (0)
 
   // ======================= phase A: every global load =======================
   // XLDS (cooperative form, phases whose n + 1 state rows fit one 68-row slab): the four decision vectors' state rows are
@@ -867,9 +912,16 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     //      position Jacobian entries, the whole quaternion group (:155-213, :499-632) ----
     if (JAC && lead) {
       // pos/velocity diagonal (:190-196): the same value for every node and component -> one scalar per phase
-      if (j == 0) EMIT_AT(packed ? (ph.K - sub_hi) * cw8 : ph.K * n * 8, -(P.kpt * (tf - to)));   // behind all chunks' blocks of the phase (packed: behind the unit's slots)
+      if (coo) {   // the 3 n copies of the scalar in pos/velocity (:180-183), this chunk's share
+        const double sc = -(P.kpt * (tf - to));
+        double* d_ = P.coo_full + GEL_COO_BASE(CG_PV) + (size_t)3 * j0;
 #pragma unroll
-      for (int c = 0; c < 3; c++) EMIT(kSlotPT + c, ve[c] * P.kpt);  // t0 column; tf = its negative
+        for (int i = 0; i < 3; i++) d_[(cw8 == 512) ? 64 * i + lane : 3 * lane + i] = sc;   // ragged chunk: only the lanes with a node are alive
+      } else if (j == 0) EMIT_AT(packed ? (ph.K - sub_hi) * cw8 : ph.K * n * 8, -(P.kpt * (tf - to)));   // behind all chunks' blocks of the phase (packed: behind the unit's slots)
+      {
+        const double pt[3] = {ve[0] * P.kpt, ve[1] * P.kpt, ve[2] * P.kpt};   // t0 column; tf = its negative
+        EMIT_GROUP(3, kSlotPT, pt, CG_PT, 0, true, true);
+      }
     }
     if (!ph.hold && lead) {
       double fq[4];
@@ -914,12 +966,23 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         EMIT(ph.s_qq + 0, 0.5 * ((u0 * P.uu) * d2r) * hS);
         EMIT(ph.s_qq + 1, 0.5 * ((u1 * P.uu) * d2r) * hS);
         const double kq = 0.5 * (P.uu * d2r) * hS;
-        EMIT(ph.s_qq + 2, -(kq * q[0]));
-        EMIT(ph.s_qq + 3, kq * q[1]);
-        EMIT(ph.s_qq + 4, kq * q[2]);
-        EMIT(ph.s_qq + 5, kq * q[3]);
-#pragma unroll
-        for (int c = 0; c < 4; c++) EMIT(ph.s_qq + 6 + c, fq[c] * hT);  // t0 column; tf = its negative
+        if (coo) {
+          // quat/u (:600-613): entry (c, k) = -d(dq_c)/d(u_k) S = sign[k][c] C_which[k][c], C_i = kq q_i -- what the gather map makes of the
+          // four slots below (gel_host.hip walk_pattern), spelled out: the same products, the same bits
+          const double C0 = kq * q[0], C1 = kq * q[1], C2 = kq * q[2], C3 = kq * q[3];
+          const double u0v[4] = {C2, C3, -C0, -C1}, u1v[4] = {C3, -C2, C1, -C0};
+          EMIT_GROUP(4, 0, u0v, CG_QU, 0, false, true);
+          EMIT_GROUP(4, 0, u1v, CG_QU, 1, false, true);
+        } else {
+          EMIT(ph.s_qq + 2, -(kq * q[0]));
+          EMIT(ph.s_qq + 3, kq * q[1]);
+          EMIT(ph.s_qq + 4, kq * q[2]);
+          EMIT(ph.s_qq + 5, kq * q[3]);
+        }
+        {
+          const double qt[4] = {fq[0] * hT, fq[1] * hT, fq[2] * hT, fq[3] * hT};   // t0 column; tf = its negative
+          EMIT_GROUP(4, ph.s_qq + 6, qt, CG_QT, 0, true, true);
+        }
       }
     }
     if (rb) {
@@ -975,9 +1038,10 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
       const double dl_ = (q_[k] + dx) - q_[k];                                                                         \
       const double a_ = (k < 2) ? -(dl_ * kq_) : dl_ * kq_;   /* entry = -(f_p - f_c) fds; d dir_x / d q_k = +-2 q_k */ \
       const double b_ = -2.0 * (dl_ * kq_);                                                                            \
-      EMIT(ph.s_vq + 3 * k + 0, (2.0 * q_[k] + dl_) * a_);                                                             \
-      EMIT(ph.s_vq + 3 * k + 1, q_[3 - k] * b_);              /* d dir_y / d q = 2 (q3, q2, q1, q0) */                  \
-      EMIT(ph.s_vq + 3 * k + 2, ((k & 1) ? q_[k ^ 2] : -q_[k ^ 2]) * b_);   /* d dir_z / d q = 2 (-q2, q3, -q0, q1) */  \
+      const double vq_[3] = {(2.0 * q_[k] + dl_) * a_,                                                                 \
+                             q_[3 - k] * b_,                  /* d dir_y / d q = 2 (q3, q2, q1, q0) */                  \
+                             ((k & 1) ? q_[k ^ 2] : -q_[k ^ 2]) * b_};   /* d dir_z / d q = 2 (-q2, q3, -q0, q1) */     \
+      EMIT_GROUP(3, ph.s_vq + 3 * k, vq_, CG_VQ, k, false, true);                                                      \
     }                                                                                                                  \
   } while (0)
 #define GEL_MASS_CLOSED(tm_)                                                                                           \
@@ -985,7 +1049,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     /* two ROUNDED products, as the reference forms them (a contracted fma would difference an unrounded one) */      \
     const double e_ = (fresh_product(me + dx, P.um) - fresh_product(me, P.um)) * inv_m;                                \
     const double k_ = (e_ * (1.0 - e_ * (1.0 - e_))) * (inv_uv * fds);                                                 \
-    _Pragma("unroll") for (int c = 0; c < 3; c++) EMIT(kSlotVM + c, (tm_)[c] * k_);                                    \
+    const double vm_[3] = {(tm_)[0] * k_, (tm_)[1] * k_, (tm_)[2] * k_};                                               \
+    EMIT_GROUP(3, kSlotVM, vm_, CG_VM, 0, false, true);                                                                \
   } while (0)
     if (ph.air) {
       // The Earth angle omega t enters the RHS only through the rotation of the wind into ECI (the air-relative velocity's two
@@ -1129,8 +1194,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
           // 1e-8 typically).  The entries are therefore written in that closed form, which is also what the reference itself
           // uses for the phases without aerodynamics (:478-480); GEL_FLAG_FD_RECOMPUTE keeps the two sweeps (below).
           if (!ph.t_fd) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * hT);  // t0 column; tf = its negative
+            const double vt[3] = {fc[0] * hT, fc[1] * hT, fc[2] * hT};  // t0 column; tf = its negative
+            EMIT_GROUP(3, ph.s_vt, vt, CG_VT, 0, true, true);
           }
         }
         if (JAC) {   // quaternion and D[j][j+1] are no longer needed: their slots take f_c and the thrust direction
@@ -1159,9 +1224,10 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     const double Td_[3] = {Tp_ * PARK_GET(PK_Q3), Tp_ * PARK_GET(PK_DJJ), Tp_ * dir2};                        \
     accel(Td_, Fp_, inv_m, (pq).g, inv_uv, f_);                                                               \
   } while (0)
-#define GEL_POS_SWEEP_EMIT(kk, f_)                                                                            \
+#define GEL_POS_SWEEP_EMIT(kk, f_, okl_)                                                                      \
   do {                                                                                                        \
-    _Pragma("unroll") for (int c = 0; c < 3; c++) EMIT(kSlotVP + 3 * (kk) + c, FDQ((f_)[c], PARK_GET(PK_Q0 + c))); \
+    const double vp_[3] = {FDQ((f_)[0], PARK_GET(PK_Q0)), FDQ((f_)[1], PARK_GET(PK_Q1)), FDQ((f_)[2], PARK_GET(PK_Q2))}; \
+    EMIT_GROUP(3, kSlotVP + 3 * (kk), vp_, CG_VP, kk, false, okl_);                                           \
   } while (0)
         // PosCentre and the centre's position part as far as pos_delta() reads them, from the park
 #define GEL_LOAD_POS_CENTRE(pc, pcv)                                                                                   \
@@ -1174,6 +1240,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   pcv.shp = PARK_GET(PK_LV0); pcv.chp = PARK_GET(PK_LV1); pcv.inv_p = PARK_GET(PK_LV2);                                \
   pos_centre_tail(pt, cen_rho, cen_P, tb, pc, pcv.wn, pcv.we)
         unsigned todo = 0;   // sweeps with a lane the difference form does not cover (wave-uniform)
+        unsigned long long coo_okm = 0;   // COO-direct output: the verdict of the difference form, kept for the recomputing pass (the LDS tile
+                                          // of the first pass's stores has overwritten the parked PosCentre by then)
         if (P.fd_recompute) {
           todo = ((1u << k1) - 1u) & ~((1u << k0) - 1u);
         } else {
@@ -1188,6 +1256,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
             const double dlt = (k == 0) ? rp[0] - r[0] : ((k == 1) ? rp[1] - r[1] : rp[2] - r[2]);   // exact
             PosPart pq;
             const bool ok = pos_delta(r, k, dlt, pcv, pc, tb, pq);
+            if (coo) coo_okm = __builtin_amdgcn_ballot_w64(ok);   // the latency form runs ONE sweep per wavefront
             if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
               todo |= 1u << k;
               if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
@@ -1199,7 +1268,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
             // the recomputation below: every lane writes once, and a covered lane always writes the value of the difference
             // form -- a lane's entries do not depend on which other nodes (or, with two vectors per wavefront, which other
             // decision vector) share its wavefront
-            if (ok) GEL_POS_SWEEP_EMIT(k, f);
+            GEL_POS_SWEEP_EMIT(k, f, ok);
           }
         }
         if (todo) {
@@ -1213,7 +1282,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #pragma unroll
             for (int c = 0; c < 3; c++) rp[c] = fresh_product((k == c) ? re[c] + dx : re[c], P.up);
             bool ok = false;   // a lane mask on the scalar unit: the verdict of the difference form once more
-            if (!P.fd_recompute) {
+            if (!P.fd_recompute && coo) {
+              ok = ((coo_okm >> lane) & 1ull) != 0;
+            } else if (!P.fd_recompute) {
               GEL_LOAD_POS_CENTRE(pc, pcv);
               const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
               const double dlt = (k == 0) ? rp[0] - r[0] : ((k == 1) ? rp[1] - r[1] : rp[2] - r[2]);
@@ -1224,7 +1295,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
             PosPart pq = pos_part(rp, tb, P.barC20);
             double f[3];
             GEL_POS_SWEEP_F(rp, pq, f);
-            if (!ok) GEL_POS_SWEEP_EMIT(k, f);
+            GEL_POS_SWEEP_EMIT(k, f, !ok);
           }
         }
 #undef GEL_LOAD_POS_CENTRE
@@ -1309,8 +1380,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
           for (int c = 0; c < 3; c++) r[c] = ((k == c) ? (re[c] + dx) : re[c]) * P.up;
           gravity_eci(r, P.barC20, gp);
           accel_noair(Td, inv_m, gp, inv_uv, f);
-#pragma unroll
-          for (int c = 0; c < 3; c++) EMIT(kSlotVP + 3 * k + c, FDQ(f[c], fc[c]));
+          const double vp[3] = {FDQ(f[0], fc[0]), FDQ(f[1], fc[1]), FDQ(f[2], fc[2])};
+          EMIT_GROUP(3, kSlotVP + 3 * k, vp, CG_VP, k, false, true);
         }
         if (!P.fd_recompute) {
           GEL_QUAT_CLOSED(T);
@@ -1329,11 +1400,16 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
             for (int c = 0; c < 3; c++) EMIT(ph.s_vq + 3 * k + c, FDQ(f[c], fc[c]));
           }
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) EMIT(ph.s_vt + c, fc[c] * hT);  // t0 column; tf = its negative
+        {
+          const double vt[3] = {fc[0] * hT, fc[1] * hT, fc[2] * hT};  // t0 column; tf = its negative
+          EMIT_GROUP(3, ph.s_vt, vt, CG_VT, 0, true, true);
+        }
       }
     }
   }
+#undef EMIT_GROUP
+#undef GEL_COO_EMIT
+#undef GEL_COO_BASE
 #undef EMIT
 #undef GEL_CA_BRACKET
 #undef GEL_QUAT_CLOSED

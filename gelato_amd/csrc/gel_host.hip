@@ -164,6 +164,16 @@ struct gel_problem {
   int32_t* d_src = nullptr;
   int32_t *d_vdst = nullptr, *d_vsrc = nullptr;   // the x-dependent entries of the gather map: destination (ascending), signed source
   int32_t nvar_entries = 0;
+  int32_t* d_vline = nullptr;     // the 64-byte lines (index / 8) of a value vector that hold an x-dependent entry
+  int32_t nvar_lines = 0;
+  // COO-direct output of the one-vector latency path (gel_eval_kernel.h "COO-DIRECT"): first entry of the eight groups of runs per
+  // phase; the runs of the gather map that are left to the host (dense velocity / quaternion blocks); the engine's own full value
+  // array in pinned host memory (constants laid down once; the kernel and the host scatter rewrite the x-dependent entries)
+  std::vector<int32_t> coo_tab;   // [8 * S]; empty: the mode is not available for this problem
+  std::vector<Run> rest_runs;
+  int32_t* d_coo = nullptr;
+  double* h_full = nullptr;
+  double* cb_res = nullptr;       // pinned residual vector a caller may name as its own output (gel_pinned_buffers): no copy then
   int32_t* d_flag = nullptr;
   // B = 1 / small-batch working set
   int capB = 0;
@@ -387,8 +397,46 @@ static hipError_t spin_wait(hipStream_t s) {
   return q;
 }
 
-// run B evals from host x; leaves results in the pinned staging buffers
-int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_jac) {
+// The engine's own full COO value array and residual vector in pinned host memory (one-vector latency path): the constants are
+// laid down here, once; the COO-direct kernel and the host's scatter of the few entries left to it rewrite the x-dependent ones.
+int ensure_full(gel_problem* p) {
+  if (p->h_full) return GEL_OK;
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipHostMalloc((void**)&p->h_full, std::max<size_t>(1, p->cval.size()) * 8));
+  std::memcpy(p->h_full, p->cval.data(), p->cval.size() * 8);
+  HIPCHK(hipHostMalloc((void**)&p->cb_res, (size_t)11 * p->dims.N * 8));
+  return GEL_OK;
+}
+// GEL_NO_COO_DIRECT=1 (measurement switch): the compact layout + the host scatter of every x-dependent entry, as before round 5
+bool coo_direct(const gel_problem* p) {
+  static const bool off = [] { const char* e = getenv("GEL_NO_COO_DIRECT"); return e && atoi(e) != 0; }();
+  return !off && !p->coo_tab.empty() && p->d_coo != nullptr;
+}
+// After a COO-direct evaluation: the entries the kernel left to the host (the diagonal of the dense velocity block, the pairs of the
+// dense quaternion block: 11 of a node's 49 slots) go from the compact vector into the engine's array; a caller that brought its
+// own array gets the all-x-dependent blocks as whole copies and the same few scattered entries.
+void finish_full(gel_problem* p, double* vals_full, int fill) {
+  auto rest = [&](double* out) {
+    for (const gel_problem::Run& r : p->rest_runs) {
+      double* d = out + r.dst0;
+      const double* v = p->h_jv + r.src0;
+      if (r.sign > 0) for (int64_t k = 0; k < r.len; k++) d[k * r.dstride] = v[k * r.sstride];
+      else for (int64_t k = 0; k < r.len; k++) d[k * r.dstride] = -v[k * r.sstride];
+    }
+  };
+  rest(p->h_full);
+  if (vals_full == p->h_full) return;
+  if (fill) std::memcpy(vals_full, p->cval.data(), p->cval.size() * 8);
+  for (int b : {3, 4, 5, 6, 8, 9, 11, 12})
+    std::memcpy(vals_full + p->block_off[b], p->h_full + p->block_off[b], (size_t)(p->block_off[b + 1] - p->block_off[b]) * 8);
+  rest(vals_full);
+}
+
+// run B evals from host x; leaves results in the pinned staging buffers (res_to: where the kernel writes the residual vector
+// of a one-vector call -- the handle's staging buffer or the pinned vector the caller named; coo: COO-direct Jacobian output)
+int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_jac, double* res_to = nullptr, bool* coo_io = nullptr) {
+  const bool coo = coo_io && *coo_io;
+  if (coo_io) *coo_io = false;   // set again where the mode is really used (the zero-copy branch)
   int rc = ensure_capacity(p, B);
   if (rc) return rc;
   HIPCHK(hipSetDevice(p->device));
@@ -401,7 +449,8 @@ int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_ja
     // so it may live in host memory too.
     gel::ProblemDev dv = p->dev;
     dv.flag = p->h_flag;
-    HIPCHK(gel::launch_eval(dv, B, p->h_x, want_res ? p->h_res : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
+    if (coo && B == 1 && want_jac) { dv.coo_full = p->h_full; dv.coo = p->d_coo; *coo_io = true; }
+    HIPCHK(gel::launch_eval(dv, B, p->h_x, want_res ? (res_to ? res_to : p->h_res) : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
     HIPCHK(spin_wait(p->stream));
     if (*p->h_flag) { *p->h_flag = 0; return GEL_NONFINITE; }
     return GEL_OK;
@@ -412,6 +461,7 @@ int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_ja
   if (want_jac && nj) HIPCHK(hipMemcpyAsync(p->h_jv, p->d_jv, nj * 8, hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
+  if (want_res && res_to) std::memcpy(res_to, p->h_res, nr * 8);
   if (*p->h_flag) {
     HIPCHK(hipMemsetAsync(p->d_flag, 0, 4, p->stream));
     return GEL_NONFINITE;
@@ -733,6 +783,52 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     }
   }
 
+  if (!p->fd_recompute) {
+    // COO-direct groups: where the runs of the all-x-dependent blocks start in the full value vector (the emission order of
+    // walk_pattern() = the reference's), checked against the gather map itself -- any surprise switches the mode off
+    int64_t kb[GEL_NUM_BLOCKS] = {0};
+    std::vector<int32_t> tab((size_t)8 * S, -1);
+    bool ok = tot < (int64_t)1 << 31;
+    for (int i = 0; i < S && ok; i++) {
+      const HostPhase& h = p->ph[i];
+      const int n = h.n;
+      auto at = [&](int b) { return p->block_off[b] + kb[b]; };
+      int32_t* t = &tab[(size_t)8 * i];
+      t[0] = (int32_t)at(3); t[1] = (int32_t)at(4); t[2] = (int32_t)at(5); t[3] = (int32_t)at(6); t[4] = (int32_t)at(8); t[5] = (int32_t)at(9);
+      t[6] = h.hold ? -1 : (int32_t)at(11); t[7] = h.hold ? -1 : (int32_t)at(12);
+      // spot checks against the map: node j, component c of group g sits at t[g] + w (n k + j) + c and takes slot(g, k, c) of node j
+      auto expect = [&](int64_t f, int slot, int j, int sign) {
+        const int64_t s = compact_index(h, slot, j);
+        ok = ok && f >= 0 && f < tot && p->src[(size_t)f] == (sign > 0 ? (int32_t)s : (int32_t)(-2 - s));
+      };
+      for (int j : {0, n - 1})
+        for (int c = 0; c < 3; c++) {
+          ok = ok && p->src[(size_t)(t[0] + 3 * j + c)] == (int32_t)(h.voff + (int64_t)h.K * n);
+          expect(t[1] + 3 * j + c, 0 + c, j, +1); expect(t[1] + 3 * (n + j) + c, 0 + c, j, -1);
+          expect(t[2] + 3 * j + c, 3 + c, j, +1);
+          for (int k = 0; k < 3; k++) expect(t[3] + 3 * (n * k + j) + c, 6 + 3 * k + c, j, +1);
+          for (int k = 0; k < 4; k++) expect(t[4] + 3 * (n * k + j) + c, h.s_vq + 3 * k + c, j, +1);
+          expect(t[5] + 3 * j + c, h.s_vt + c, j, +1); expect(t[5] + 3 * (n + j) + c, h.s_vt + c, j, -1);
+        }
+      if (!h.hold)
+        for (int j : {0, n - 1})
+          for (int c = 0; c < 4; c++) {
+            // quat/u: the kernel's COO form writes {C2, C3, -C0, -C1 | C3, -C2, C1, -C0} with slots s_qq + 2 .. 5 = -C0, C1, C2, C3
+            static const int which[2][4] = {{2, 3, 0, 1}, {3, 2, 1, 0}}, sg[2][4] = {{+1, +1, -1, -1}, {+1, -1, +1, -1}};
+            for (int k = 0; k < 2; k++) expect(t[6] + 4 * (n * k + j) + c, h.s_qq + 2 + which[k][c], j, which[k][c] == 0 ? -sg[k][c] : sg[k][c]);
+            expect(t[7] + 4 * j + c, h.s_qq + 6 + c, j, +1); expect(t[7] + 4 * (n + j) + c, h.s_qq + 6 + c, j, -1);
+          }
+      for (int b = 0; b < GEL_NUM_BLOCKS; b++) kb[b] += phase_block_nnz(h, b);
+    }
+    if (ok) {
+      p->coo_tab = tab;
+      for (const gel_problem::Run& r : p->var_runs) {
+        const int b = (int)(std::upper_bound(p->block_off, p->block_off + GEL_NUM_BLOCKS + 1, r.dst0) - p->block_off) - 1;
+        if (b == 7 || b == 10) p->rest_runs.push_back(r);
+      }
+    }
+  }
+
   for (int i = 0; i < S; i++)
     for (int j0 = 0; j0 < p->ph[i].n; j0 += 64) p->chunk_phase.push_back(i);
   if (p->device == GEL_DEVICE_NONE) {
@@ -815,6 +911,18 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
       gel_problem_destroy(p);
       return rc;
     }
+    std::vector<int32_t> vline;
+    for (int32_t d : vdst)
+      if (vline.empty() || vline.back() != d / 8) vline.push_back(d / 8);
+    p->nvar_lines = (int32_t)vline.size();
+    if (!vline.empty() && (rc = upload(&p->d_vline, vline))) {
+      gel_problem_destroy(p);
+      return rc;
+    }
+    if (!p->coo_tab.empty() && (rc = upload(&p->d_coo, p->coo_tab))) {
+      gel_problem_destroy(p);
+      return rc;
+    }
   }
   {
     // one-phase sub-problems for the phase-by-phase forward difference (gel_jac_fd)
@@ -890,7 +998,9 @@ int gel_problem_destroy(gel_problem* p) {
   hipSetDevice(p->device);
   if (p->stream) { hipStreamSynchronize(p->stream); hipStreamDestroy(p->stream); }
   hipFree(p->d_phases); hipFree(p->d_node_phase); hipFree(p->d_chunks); hipFree(p->d_chunks_sorted); hipFree(p->d_Dsw); hipFree(p->d_Dst); hipFree(p->d_Dt); hipFree(p->d_tau); hipFree(p->d_tables);
-  hipFree(p->d_vdst); hipFree(p->d_vsrc);
+  hipFree(p->d_vdst); hipFree(p->d_vsrc); hipFree(p->d_vline); hipFree(p->d_coo);
+  if (p->h_full) hipHostFree(p->h_full);
+  if (p->cb_res) hipHostFree(p->cb_res);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag); hipFree(p->d_unit_base); hipFree(p->d_shard_pos);
   hipFree(p->d_aero_nodes); hipFree(p->d_aero_x); hipFree(p->d_aero_out);
   free_slots(p);
@@ -961,11 +1071,21 @@ int gel_full_source(const gel_problem* p, int32_t* src) {
   return GEL_OK;
 }
 
+int gel_pinned_buffers(gel_problem* p, double** res, double** vals_full) {
+  if (!p) return fail(GEL_ERR_ARG, "null argument");
+  NEED_DEVICE(p);
+  if (int rc = ensure_full(p)) return rc;
+  if (res) *res = p->cb_res;
+  if (vals_full) *vals_full = p->h_full;
+  return GEL_OK;
+}
+
 int gel_eval_residual(gel_problem* p, const double* x, double* res) {
   if (!p || !x || !res) return fail(GEL_ERR_ARG, "null argument");
-  const int rc = run_host(p, 1, x, true, false);
+  const bool own = p->cb_res && res == p->cb_res;   // the caller named the handle's pinned vector: the kernel writes it, no copy
+  const int rc = run_host(p, 1, x, true, false, own ? p->cb_res : nullptr);
   if (rc < 0) return rc;
-  std::memcpy(res, p->h_res, (size_t)11 * p->dims.N * 8);
+  if (!own) std::memcpy(res, p->h_res, (size_t)11 * p->dims.N * 8);
   return rc;
 }
 
@@ -975,10 +1095,15 @@ int gel_eval_jacobian(gel_problem* p, const double* x, double* vals_full, int32_
 
 int gel_eval(gel_problem* p, const double* x, double* res, double* vals_full, int32_t fill_constants) {
   if (!p || !x || !vals_full) return fail(GEL_ERR_ARG, "null argument");
-  const int rc = run_host(p, 1, x, res != nullptr, true);
+  NEED_DEVICE(p);
+  bool coo = coo_direct(p);
+  if (coo) { if (int rc0 = ensure_full(p)) return rc0; }
+  const bool own = res && p->cb_res && res == p->cb_res;
+  const int rc = run_host(p, 1, x, res != nullptr, true, own ? p->cb_res : nullptr, &coo);
   if (rc < 0) return rc;
-  if (res) std::memcpy(res, p->h_res, (size_t)11 * p->dims.N * 8);
-  scatter_full(p, p->h_jv, vals_full, fill_constants);
+  if (res && !own) std::memcpy(res, p->h_res, (size_t)11 * p->dims.N * 8);
+  if (coo) finish_full(p, vals_full, fill_constants);
+  else scatter_full(p, p->h_jv, vals_full, fill_constants);
   return rc;
 }
 
@@ -1198,7 +1323,8 @@ int gel_fill_full_device(gel_problem* p, int32_t B, double* d_jfull, void* strea
 int gel_update_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream) {
   if (!p || !d_jvar || !d_jfull || B < 1) return fail(GEL_ERR_ARG, "bad argument");
   NEED_DEVICE(p);
-  HIPCHK(gel::launch_update_full(p->dims.total_nnz, p->dims.num_var_entries, p->nvar_entries, B, p->d_vdst, p->d_vsrc, d_jvar, d_jfull,
+  HIPCHK(gel::launch_update_full(p->dims.total_nnz, p->dims.num_var_entries, p->nvar_entries, B, p->d_vdst, p->d_vsrc,
+                                 p->nvar_lines, p->d_vline, p->d_src, p->d_cval, d_jvar, d_jfull,
                                  stream ? (hipStream_t)stream : p->stream));
   return GEL_OK;
 }
@@ -1727,6 +1853,13 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
   dv.flag = p->h_flag;
   const bool want_jac = io->vals_full != nullptr;
   const bool fused = io->res || want_jac;
+  const bool coo = want_jac && coo_direct(p);
+  if (coo) {
+    if ((rc = ensure_full(p))) return rc;
+    dv.coo_full = p->h_full; dv.coo = p->d_coo;
+  }
+  const bool own_res = io->res && p->cb_res && io->res == p->cb_res;
+  double* const res_to = own_res ? p->cb_res : p->h_res;
   gel::AeroLaunchOut out;
   if (aero)
     for (int k = 0; k < 3; k++) {
@@ -1738,20 +1871,23 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
   // GEL_CB_MODE=3 (measurement switch): the three launches of rounds 1-2, back to back on the handle's stream
   static const int cb_mode = [] { const char* e = getenv("GEL_CB_MODE"); return e ? atoi(e) : 0; }();
   if (cb_mode == 3 || !fused) {
-    if (fused) HIPCHK(gel::launch_eval(dv, 1, p->h_x, p->h_res, want_jac ? p->h_jv : nullptr, p->stream));
+    if (fused) HIPCHK(gel::launch_eval(dv, 1, p->h_x, res_to, want_jac ? p->h_jv : nullptr, p->stream));
     if (rows) HIPCHK(gel::launch_rows(dv, (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, 1, p->h_x, p->h_rows,
                                       io->rows_jfn ? p->h_rows + R : nullptr, p->stream));
     if (aero) HIPCHK(gel::launch_aero(dv, (int)p->aero_nodes.size(), p->d_aero_nodes, 1, p->h_x, out, p->stream));
   } else {
     // ONE launch: defect groups, aero kinds and row table as workgroup ranges of one grid (gel_kernels.hip callback_kernel)
-    HIPCHK(gel::launch_callback(dv, want_jac, p->h_x, p->h_res, want_jac ? p->h_jv : nullptr,
+    HIPCHK(gel::launch_callback(dv, want_jac, p->h_x, res_to, want_jac ? p->h_jv : nullptr,
                                 aero ? (int)p->aero_nodes.size() : 0, p->d_aero_nodes, aero ? &out : nullptr,
                                 (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, rows ? p->h_rows : nullptr,
                                 (rows && io->rows_jfn) ? p->h_rows + R : nullptr, p->stream));
   }
   HIPCHK(hipStreamSynchronize(p->stream));   // the ONE wait of the callback (a sleeping wait: polling hipStreamQuery measured slower)
-  if (io->res) std::memcpy(io->res, p->h_res, (size_t)11 * p->dims.N * 8);
-  if (want_jac) scatter_full(p, p->h_jv, io->vals_full, io->fill_constants);
+  if (io->res && !own_res) std::memcpy(io->res, p->h_res, (size_t)11 * p->dims.N * 8);
+  if (want_jac) {
+    if (coo) finish_full(p, io->vals_full, io->fill_constants);
+    else scatter_full(p, p->h_jv, io->vals_full, io->fill_constants);
+  }
   if (rows) {
     std::memcpy(io->rows_con, p->h_rows, R * 8);
     if (io->rows_jfn) std::memcpy(io->rows_jfn, p->h_rows + R, 7 * nfn * 8);

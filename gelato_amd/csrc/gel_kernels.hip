@@ -128,6 +128,26 @@ __global__ __launch_bounds__(kBlock) void update_full_kernel(long long nnz, long
     full[(size_t)b * nnz + d] = (s >= 0) ? v : -v;
   }
 }
+// The same update by whole 64-byte lines: every line of a vector's value array that holds at least one x-dependent entry is written
+// in full, its constants from the template -- eight lanes per line.  An entry that sits alone between constants (the diagonal of the
+// dense velocity blocks: 2,880 per vector at mixed-6x64) is then a full-line write instead of an 8-byte one, which HBM (ECC words of
+// 32 / 64 bytes) turns into a read-modify-write: measured 0.26 -> see DESIGN.md ms at B = 1024 for 8 x fewer partial writes.  Needs
+// nnz % 8 == 0 (every vector's array starts on a line); launch_update_full() falls back to the entry-wise kernel otherwise.
+__global__ __launch_bounds__(kBlock) void update_lines_kernel(long long nnz, long long V, int nlines, int B, const int32_t* __restrict__ vline,
+                                                              const int32_t* __restrict__ src, const double* __restrict__ cval,
+                                                              const double* __restrict__ jvar, double* __restrict__ full) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 8 * nlines) return;
+  const long long i = 8LL * vline[t >> 3] + (t & 7);
+  const int s = src[i];
+  const double c = (s == -1) ? cval[i] : 0.0;
+  const int g = (s >= 0) ? s : -2 - s;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    double v = c;
+    if (s != -1) { const double w = jvar[(size_t)b * V + g]; v = (s >= 0) ? w : -w; }
+    __builtin_nontemporal_store(v, full + (size_t)b * nnz + i);
+  }
+}
 __global__ __launch_bounds__(kBlock) void fill_full_kernel(long long nnz, int B, const double* __restrict__ cval, double* __restrict__ full) {
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (long long)gridDim.x * kBlock) {
     const double c = cval[i];
@@ -473,7 +493,14 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   // q, cos, 1/sin, the node's rows) and what only the light sweeps need (centre wind, air velocity, body axis) wait there
   // instead of in registers across the position sweeps (234 -> 164 VGPRs).
   lds_f64* park = (lds_f64*)lds + ((table_doubles(P.Kw, P.Kc) + 1) & ~1) + (size_t)(threadIdx.x >> 6) * (kAeroParkSlots * 64) + lane;
-  lds_int* ipark = (lds_int*)(park - lane + AP_INTS * 64) + lane;      // ints: k, row0[3], nk[3], row[3] (or -1), centre_ok
+  // ints (12 per lane): [kind] 8 nk; then per kind and block width w the BYTE offset 8 (w row0 + k) of this node's entries inside a
+  // block of that width (or -1: no row of this kind / no gradient asked) -- alpha: w = 3, 4, 2 at 3, 4, 5; q: w = 3, 2 at 6, 7;
+  // q-alpha: w = 3, 4, 2 at 8, 9, 10; [11] centre_ok.  An entry of block (bo, w), column col then sits at byte
+  // 8 bo R + col (8 nk) + that offset of the kind's gradient vector: one 32-bit multiply-add per store, the rest on the scalar unit
+  // (round 4 formed bo R + w row0 + col nk + k in 64-bit vector arithmetic per entry and kind: 369 of the 2,349 vector instructions
+  // of a tile were integer address work)
+  lds_int* ipark = (lds_int*)(park - lane + AP_INTS * 64) + lane;
+#define AP_AIDX(kind, w) ((kind) == 0 ? ((w) == 3 ? 3 : ((w) == 4 ? 4 : 5)) : ((kind) == 1 ? ((w) == 3 ? 6 : 7) : ((w) == 3 ? 8 : ((w) == 4 ? 9 : 10))))
 #define AP_GET(i) (park[(i) * 64])
 #define AP_SET(i, v) (park[(i) * 64] = (v))
   // ---- centre (con_aero.py:39-87: scale, evaluate)
@@ -511,15 +538,20 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     for (int kind = 0; kind < 3; kind++) {
       const double il = frcp(Nd.limit[kind]);
       AP_SET(AP_ILIM + kind, il);
-      ipark[(1 + kind) * 64] = Nd.row0[kind]; ipark[(4 + kind) * 64] = Nd.nk[kind];
-      ipark[(7 + kind) * 64] = (live && O.jac[kind]) ? Nd.row[kind] : -1;
       const int row = Nd.row[kind];
+      {
+        const bool has = live && O.jac[kind] && row >= 0;
+        ipark[kind * 64] = 8 * Nd.nk[kind];
+        ipark[AP_AIDX(kind, 3) * 64] = has ? 8 * (3 * Nd.row0[kind] + Nd.k) : -1;
+        ipark[AP_AIDX(kind, 2) * 64] = has ? 8 * (2 * Nd.row0[kind] + Nd.k) : -1;
+        if (kind != 1) ipark[AP_AIDX(kind, 4) * 64] = has ? 8 * (4 * Nd.row0[kind] + Nd.k) : -1;
+      }
       if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
       const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
       O.con[kind][(size_t)b * O.nrows[kind] + row] = cv;
       chk += cv;
     }
-    ipark[0] = Nd.k; ipark[10 * 64] = centre_ok ? 1 : 0;
+    ipark[11 * 64] = centre_ok ? 1 : 0;
     AP_SET(AP_AC, alpha_c); AP_SET(AP_QC, qdyn_c); AP_SET(AP_CC, cc); AP_SET(AP_IS, isc); AP_SET(AP_IND, ind);
 #pragma unroll
     for (int c = 0; c < 3; c++) { AP_SET(AP_W + c, w[c]); AP_SET(AP_A0 + c, a0[c]); AP_SET(AP_DIR + c, dir[c]); }
@@ -542,29 +574,37 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       dq_ = qp_ - qc_;                                                                                            \
       if (need_alpha) {                                                                                           \
         const double cp_ = aero_cos(a, nv2, d, ind);                                                              \
-        if (__builtin_amdgcn_ballot_w64(!aero_dalpha(cp_, nv2, AP_GET(AP_CC), AP_GET(AP_IS), ipark[10 * 64] != 0, t_)) != 0) \
+        if (__builtin_amdgcn_ballot_w64(!aero_dalpha(cp_, nv2, AP_GET(AP_CC), AP_GET(AP_IS), ipark[11 * 64] != 0, t_)) != 0) \
           t_ = aero_acos(cp_, nv2) - ac_;                                                                         \
       }                                                                                                           \
     }                                                                                                             \
-    const int k_ = ipark[0];                                                                                      \
     _Pragma("unroll") for (int kind = 0; kind < 3; kind++) {                                                      \
       if ((skip_q) && kind == 1) continue;                 /* dynamic pressure has no quaternion block */        \
-      if (ipark[(7 + kind) * 64] < 0) continue;                                                                   \
-      const int R = O.nrows[kind], nq = (kind == 1) ? 0 : 4;                                                      \
+      const int a8_ = ipark[AP_AIDX(kind, width) * 64];                                                           \
+      if (a8_ < 0) continue;                                                                                      \
+      const int nq = (kind == 1) ? 0 : 4;                                                                         \
       const int bo = ((boff) < 0) ? (6 + nq) : (boff);                                                            \
-      double* jb = O.jac[kind] + (size_t)b * R * (8 + nq);                                                        \
       const double df_ = (kind == 0) ? t_ : ((kind == 1) ? dq_ : qp_ * t_ + dq_ * ac_);                           \
       const double gv = (zero) ? 0.0 : -(df_ * AP_GET(AP_ILIM + kind)) * inv_dx;                                  \
-      jb[(size_t)bo * R + (width) * ipark[(1 + kind) * 64] + (col) * ipark[(4 + kind) * 64] + k_] = gv;           \
+      gel_au2 gd_;                                                                                                \
+      __builtin_memcpy(&gd_, &gv, 8);                                                                             \
+      __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], ((col) == 0) ? a8_ : a8_ + (col) * ipark[kind * 64], 8 * bo * O.nrows[kind], 0); \
       chk += gv;                                                                                                  \
     }                                                                                                             \
   } while (0)
+  // one buffer resource per kind: base = this vector's gradient values, [R][8 + nq] doubles (wave-uniform: scalar registers)
+  typedef unsigned gel_au2 __attribute__((ext_vector_type(2)));
+  __amdgpu_buffer_rsrc_t jrs[3];
+#pragma unroll
+  for (int kind = 0; kind < 3; kind++)
+    jrs[kind] = __builtin_amdgcn_make_buffer_rsrc(O.jac[kind] ? (void*)(O.jac[kind] + (size_t)b * O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4))) : (void*)nullptr,
+                                                  0, -1, 0x00020000);
   if (want_jac) {
     // ---- t0 / tf columns
 #pragma unroll 1
     for (int c = (ROLES && sw != 0) ? 2 : 0; c < 2; c++) {
       if (P.fd_recompute) {   // audit form: the knot times and the node's abscissa are read again (not carried in registers)
-        const int kn = ipark[0], phn = nodes[ni].phase;
+        const int kn = nodes[ni].k, phn = nodes[ni].phase;
         const double to2 = xb[11 * M + 2 * N + phn], tf2 = xb[11 * M + 2 * N + phn + 1];
         const double tau2 = (kn == 0) ? 0.0 : P.tau[P.phases[phn].toff + kn - 1];
         const double to_p = (c == 0) ? to2 + dx : to2, tf_p = (c == 1) ? tf2 + dx : tf2;
@@ -663,6 +703,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     }
   }
 #undef GEL_AERO_EMIT
+#undef AP_AIDX
 #undef AP_GET
 #undef AP_SET
   if (!(fabs(chk) <= 1.79769313486231570815e308)) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
@@ -1209,8 +1250,15 @@ hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, 
 }
 
 hipError_t launch_update_full(long long nnz, long long V, int nvar, int B, const int32_t* vdst, const int32_t* vsrc,
+                              int nlines, const int32_t* vline, const int32_t* src, const double* cval,
                               const double* d_jvar, double* d_full, hipStream_t s) {
   if (B <= 0 || nvar <= 0) return hipSuccess;
+  if (nlines > 0 && (nnz & 7) == 0 && ((uintptr_t)d_full & 63) == 0) {
+    const unsigned gx = (unsigned)((8LL * nlines + kBlock - 1) / kBlock);
+    const unsigned gy = (unsigned)std::min<long long>(B, std::max<long long>(1, 16384 / gx));
+    hipLaunchKernelGGL(update_lines_kernel, dim3(gx, gy), dim3(kBlock), 0, s, nnz, V, nlines, B, vline, src, cval, d_jvar, d_full);
+    return hipGetLastError();
+  }
   const unsigned gx = (unsigned)((nvar + kBlock - 1) / kBlock);
   // enough workgroups to fill the chip whatever the batch; every workgroup strides over the vectors
   const unsigned gy = (unsigned)std::min<long long>(B, std::max<long long>(1, 8192 / gx));

@@ -17,6 +17,7 @@ hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, 
                          const double* d_jvar, double* d_full, hipStream_t s);
 // x-dependent entries only, into a full COO buffer that holds the constants (launch_fill_full lays them down)
 hipError_t launch_update_full(long long nnz, long long V, int nvar, int B, const int32_t* vdst, const int32_t* vsrc,
+                              int nlines, const int32_t* vline, const int32_t* src, const double* cval,
                               const double* d_jvar, double* d_full, hipStream_t s);
 hipError_t launch_fill_full(long long nnz, int B, const double* cval, double* d_full, hipStream_t s);
 // packed unit-shard exchange buffer [nranks][B][width] -> the ordinary res [B][nres] / jvar [B][V] layouts (either may be null)

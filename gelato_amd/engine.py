@@ -187,14 +187,36 @@ class Engine:
         rc = check(lib().gel_eval_jacobian(self._h, _d(x), _d(out), fill))
         return out, rc
 
-    def eval(self, x, out=None):
+    def pinned_buffers(self):
+        """(res [11N], vals_full [total_nnz]): numpy views of the handle's own pinned host buffers (gel_pinned_buffers).  Passing
+        them as `res_out` / `out` of eval / eval_jacobian (eval_callback uses them by itself) makes the one-vector calls
+        zero-copy: the kernel writes the residual rows and every all-x-dependent block of the value vector straight into them.
+        They belong to the engine and are rewritten by its next one-vector call."""
+        pb = self.__dict__.get("_pinned")
+        if pb is None:
+            r, v = C.c_void_p(), C.c_void_p()
+            check(lib().gel_pinned_buffers(self._h, C.byref(r), C.byref(v)))
+            dp = C.POINTER(C.c_double)
+            res = np.ctypeslib.as_array(C.cast(r, dp), shape=(self.nres,))
+            vals = np.ctypeslib.as_array(C.cast(v, dp), shape=(max(self.total_nnz, 1),))[:self.total_nnz]
+            pb = self._pinned = (res, vals, _d(res), _d(vals))
+        return pb[0], pb[1]
+
+    def eval(self, x, out=None, res_out=None):
+        """-> (res, vals_full, status).  out / res_out: arrays to write into (the engine's pinned_buffers() make it zero-copy)."""
         x = _f64(x)
-        res = np.empty(self.nres)
+        pb = self.__dict__.get("_pinned")
+        if res_out is None:
+            res, rp = np.empty(self.nres), None
+        else:
+            res = res_out
+            rp = pb[2] if (pb is not None and res_out is pb[0]) else _d(res_out)
         fill = 0
         if out is None:
             out = np.empty(self.total_nnz)
             fill = 1
-        rc = check(lib().gel_eval(self._h, _d(x), _d(res), _d(out), fill))
+        vp = pb[3] if (pb is not None and out is pb[1]) else _d(out)
+        rc = check(lib().gel_eval(self._h, _d(x), rp if rp is not None else _d(res), vp, fill))
         return res, out, rc
 
     def eval_batch(self, X, want_res=True, want_jac=True, out=None):
@@ -394,13 +416,16 @@ class Engine:
         slot = self.__dict__.setdefault("_cb_out", {}).get(key)
         if slot is None:
             io = GelCallbackIO()
-            out = {"res": np.empty(self.nres), "vals": None, "rows_con": None, "rows_jfn": None, "aero_con": {}, "aero_jac": {}}
-            io.res = _d(out["res"])
+            # the handle's own pinned buffers: the kernel writes the residual rows and the all-x-dependent blocks of the value
+            # vector straight into them (gel_pinned_buffers: no host copy of either)
+            pres, pvals = self.pinned_buffers()
+            out = {"res": pres, "vals": None, "rows_con": None, "rows_jfn": None, "aero_con": {}, "aero_jac": {}}
+            io.res = self._pinned[2]
             if want_jac:
                 if self._vals is None:
-                    self._vals = self.const_values()          # constants once; x-dependent entries rewritten per call
+                    self._vals = pvals          # constants in place; x-dependent entries rewritten per call
                 out["vals"] = self._vals
-                io.vals_full, io.fill_constants = _d(self._vals), 0
+                io.vals_full, io.fill_constants = (self._pinned[3] if self._vals is pvals else _d(self._vals)), 0
             if self._nlin + self._nfn:
                 out["rows_con"] = np.empty(self._nlin + self._nfn)
                 io.rows_con = _d(out["rows_con"])

@@ -161,6 +161,13 @@ int gel_eval_batch_device(gel_problem* p, int32_t B, const double* d_x, double* 
 /* materialise every COO value like the reference does: d_jfull [B][total_nnz],
  * from d_jvar [B][V] (compact -> full expansion kernel). */
 int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream);
+/* The handle's own pinned host buffers for the one-vector calls (gel_eval_residual, gel_eval, gel_eval_jacobian,
+ * gel_eval_callback): *res [11N] and *vals_full [total_nnz, the constants already in place].  A caller that passes THESE pointers
+ * as its res / vals_full gets its results without a host copy: the kernel writes the residual rows and every block of the value
+ * vector whose entries are all x-dependent straight to their places (COO-direct output, gelato_amd/csrc/gel_eval_kernel.h), and
+ * the host only scatters the entries that sit alone between constants.  The buffers belong to the handle and are rewritten by the
+ * next such call (the reference returns fresh arrays, lib/con_dynamics.py:108-113; pyoptsparse copies what it is given at once). */
+int gel_pinned_buffers(gel_problem* p, double** res, double** vals_full);
 /* The same result without rewriting the constants (the reference rebuilds every COO value per call,
  * lib/con_dynamics.py:108-111,491-494,627-630): gel_fill_full_device lays the constant template into d_jfull [B][total_nnz]
  * ONCE, gel_update_full_device then writes only the x-dependent entries (4 % of the values at 6 x 64) from d_jvar [B][V] after

@@ -627,7 +627,10 @@ def test_device_pointer_api_and_full_expansion():
     assert np.array_equal(dfull.cpu().numpy(), E.expand(jv))
     # the update-in-place mode: constants laid down once, then only the x-dependent entries per evaluation --
     # the same bits as the full rewrite, also after the buffer has served another batch, for one vector and for a ragged batch
-    for Bu in (1, B, 37):
+    prob_e, x0_e, _ = named_problem("example")      # total_nnz = 20002: not a multiple of 8 -> the entry-wise update kernel
+    E_e, _ = make_pair(prob_e)
+    assert E.total_nnz % 8 == 0 and E_e.total_nnz % 8 != 0
+    for E, x0, Bu in ((E, x0, 1), (E, x0, B), (E, x0, 37), (E_e, x0_e, 3)):
         Xu = problem.synthetic_batch(x0, E.M, Bu, seed=77)
         dXu = torch.from_numpy(Xu).to(dev)
         dr = torch.empty((Bu, E.nres), dtype=torch.float64, device=dev)
@@ -1254,3 +1257,51 @@ def test_packed_unit_shards_with_the_recomputing_form():
     assert E.sync(s) == 0
     res, jv = sh.gather(out)
     assert torch.equal(res, ref_r) and torch.equal(jv, ref_j)
+
+
+# --------------------------------------------------------------------------
+# COO-direct output of the one-vector latency path (gel_pinned_buffers, gel_eval_kernel.h "COO-DIRECT"): the kernel writes the
+# all-x-dependent blocks of the full value vector straight into the handle's pinned array; the rest is scattered by the host
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["example", "3x32", "mixed-6x64", "dense-6x64", "stress-12x128", "ragged", "breaks", "polar"])
+def test_coo_direct_one_vector_output_equals_the_compact_path(name):
+    """Engine.eval into the handle's pinned buffers (zero-copy, COO-direct kernel output), into caller arrays, and through
+    eval_callback, against the compact batch path + the gather map (an independent route: cooperative kernel forms, expand on the
+    host): the same bits -- full chunks (LDS-tile stores), ragged chunks (per-lane stores), phases of several chunks, held and
+    engine-off and NoAir phases, wavefronts with lanes the difference form does not cover (masked first pass + recomputing pass), and
+    the same buffers re-used for another decision vector."""
+    _setup()
+    import states
+    from gelato_amd import Engine, problem
+    if name in ("ragged", "breaks", "polar"):
+        prob, x0 = {"ragged": states.ragged_state, "breaks": lambda: states.with_coast_tail(states.layer_break_state),
+                    "polar": lambda: states.with_coast_tail(states.polar_dense_state)}[name]()
+    else:
+        prob, x0, _ = named_problem(name)
+    E = Engine(prob)
+    pres, pvals = E.pinned_buffers()
+    assert np.array_equal(pvals, E.const_values())            # the constants lie there before the first evaluation
+    X = problem.synthetic_batch(x0, E.M, 3, seed=5)
+    X[2] = x0 * (1.0 + 2e-7)
+    res_b, jv_b, rc_b = E.eval_batch(np.concatenate([X, X, X])[:9])     # nine vectors: a cooperative form, not the latency form
+    full_b = E.expand(jv_b)
+    for b in (0, 1, 2, 0):
+        r, v, rc = E.eval(X[b], out=pvals, res_out=pres)
+        assert rc == 0 and r is pres and v is pvals
+        assert np.array_equal(pres, res_b[b]) and np.array_equal(pvals, full_b[b]), (name, b)
+        r2, v2, rc2 = E.eval(X[b])                              # caller arrays, constants filled
+        assert rc2 == 0 and np.array_equal(r2, res_b[b]) and np.array_equal(v2, full_b[b])
+        v3 = np.full(E.total_nnz, np.nan)
+        v3[~E.var_mask()] = E.const_values()[~E.var_mask()]
+        _, v3b, _ = E.eval(X[b], out=v3)                        # caller array that holds the constants already
+        assert v3b is v3 and np.array_equal(v3, full_b[b])
+        cb = E.eval_callback(X[b], True)
+        assert cb["rc"] == 0 and np.array_equal(cb["res"], res_b[b]) and np.array_equal(cb["vals"], full_b[b])
+        vj, rcj = E.eval_jacobian(X[b], out=pvals)
+        assert rcj == 0 and np.array_equal(vj, full_b[b])
+    # a non-finite input is reported through the pinned route as well, and the next call is clean
+    xb = X[0].copy(); xb[E.M + 4] = np.nan
+    _, _, rc = E.eval(xb, out=pvals, res_out=pres)
+    assert rc == 1 and np.isnan(pres).any()
+    _, _, rc = E.eval(X[1], out=pvals, res_out=pres)
+    assert rc == 0 and np.array_equal(pvals, full_b[1]) and np.array_equal(pres, res_b[1])

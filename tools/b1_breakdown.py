@@ -25,6 +25,11 @@ for workload in sys.argv[1:] or ["example", "mixed-6x64"]:
     _, vals, _ = E.eval(x0)
     out = {"workload": workload}
     out["gel_eval (res + full COO values)"] = bench(lambda: E.eval(x0, out=vals))
+    pres, pvals = E.pinned_buffers()
+    out["gel_eval into the handle's pinned buffers (zero-copy)"] = bench(lambda: E.eval(x0, out=pvals, res_out=pres))
+    assert np.array_equal(pvals, vals) and np.array_equal(pres, E.eval(x0, out=vals)[0])
+    out["gel_eval_callback (defect groups, values + derivatives)"] = bench(lambda: E.eval_callback(x0, True))
+    out["gel_eval_callback (defect groups, values)"] = bench(lambda: E.eval_callback(x0, False))
     out["gel_eval_batch B=1 (res + compact)"] = bench(lambda: E.eval_batch(x0))
     out["gel_eval_residual"] = bench(lambda: E.eval_residual(x0))
     dev = torch.device("cuda:0")
