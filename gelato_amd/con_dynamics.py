@@ -19,7 +19,7 @@ non-finite output -> 1 (the reference hard-codes fail=False).
 """
 import numpy as np
 
-from .engine import BLOCKS, Engine, pack_x
+from .engine import BLOCKS, Engine, _d, pack_x
 
 _KEY = "_gelato_amd"
 
@@ -64,25 +64,37 @@ class _State:
         self._pinned_user = None
         self._pinned_aero = None
         self._jd = None
+        # two persistent packed-x buffers (and their ctypes pointers), used in turn: the one that is not the cached frame's receives
+        # the next decision vector, so the frame's x stays intact for the comparison that decides whether the frame can be reused
+        # (the handle's own pinned buffers where there is a device: the kernel then reads the vector in place)
+        if int(pdict.get("device", 0)) >= 0:
+            self._xb, self._xp = self.engine.pinned_x()
+        else:
+            self._xb = [np.empty(self.engine.nvars), np.empty(self.engine.nvars)]
+            self._xp = [_d(b) for b in self._xb]
 
     def frame(self, xdict, need_jac):
         """All device outputs for `xdict`: the first function of a callback that asks evaluates the four defect groups,
         the knot / terminal / user row table and the aero path constraints -- whatever is configured on the handle -- in
         ONE round trip (gel_eval_callback); the other functions of the callback read their share.  A derivative asked
         for after a values-only frame of the same xdict re-evaluates with derivatives."""
-        if xdict is self._pinned:
-            if self._pinned_x is None:
-                self._pinned_x = pack_x(xdict)
+        fr = self._frame
+        if xdict is self._pinned and self._pinned_x is not None:
             x = self._pinned_x
         else:
-            x = pack_x(xdict)
+            which = 1 if (fr is not None and fr["x"] is self._xb[0]) else 0
+            x = pack_x(xdict, out=self._xb[which])
+            if xdict is self._pinned:
+                self._pinned_x = x
         eng = self.engine
         sig = eng._cfg_gen      # a frame is only valid for the row table / aero specs it was evaluated with
-        fr = self._frame
-        if fr is None or self._frame_sig != sig or (need_jac and not fr["jac"]) or not (fr["x"] is x or np.array_equal(fr["x"], x)):
-            fr = dict(eng.eval_callback(x, need_jac))
+        if (fr is None or self._frame_sig != sig or (need_jac and not fr["jac"])
+                or not (fr["x"] is x or (fr["x"][0] == x[0] and fr["x"][-1] == x[-1] and np.array_equal(fr["x"], x)))):
+            fr = dict(eng.eval_callback(x, need_jac, xptr=self._xp[0] if x is self._xb[0] else self._xp[1]))
             fr["x"], fr["jac"] = x, bool(need_jac)
             self._frame, self._frame_sig = fr, sig
+        elif fr["x"] is not x and xdict is self._pinned:
+            self._pinned_x = fr["x"]      # equal content: keep handing out the frame's own buffer for this callback
         self.status |= fr["rc"]             # also when the cached frame is handed out again
         return fr
 
@@ -161,7 +173,7 @@ def _copy_jac(j, pdict=None):
     # by the next evaluation): pyoptsparse copies what it is given into its own matrices straight away, and the
     # fresh copies of 607 k values are half of a sens() call at 6 x 64.
     if pdict is not None and pdict.get("gelato_amd_share_values"):
-        return {var: {"coo": [blk["coo"][0], blk["coo"][1], blk["coo"][2]], "shape": blk["shape"]} for var, blk in j.items()}
+        return dict(j)      # the block dicts themselves (views of the engine's value array, built once per array)
     return {var: {"coo": [blk["coo"][0], blk["coo"][1], blk["coo"][2].copy()], "shape": blk["shape"]}
             for var, blk in j.items()}
 

@@ -141,12 +141,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // the matrix-pipe forms are only launched when residual rows are asked for (eval_form(): mfma = use_mfma && want_res): knowing
   // that, the compiler drops the `if (rb)` tests of the cooperative forms and the thirty zero-initialisations in front of them
   if (MFMA) __builtin_assume(res != nullptr);
-#ifdef GEL_STAMP  // diagnostic build only (tools/stamp_phases.py): where a wavefront's lifetime goes, in shader cycles
-#define GEL_STAMP_AT(i) do { if ((threadIdx.x & 63) == 0) gel_stamps[(((size_t)vblk * 4 + (threadIdx.x >> 6)) & ((1u << 18) - 1)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define GEL_STAMP_AT(i) do {} while (0)
-#endif
-  GEL_STAMP_AT(0);
   const int park_off = P.park_off;
   // the cooperative forms meet at a barrier (operand image / hand-over) before any table lookup: no barrier of its own
   constexpr bool kSplitStage = MFMA && !SPLIT;   // cooperative forms: table entry requested now, written before their first barrier
@@ -281,8 +275,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // Trajectory_Optimization.py:240,311 hard-code fail = False).
   unsigned long long bad = 0;
 #define GEL_CHK(v) (bad |= __builtin_amdgcn_ballot_w64(!(fabs(v) <= 1.79769313486231570815e308)))
-
-  GEL_STAMP_AT(1);
   // PACKED (split form only, P.shard_width != 0: gel_eval_shard_packed_device): every unit writes ITS entries of a decision
   // vector as one contiguous block -- compact Jacobian slots first ([slot][node of the chunk], only the slots the unit owns),
   // then the phase scalar (first chunk of a phase), then the residual rows mass | position | velocity | quaternion of the
@@ -550,7 +542,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         }
         stage_tables_commit(P, lds, tab_mine);
         __syncthreads();
-        GEL_STAMP_AT(2);
         const int klast = ksteps;
         if (kAAll) {
 #pragma unroll
@@ -585,7 +576,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
           }
         }
         GEL_DX_TAIL_ACC(regions[xoff[ct] + (n - kq) * 11]);   // row n of this lane's column (xoff points at row kq)
-        GEL_STAMP_AT(3);
         {
           // the node's own state row comes from the same image (after the product: nothing of it is live across the loop)
           lds_double* src = wave_lds + (half * kPackRows + jc + 1) * 11;
@@ -619,7 +609,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
           }
         }
         __syncthreads();
-        GEL_STAMP_AT(4);
         if (ghost) return;
         lds_double* row = wave_lds + kHO + lane * 11;
         lm = row[0];
@@ -1011,7 +1000,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
       }
     }
   }
-  GEL_STAMP_AT(5);
   // ======================= from here on: no global loads =======================
   // compiler barrier: parked values are re-read from LDS below, not forwarded through VGPRs
   asm volatile("" ::: "memory");
@@ -1207,7 +1195,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #undef GEL_TDC
 #undef GEL_T
       }
-      GEL_STAMP_AT(6);
       // position sweeps (lib/con_dynamics.py:381-400); SPLIT: this wavefront's one
       if (JAC && (!SPLIT || part)) {
         const int k0 = SPLIT ? part - 1 : 0, k1 = SPLIT ? part : 3;
@@ -1425,7 +1412,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #undef GEL_TAKE_KNOT_TIMES
 #undef PARK_GET
 #undef PARK_SET
-  GEL_STAMP_AT(7);
   if (bad) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 

@@ -174,6 +174,7 @@ struct gel_problem {
   int32_t* d_coo = nullptr;
   double* h_full = nullptr;
   double* cb_res = nullptr;       // pinned residual vector a caller may name as its own output (gel_pinned_buffers): no copy then
+  double* cb_x[2] = {nullptr, nullptr};   // two pinned decision-vector buffers a caller may fill in turn and pass as x: read in place
   int32_t* d_flag = nullptr;
   // B = 1 / small-batch working set
   int capB = 0;
@@ -405,6 +406,7 @@ int ensure_full(gel_problem* p) {
   HIPCHK(hipHostMalloc((void**)&p->h_full, std::max<size_t>(1, p->cval.size()) * 8));
   std::memcpy(p->h_full, p->cval.data(), p->cval.size() * 8);
   HIPCHK(hipHostMalloc((void**)&p->cb_res, (size_t)11 * p->dims.N * 8));
+  for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void**)&p->cb_x[i], (size_t)p->dims.num_vars * 8));
   return GEL_OK;
 }
 // GEL_NO_COO_DIRECT=1 (measurement switch): the compact layout + the host scatter of every x-dependent entry, as before round 5
@@ -441,7 +443,10 @@ int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_ja
   if (rc) return rc;
   HIPCHK(hipSetDevice(p->device));
   const size_t nx = (size_t)B * p->dims.num_vars, nr = (size_t)B * 11 * p->dims.N, nj = (size_t)B * p->dims.num_var_entries;
-  std::memcpy(p->h_x, x, nx * 8);
+  // a one-vector call whose x IS one of the handle's pinned decision-vector buffers (gel_pinned_buffers) is read in place
+  const bool x_pinned = B == 1 && p->cb_x[0] && (x == p->cb_x[0] || x == p->cb_x[1]);
+  if (!x_pinned) std::memcpy(p->h_x, x, nx * 8);
+  const double* const xin = x_pinned ? x : p->h_x;
   if ((nx + (want_res ? nr : 0) + (want_jac ? nj : 0)) * 8 <= kZeroCopyBytes) {
     // Small calls (the optimiser's one-vector callbacks): the kernel reads x from and writes its results
     // to the pinned staging buffers itself -- one launch and one synchronise instead of launch + four
@@ -450,12 +455,12 @@ int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_ja
     gel::ProblemDev dv = p->dev;
     dv.flag = p->h_flag;
     if (coo && B == 1 && want_jac) { dv.coo_full = p->h_full; dv.coo = p->d_coo; *coo_io = true; }
-    HIPCHK(gel::launch_eval(dv, B, p->h_x, want_res ? (res_to ? res_to : p->h_res) : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
+    HIPCHK(gel::launch_eval(dv, B, xin, want_res ? (res_to ? res_to : p->h_res) : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
     HIPCHK(spin_wait(p->stream));
     if (*p->h_flag) { *p->h_flag = 0; return GEL_NONFINITE; }
     return GEL_OK;
   }
-  HIPCHK(hipMemcpyAsync(p->d_x, p->h_x, nx * 8, hipMemcpyHostToDevice, p->stream));
+  HIPCHK(hipMemcpyAsync(p->d_x, xin, nx * 8, hipMemcpyHostToDevice, p->stream));
   HIPCHK(gel::launch_eval(p->dev, B, p->d_x, want_res ? p->d_res : nullptr, want_jac ? p->d_jv : nullptr, p->stream));
   if (want_res) HIPCHK(hipMemcpyAsync(p->h_res, p->d_res, nr * 8, hipMemcpyDeviceToHost, p->stream));
   if (want_jac && nj) HIPCHK(hipMemcpyAsync(p->h_jv, p->d_jv, nj * 8, hipMemcpyDeviceToHost, p->stream));
@@ -1001,6 +1006,7 @@ int gel_problem_destroy(gel_problem* p) {
   hipFree(p->d_vdst); hipFree(p->d_vsrc); hipFree(p->d_vline); hipFree(p->d_coo);
   if (p->h_full) hipHostFree(p->h_full);
   if (p->cb_res) hipHostFree(p->cb_res);
+  for (int i = 0; i < 2; i++) if (p->cb_x[i]) hipHostFree(p->cb_x[i]);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag); hipFree(p->d_unit_base); hipFree(p->d_shard_pos);
   hipFree(p->d_aero_nodes); hipFree(p->d_aero_x); hipFree(p->d_aero_out);
   free_slots(p);
@@ -1071,12 +1077,14 @@ int gel_full_source(const gel_problem* p, int32_t* src) {
   return GEL_OK;
 }
 
-int gel_pinned_buffers(gel_problem* p, double** res, double** vals_full) {
+int gel_pinned_buffers(gel_problem* p, double** res, double** vals_full, double** x0, double** x1) {
   if (!p) return fail(GEL_ERR_ARG, "null argument");
   NEED_DEVICE(p);
   if (int rc = ensure_full(p)) return rc;
   if (res) *res = p->cb_res;
   if (vals_full) *vals_full = p->h_full;
+  if (x0) *x0 = p->cb_x[0];
+  if (x1) *x1 = p->cb_x[1];
   return GEL_OK;
 }
 
@@ -1847,7 +1855,9 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
   }
   if (rows && (rc = grow(&p->h_rows, &p->h_rows_cap, R + 7 * nfn + 1, true))) return rc;
   if (aero && (rc = grow(&p->h_aero, &p->h_aero_cap, atotal, true))) return rc;
-  std::memcpy(p->h_x, x, (size_t)p->dims.num_vars * 8);
+  const bool x_pinned = p->cb_x[0] && (x == p->cb_x[0] || x == p->cb_x[1]);
+  if (!x_pinned) std::memcpy(p->h_x, x, (size_t)p->dims.num_vars * 8);
+  const double* const xin = x_pinned ? x : p->h_x;
   // everything reads x from and writes to pinned host memory: no copy commands
   gel::ProblemDev dv = p->dev;
   dv.flag = p->h_flag;
@@ -1871,13 +1881,13 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
   // GEL_CB_MODE=3 (measurement switch): the three launches of rounds 1-2, back to back on the handle's stream
   static const int cb_mode = [] { const char* e = getenv("GEL_CB_MODE"); return e ? atoi(e) : 0; }();
   if (cb_mode == 3 || !fused) {
-    if (fused) HIPCHK(gel::launch_eval(dv, 1, p->h_x, res_to, want_jac ? p->h_jv : nullptr, p->stream));
-    if (rows) HIPCHK(gel::launch_rows(dv, (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, 1, p->h_x, p->h_rows,
+    if (fused) HIPCHK(gel::launch_eval(dv, 1, xin, res_to, want_jac ? p->h_jv : nullptr, p->stream));
+    if (rows) HIPCHK(gel::launch_rows(dv, (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, 1, xin, p->h_rows,
                                       io->rows_jfn ? p->h_rows + R : nullptr, p->stream));
-    if (aero) HIPCHK(gel::launch_aero(dv, (int)p->aero_nodes.size(), p->d_aero_nodes, 1, p->h_x, out, p->stream));
+    if (aero) HIPCHK(gel::launch_aero(dv, (int)p->aero_nodes.size(), p->d_aero_nodes, 1, xin, out, p->stream));
   } else {
     // ONE launch: defect groups, aero kinds and row table as workgroup ranges of one grid (gel_kernels.hip callback_kernel)
-    HIPCHK(gel::launch_callback(dv, want_jac, p->h_x, res_to, want_jac ? p->h_jv : nullptr,
+    HIPCHK(gel::launch_callback(dv, want_jac, xin, res_to, want_jac ? p->h_jv : nullptr,
                                 aero ? (int)p->aero_nodes.size() : 0, p->d_aero_nodes, aero ? &out : nullptr,
                                 (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, rows ? p->h_rows : nullptr,
                                 (rows && io->rows_jfn) ? p->h_rows + R : nullptr, p->stream));

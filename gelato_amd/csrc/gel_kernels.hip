@@ -65,9 +65,6 @@ GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds, bool sync = true) 
   return table_view(lds, P.Kw, P.Kc);
 }
 
-#ifdef GEL_STAMP
-__device__ unsigned long long gel_stamps[(1u << 18) * 8];
-#endif
 }  // namespace gel
 #include "gel_eval_kernel.h"
 namespace gel {
@@ -1337,9 +1334,3 @@ hipError_t launch_point(int kind, int n, const double* in, const double* aux, in
 
 }  // namespace gel
 
-#ifdef GEL_STAMP
-// diagnostic build only: the s_memtime stamps of the last fused launches (see GEL_STAMP_AT in gel_eval_kernel.h)
-extern "C" int gel_debug_stamps(unsigned long long* out, size_t count) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gel::gel_stamps), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
-}
-#endif

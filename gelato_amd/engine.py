@@ -32,9 +32,9 @@ def _d(a):
     return a.ctypes.data_as(_dp)
 
 
-def pack_x(xdict):
-    """xdict (reference layout, Trajectory_Optimization.py:318-352) -> packed decision vector."""
-    return np.concatenate([np.asarray(xdict[k], dtype=np.float64).ravel() for k in XKEYS])
+def pack_x(xdict, out=None):
+    """xdict (reference layout, Trajectory_Optimization.py:318-352) -> packed decision vector (into `out` if given)."""
+    return np.concatenate([np.asarray(xdict[k], dtype=np.float64).ravel() for k in XKEYS], out=out)
 
 
 class Engine:
@@ -194,13 +194,20 @@ class Engine:
         They belong to the engine and are rewritten by its next one-vector call."""
         pb = self.__dict__.get("_pinned")
         if pb is None:
-            r, v = C.c_void_p(), C.c_void_p()
-            check(lib().gel_pinned_buffers(self._h, C.byref(r), C.byref(v)))
+            r, v, x0, x1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            check(lib().gel_pinned_buffers(self._h, C.byref(r), C.byref(v), C.byref(x0), C.byref(x1)))
             dp = C.POINTER(C.c_double)
             res = np.ctypeslib.as_array(C.cast(r, dp), shape=(self.nres,))
             vals = np.ctypeslib.as_array(C.cast(v, dp), shape=(max(self.total_nnz, 1),))[:self.total_nnz]
-            pb = self._pinned = (res, vals, _d(res), _d(vals))
+            xb = [np.ctypeslib.as_array(C.cast(q, dp), shape=(self.nvars,)) for q in (x0, x1)]
+            pb = self._pinned = (res, vals, _d(res), _d(vals), xb, [_d(b) for b in xb])
         return pb[0], pb[1]
+
+    def pinned_x(self):
+        """-> ([x0, x1], [their ctypes pointers]): two pinned decision-vector buffers of the handle; a one-vector call whose x is
+        one of them (eval_callback(x, .., xptr=pointer)) reads it in place instead of copying it into the staging buffer"""
+        self.pinned_buffers()
+        return self._pinned[4], self._pinned[5]
 
     def eval(self, x, out=None, res_out=None):
         """-> (res, vals_full, status).  out / res_out: arrays to write into (the engine's pinned_buffers() make it zero-copy)."""
@@ -405,13 +412,15 @@ class Engine:
         jp = (C.c_void_p * 3)(*[p or None for p in d_jac]) if d_jac is not None else None
         check(lib().gel_eval_aero_all_device(self._h, B, d_x, cp, jp, stream or None))
 
-    def eval_callback(self, x, want_jac):
+    def eval_callback(self, x, want_jac, xptr=None):
         """ONE device round trip for one decision vector: the four defect groups, the row table (if configured) and the aero
         kinds (if configured), values only or values + derivatives.  -> dict of the engine's own output arrays (overwritten
         by the next call): res, vals (full COO values) | None, rows_con, rows_jfn | None, aero_con {kind}, aero_jac {kind} |
         None, rc."""
-        x = _f64(x)
-        assert x.size == self.nvars
+        if xptr is None:      # xptr: the caller's cached pointer to x (a persistent, contiguous float64 buffer of nvars doubles)
+            x = _f64(x)
+            assert x.size == self.nvars
+            xptr = _d(x)
         key = bool(want_jac)
         slot = self.__dict__.setdefault("_cb_out", {}).get(key)
         if slot is None:
@@ -443,7 +452,7 @@ class Engine:
             slot = (io, out)
             self._cb_out[key] = slot
         io, out = slot
-        out["rc"] = check(lib().gel_eval_callback(self._h, _d(x), C.byref(io)))
+        out["rc"] = check(lib().gel_eval_callback(self._h, xptr, C.byref(io)))
         if out["rows_jfn"] is not None:
             out["rows_jfn"] = out["rows_jfn"][:self._nfn]
         return out

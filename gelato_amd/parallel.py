@@ -74,10 +74,16 @@ class UnitShards:
     (pos = rank * width + offset); `gather` reads a finished buffer through them, Engine.shard_unpack_device does it in one
     launch on the device."""
 
-    def __init__(self, engine, world, rank):
+    def __init__(self, engine, world, rank, unit_begin=None):
+        """unit_begin [world + 1] (optional): the caller's own contiguous unit ranges instead of the cost-balanced cut"""
         self.world, self.rank = int(world), int(rank)
-        self.ranges = shard_chunks(unit_costs(engine), world)
-        self.unit_begin = np.array([r[0] for r in self.ranges] + [self.ranges[-1][0] + self.ranges[-1][1]], dtype=np.int32)
+        if unit_begin is None:
+            self.ranges = shard_chunks(unit_costs(engine), world)
+            self.unit_begin = np.array([r[0] for r in self.ranges] + [self.ranges[-1][0] + self.ranges[-1][1]], dtype=np.int32)
+        else:
+            self.unit_begin = np.ascontiguousarray(unit_begin, dtype=np.int32)
+            assert len(self.unit_begin) == self.world + 1
+            self.ranges = [(int(self.unit_begin[r]), int(self.unit_begin[r + 1] - self.unit_begin[r])) for r in range(self.world)]
         self.engine = engine
         import os
         self.inplace = os.environ.get("GELATO_AMD_ALLGATHER_COPY", "0") in ("", "0")

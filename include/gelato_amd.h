@@ -166,8 +166,10 @@ int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, doub
  * as its res / vals_full gets its results without a host copy: the kernel writes the residual rows and every block of the value
  * vector whose entries are all x-dependent straight to their places (COO-direct output, gelato_amd/csrc/gel_eval_kernel.h), and
  * the host only scatters the entries that sit alone between constants.  The buffers belong to the handle and are rewritten by the
- * next such call (the reference returns fresh arrays, lib/con_dynamics.py:108-113; pyoptsparse copies what it is given at once). */
-int gel_pinned_buffers(gel_problem* p, double** res, double** vals_full);
+ * next such call (the reference returns fresh arrays, lib/con_dynamics.py:108-113; pyoptsparse copies what it is given at once).
+ * *x0, *x1 [num_vars]: two pinned decision-vector buffers; a one-vector call whose x is one of them reads it in place (two, so that a
+ * caller can keep the previous vector for comparison while it fills the next).  Any of the four out-pointers may be NULL. */
+int gel_pinned_buffers(gel_problem* p, double** res, double** vals_full, double** x0, double** x1);
 /* The same result without rewriting the constants (the reference rebuilds every COO value per call,
  * lib/con_dynamics.py:108-111,491-494,627-630): gel_fill_full_device lays the constant template into d_jfull [B][total_nnz]
  * ONCE, gel_update_full_device then writes only the x-dependent entries (4 % of the values at 6 x 64) from d_jvar [B][V] after

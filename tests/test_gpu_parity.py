@@ -1299,6 +1299,14 @@ def test_coo_direct_one_vector_output_equals_the_compact_path(name):
         assert cb["rc"] == 0 and np.array_equal(cb["res"], res_b[b]) and np.array_equal(cb["vals"], full_b[b])
         vj, rcj = E.eval_jacobian(X[b], out=pvals)
         assert rcj == 0 and np.array_equal(vj, full_b[b])
+    # the decision vector itself in one of the handle's pinned buffers: read in place (the two buffers in turn)
+    xb, xp = E.pinned_x()
+    for k, b in enumerate((1, 2, 0)):
+        np.copyto(xb[k & 1], X[b])
+        cb = E.eval_callback(xb[k & 1], True, xptr=xp[k & 1])
+        assert cb["rc"] == 0 and np.array_equal(cb["res"], res_b[b]) and np.array_equal(cb["vals"], full_b[b])
+        r, v, rc = E.eval(xb[k & 1], out=pvals, res_out=pres)
+        assert rc == 0 and np.array_equal(r, res_b[b]) and np.array_equal(v, full_b[b])
     # a non-finite input is reported through the pinned route as well, and the next call is clean
     xb = X[0].copy(); xb[E.M + 4] = np.nan
     _, _, rc = E.eval(xb, out=pvals, res_out=pres)

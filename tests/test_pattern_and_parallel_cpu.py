@@ -170,9 +170,7 @@ if {empty_rank} >= 0:
     ub = sh.unit_begin.copy()
     ub[{empty_rank} + 1:-1] = np.maximum(ub[{empty_rank} + 1:-1], ub[{empty_rank}])
     ub[{empty_rank} + 1] = ub[{empty_rank}]
-    sh.ranges = [(int(ub[r]), int(ub[r + 1] - ub[r])) for r in range(world)]
-    sh.unit_begin = ub
-    sh.width, sh.res_pos, sh.jv_pos = E.shard_plan(ub)
+    sh = parallel.UnitShards(E, world, rank, unit_begin=ub)      # a new plan on the handle: a new object (the old one is stale now)
     assert sh.ranges[{empty_rank}][1] == 0
 # the plan agrees with the ownership table: an entry lies in the slice of the rank that holds its unit, and the entries of
 # one unit form one contiguous run

@@ -21,6 +21,13 @@ class Stub:
     def __getattr__(self, name):
         if name == "gel_eval_callback":
             return lambda *a: 0
+        if name == "gel_pinned_buffers":      # a host-only handle has no pinned buffers: plain arrays stand in
+            def pinned(h, r, v, x0, x1):
+                self.__dict__["_keep"] = (np.zeros(E.nres), np.zeros(max(E.total_nnz, 1)), np.zeros(E.nvars), np.zeros(E.nvars))
+                for q, a in zip((r, v, x0, x1), self._keep):
+                    q._obj.value = a.ctypes.data
+                return 0
+            return pinned
         return getattr(real, name)
 
 
