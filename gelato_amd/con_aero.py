@@ -83,16 +83,19 @@ def _jacobian(xdict, pdict, unitdict, condition, kind):
         return None
     eng = st.engine
     pats = st.__dict__.setdefault("aero_pattern", {})
-    if kind not in pats:
-        pats[kind] = eng.aero_pattern(kind)
-    nrow, nnz = eng.aero_dims(kind)
-    shapes = [(nrow, pdict["M"] * 3), (nrow, pdict["M"] * 3), (nrow, pdict["M"] * 4),
-              (nrow, pdict["num_sections"] + 1)]
-    jac, off = {}, 0
+    meta = pats.get(kind)
+    if meta is None:      # pattern, value offsets and shapes of the kind's four blocks: once per configuration (three C calls otherwise)
+        nrow, nnz = eng.aero_dims(kind)
+        shapes = [(nrow, pdict["M"] * 3), (nrow, pdict["M"] * 3), (nrow, pdict["M"] * 4), (nrow, pdict["num_sections"] + 1)]
+        offs = np.concatenate([[0], np.cumsum(nnz)]).astype(int)
+        meta = pats[kind] = (eng.aero_pattern(kind), [(int(offs[v]), int(offs[v + 1])) for v in range(4)], shapes)
+    pat, offs, shapes = meta
+    share = pdict.get("gelato_amd_share_values")      # the engine's own value array (rewritten by the next evaluation) instead of copies
+    vals = jv[kind]
+    jac = {}
     for v, var in enumerate(eng.AERO_VARS):
-        r, c = pats[kind][v]
-        jac[var] = {"coo": [r, c, jv[kind][off:off + nnz[v]].copy()], "shape": shapes[v]}
-        off += nnz[v]
+        a, b = offs[v]
+        jac[var] = {"coo": [pat[v][0], pat[v][1], vals[a:b] if share else vals[a:b].copy()], "shape": shapes[v]}
     return jac
 
 

@@ -106,6 +106,7 @@ struct ProblemDev {
   // and, per phase, the first entry of the eight groups of runs in it; null: the compact layout
   double* coo_full;
   const int32_t* coo;   // [8 * S]
+  int32_t split_vel;    // latency form, whole evaluations only: velocity sweep k runs in the wavefront of position sweep k
 };
 
 }  // namespace gel

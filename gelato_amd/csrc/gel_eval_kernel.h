@@ -1133,14 +1133,19 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
           asm volatile("" ::: "memory");
           PARK_SET(PK_LV0, pp.shp); PARK_SET(PK_LV1, pp.chp); PARK_SET(PK_LV2, pp.inv_p);
         }
-        if (JAC && lead) {
+        if (JAC && lead && !P.fd_recompute) GEL_MASS_CLOSED(tm);   // first: (T d + F) / m dies here
+        // velocity sweeps: only the aerodynamic force changes.  Latency form of a WHOLE evaluation (P.split_vel: the optimiser's
+        // callback): the wavefront of position sweep k takes velocity sweep k too -- it has formed the centre's wind, force and
+        // thrust anyway -- so the lead wavefront, the longest chain of the launch, is three aerodynamic-force evaluations shorter
+        // (same operations on the same operands: the same bits).  Unit-sharded launches keep them with the lead, which owns
+        // their slots (gel_unit_owner).
+        if (JAC && ph.air_fd && (SPLIT && P.split_vel ? !lead : lead)) {
           double f[3];
-          if (!P.fd_recompute) GEL_MASS_CLOSED(tm);   // first: (T d + F) / m dies here
-          // velocity sweeps: only the aerodynamic force changes
-          if (ph.air_fd) {
+          {
             const double djj = PARK_GET(PK_DJJ);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
+              if (SPLIT && P.split_vel && k != part - 1) continue;   // wave-uniform
               double vp[3], Fp[3];
 #pragma unroll
               for (int c = 0; c < 3; c++) vp[c] = ((k == c) ? (PARK_GET(PK_V0 + c) + dx) : PARK_GET(PK_V0 + c)) * P.uv;
@@ -1153,6 +1158,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
               for (int c = 0; c < 3; c++) EMIT(ph.s_vv + 3 * k + c, ((c == k) ? djj : 0.0) + FDQ(f[c], fc[c]));
             }
           }
+        }
+        if (JAC && lead) {
+          double f[3];
           // quaternion sweeps: only the thrust direction changes; mass sweep: only the division by mass
           if (!P.fd_recompute) {
             GEL_QUAT_CLOSED(GEL_T);

@@ -455,6 +455,7 @@ int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_ja
     gel::ProblemDev dv = p->dev;
     dv.flag = p->h_flag;
     if (coo && B == 1 && want_jac) { dv.coo_full = p->h_full; dv.coo = p->d_coo; *coo_io = true; }
+    dv.split_vel = 1;   // a whole evaluation: every part of every work item is in this launch
     HIPCHK(gel::launch_eval(dv, B, xin, want_res ? (res_to ? res_to : p->h_res) : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
     HIPCHK(spin_wait(p->stream));
     if (*p->h_flag) { *p->h_flag = 0; return GEL_NONFINITE; }
@@ -1868,6 +1869,7 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
     if ((rc = ensure_full(p))) return rc;
     dv.coo_full = p->h_full; dv.coo = p->d_coo;
   }
+  dv.split_vel = 1;   // a whole evaluation: every part of every work item is in this launch
   const bool own_res = io->res && p->cb_res && io->res == p->cb_res;
   double* const res_to = own_res ? p->cb_res : p->h_res;
   gel::AeroLaunchOut out;
