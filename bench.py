@@ -549,6 +549,20 @@ def main():
         dt = time.perf_counter() - t0
         out["host_batch_pcie_inclusive"] = {"batch": Bh, "evals_per_s": Bh / dt, "ms": 1e3 * dt,
                                             "bytes_moved": Bh * E.algorithmic_bytes}
+        try:   # the same with page-locked caller buffers (torch pin_memory): the copy engines use them directly, no staging copies
+            Bp = min(B, 2048)
+            xp = torch.from_numpy(X[:Bp]).pin_memory()
+            rp = torch.empty((Bp, E.nres), dtype=torch.float64).pin_memory()
+            jp = torch.empty((Bp, E.V), dtype=torch.float64).pin_memory()
+            E.eval_batch(xp.numpy(), out=(rp.numpy(), jp.numpy()))
+            t0 = time.perf_counter()
+            E.eval_batch(xp.numpy(), out=(rp.numpy(), jp.numpy()))
+            dtp = time.perf_counter() - t0
+            out["host_batch_pcie_inclusive"].update({"pinned_caller_buffers": {"batch": Bp, "evals_per_s": Bp / dtp, "ms": 1e3 * dtp,
+                                                                                "GBps_over_pcie": Bp * 8 * (E.nvars + E.nres + E.V) / dtp / 1e9}})
+            del xp, rp, jp
+        except Exception as ex:  # noqa: BLE001
+            out["host_batch_pcie_inclusive"]["pinned_caller_buffers"] = {"error": str(ex)[:200]}
 
         # informational: generic column-batched forward difference (lib/jac_fd.py): dense
         # d(eqcon_dyn_vel)/dx over all columns = num_vars + 1 residual evaluations in one launch, host arrays out

@@ -19,30 +19,38 @@ from .engine import pack_x
 _KINDS = {"alpha": "AOA_max", "q": "dynamic_pressure_max", "qalpha": "Q_alpha_max"}
 
 
-def _spec(pdict, condition, kind):
-    cond = condition.get(_KINDS[kind], {}) or {}
+_DEG = np.pi / 180.0
+
+
+def _spec_key(pdict, condition, kind):
+    """the kind's constraint table as a tuple of (section, range_all, limit) rows -- plain Python, compared per callback"""
+    cond = condition.get(_KINDS[kind]) or {}
+    if not cond:
+        return ()
     rows = []
+    params = pdict["params"]
     for i in range(pdict["num_sections"] - 1):                      # con_aero.py:108
-        name = pdict["params"][i]["name"]
-        if name in cond:
-            c = cond[name]
-            if c["range"] not in ("all", "initial"):
-                continue
-            limit = c["value"] * np.pi / 180.0 if kind in ("alpha", "qalpha") else c["value"]   # :119,232,173
-            rows.append((i, 1 if c["range"] == "all" else 0, float(limit)))
-    return np.array(rows, dtype=np.float64).reshape(-1, 3)
+        c = cond.get(params[i]["name"])
+        if c is None or c["range"] not in ("all", "initial"):
+            continue
+        limit = c["value"] * _DEG if kind != "q" else c["value"]     # :119,232,173
+        rows.append((i, 1 if c["range"] == "all" else 0, float(limit)))
+    return tuple(rows)
+
+
+def _spec(pdict, condition, kind):
+    return np.array(_spec_key(pdict, condition, kind), dtype=np.float64).reshape(-1, 3)
 
 
 def _configured(pdict, unitdict, condition, kind):
     st = con_dynamics._state(pdict, unitdict)
-    spec = _spec(pdict, condition, kind)
-    key = spec.tobytes()
+    key = _spec_key(pdict, condition, kind)
     cache = st.__dict__.setdefault("aero_spec", {})
     if cache.get(kind) != key:
-        st.engine.aero_configure(kind, spec)
+        st.engine.aero_configure(kind, np.array(key, dtype=np.float64).reshape(-1, 3))
         cache[kind] = key
         st.__dict__.setdefault("aero_pattern", {}).pop(kind, None)
-    return st, len(spec)
+    return st, len(key)
 
 
 def _configure_all(pdict, unitdict, condition):

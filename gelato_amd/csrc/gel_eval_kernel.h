@@ -313,7 +313,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     if (!rb) GEL_CHK(_v);                                                                 \
   } while (0)
 #define EMIT(slot, val) EMIT_AT(((int)(slot) - (SPLIT ? (((int)(slot) >= kSlotVP) ? sub_hi : sub_lo) : 0)) * cw8, val)
-#define RSTORE(idx, val) rb[idx] = (val)
+// (latency form: the rows go to pinned host memory -- streamed, so that they cross PCIe while the wavefront computes on instead of
+// waiting in L2 for the end of the kernel; throughput form: the strided rows' partial lines want to meet in L2 first)
+#define RSTORE(idx, val) do { if (SPLIT) __builtin_nontemporal_store((val), rb + (idx)); else rb[idx] = (val); } while (0)
   // Residual rows as CONTIGUOUS stores.  The reference's layout is node-major ([node][x y z], [node][w x y z]): written lane =
   // node, a store instruction puts 8 bytes every 24 / 32 bytes -- 24 / 32 partial 64-byte write requests per instruction, three or
   // four instructions per line.  A full 64-node chunk instead turns its w values per node through an LDS tile (node-major in,
@@ -381,9 +383,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         const int e_ = 64 * i_ + lane;                                                                                 \
         const double v_ = t_[e_];                                                                                      \
         const int ln_ = ((W) == 4) ? (e_ >> 2) : ((e_ * 171) >> 9);   /* the lane (node) that owns entry e_ */          \
-        if ((okm_ >> ln_) & 1ull) {                                                                                    \
-          d_[e_] = v_;                                                                                                 \
-          if (twin_) d_[e_ + (W) * n] = -v_;                                                                           \
+        if ((okm_ >> ln_) & 1ull) {   /* streamed: on its way over PCIe while the wavefront computes on */                \
+          __builtin_nontemporal_store(v_, d_ + e_);                                                                    \
+          if (twin_) __builtin_nontemporal_store(-v_, d_ + e_ + (W) * n);                                              \
         }                                                                                                              \
       }                                                                                                                \
     } else if (okl_) {   /* ragged chunk (lanes past the phase have left): every lane writes its own W entries */      \

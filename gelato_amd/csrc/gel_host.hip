@@ -390,9 +390,13 @@ int ensure_capacity(gel_problem* p, int B) {
   return GEL_OK;
 }
 
-// Wait for a short launch by polling: hipStreamSynchronize() sleeps on an interrupt and returns ~5 us after the kernel has
-// ended; on the one-vector latency path (tens of microseconds in all) the host spins instead.
+// Wait for a short launch.  Round 5, measured on the one-vector path (three resident processes taking turns, same box): polling
+// hipStreamQuery 39.1 us per Engine.eval, hipStreamSynchronize 37.3 us, the same after hipSetDeviceFlags(hipDeviceScheduleSpin) 37.0 us
+// -- this runtime's synchronise spins on the completion signal itself before it sleeps, and a query is a full API call per poll
+// (rounds 1-4 measured the opposite on an earlier runtime and polled).  GEL_WAIT_MODE=0 restores the polling loop (measurement switch).
 static hipError_t spin_wait(hipStream_t s) {
+  static const int mode = [] { const char* e = getenv("GEL_WAIT_MODE"); return e ? atoi(e) : 1; }();
+  if (mode) return hipStreamSynchronize(s);
   hipError_t q;
   while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
   return q;
@@ -535,10 +539,22 @@ void free_slots(gel_problem* p) {
 
 // B evals from / to pageable host arrays in sub-batches: while sub-batch i runs (H2D, kernel, D2H on its
 // slot's stream), the host retires sub-batch i-1 of the other slot (pinned -> caller) and stages i+1.
+// Is this host pointer page-locked memory the runtime knows (hipHostMalloc / hipHostRegister, e.g. a torch tensor made with
+// pin_memory = True)?  Then the copy engines read and write it directly and the staging copy through the handle's slots is skipped.
+static bool is_pinned(const void* ptr) {
+  if (!ptr) return false;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+
 int run_host_pipelined(gel_problem* p, int B, const double* x, double* res, double* jvar) {
   int rc = ensure_slots(p);
   if (rc) return rc;
   HIPCHK(hipSetDevice(p->device));
+  // page-locked caller buffers (all that are given): no staging copies on the host at all -- H2D straight from x, D2H straight into
+  // res / jvar, sub-batch by sub-batch on the two slots' streams; the host only waits
+  const bool direct = is_pinned(x) && (!res || is_pinned(res)) && (!jvar || is_pinned(jvar));
   const int cap = p->pipe_evals;
   const size_t nv = (size_t)p->dims.num_vars, nr = (size_t)11 * p->dims.N, nj = (size_t)p->dims.num_var_entries;
   const int nsub = (B + cap - 1) / cap;
@@ -551,8 +567,10 @@ int run_host_pipelined(gel_problem* p, int B, const double* x, double* res, doub
       HIPCHK(hipMemsetAsync(sl.d_flag, 0, 4, sl.stream));
       status = GEL_NONFINITE;
     }
-    if (sl.res) par_copy(res + (size_t)sl.first * nr, sl.h_res, (size_t)sl.count * nr * 8);
-    if (sl.jac && nj) par_copy(jvar + (size_t)sl.first * nj, sl.h_jv, (size_t)sl.count * nj * 8);
+    if (!direct) {
+      if (sl.res) par_copy(res + (size_t)sl.first * nr, sl.h_res, (size_t)sl.count * nr * 8);
+      if (sl.jac && nj) par_copy(jvar + (size_t)sl.first * nj, sl.h_jv, (size_t)sl.count * nj * 8);
+    }
     sl.count = 0;
     return GEL_OK;
   };
@@ -561,14 +579,17 @@ int run_host_pipelined(gel_problem* p, int B, const double* x, double* res, doub
     if ((rc = retire(sl))) break;
     const int64_t first = (int64_t)i * cap;
     const int count = (int)std::min<int64_t>(cap, B - first);
-    par_copy(sl.h_x, x + (size_t)first * nv, (size_t)count * nv * 8);
+    if (!direct) par_copy(sl.h_x, x + (size_t)first * nv, (size_t)count * nv * 8);
     sl.first = first; sl.count = count; sl.res = res != nullptr; sl.jac = jvar != nullptr;
     gel::ProblemDev dv = p->dev;
     dv.flag = sl.d_flag;
-    if (hipMemcpyAsync(sl.d_x, sl.h_x, (size_t)count * nv * 8, hipMemcpyHostToDevice, sl.stream) != hipSuccess ||
+    const double* const hx = direct ? x + (size_t)first * nv : sl.h_x;
+    double* const hres = direct ? res + (size_t)first * nr : sl.h_res;
+    double* const hjv = direct ? jvar + (size_t)first * nj : sl.h_jv;
+    if (hipMemcpyAsync(sl.d_x, hx, (size_t)count * nv * 8, hipMemcpyHostToDevice, sl.stream) != hipSuccess ||
         gel::launch_eval(dv, count, sl.d_x, res ? sl.d_res : nullptr, jvar ? sl.d_jv : nullptr, sl.stream) != hipSuccess ||
-        (res && hipMemcpyAsync(sl.h_res, sl.d_res, (size_t)count * nr * 8, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) ||
-        (jvar && nj && hipMemcpyAsync(sl.h_jv, sl.d_jv, (size_t)count * nj * 8, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) ||
+        (res && hipMemcpyAsync(hres, sl.d_res, (size_t)count * nr * 8, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) ||
+        (jvar && nj && hipMemcpyAsync(hjv, sl.d_jv, (size_t)count * nj * 8, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) ||
         hipMemcpyAsync(sl.h_flag, sl.d_flag, 4, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) {
       rc = fail(GEL_ERR_HIP, "pipelined batch: enqueue failed");
       break;

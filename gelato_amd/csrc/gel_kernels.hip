@@ -545,7 +545,8 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       }
       if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
       const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
-      O.con[kind][(size_t)b * O.nrows[kind] + row] = cv;
+      if (ROLES) __builtin_nontemporal_store(cv, O.con[kind] + (size_t)b * O.nrows[kind] + row);
+      else O.con[kind][(size_t)b * O.nrows[kind] + row] = cv;
       chk += cv;
     }
     ipark[11 * 64] = centre_ok ? 1 : 0;
@@ -585,7 +586,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       const double gv = (zero) ? 0.0 : -(df_ * AP_GET(AP_ILIM + kind)) * inv_dx;                                  \
       gel_au2 gd_;                                                                                                \
       __builtin_memcpy(&gd_, &gv, 8);                                                                             \
-      __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], ((col) == 0) ? a8_ : a8_ + (col) * ipark[kind * 64], 8 * bo * O.nrows[kind], 0); \
+      __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], ((col) == 0) ? a8_ : a8_ + (col) * ipark[kind * 64], 8 * bo * O.nrows[kind], ROLES ? 2 : 0); /* ROLES = the one-vector callback: streamed to pinned host memory */ \
       chk += gv;                                                                                                  \
     }                                                                                                             \
   } while (0)

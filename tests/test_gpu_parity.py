@@ -1313,3 +1313,28 @@ def test_coo_direct_one_vector_output_equals_the_compact_path(name):
     assert rc == 1 and np.isnan(pres).any()
     _, _, rc = E.eval(X[1], out=pvals, res_out=pres)
     assert rc == 0 and np.array_equal(pvals, full_b[1]) and np.array_equal(pres, res_b[1])
+
+
+def test_page_locked_caller_buffers_skip_the_staging_copies():
+    """gel_eval_batch with page-locked caller buffers (torch pin_memory): H2D / D2H straight from / into them, sub-batch by sub-batch;
+    the same bits as with pageable arrays (staged through the handle's slots); a mix of pinned and pageable buffers takes the staged path."""
+    import torch
+    from gelato_amd import Engine, problem
+    prob, x0, _ = named_problem("mixed-6x64")
+    E = Engine(prob)
+    B = 300                       # > one staging slot (16 MB / 136 KB = 117 vectors): three sub-batches, the last one ragged
+    X = problem.synthetic_batch(x0, E.M, B, seed=11)
+    res, jv, rc = E.eval_batch(X)
+    assert rc == 0
+    xp = torch.from_numpy(X).pin_memory()
+    rp = torch.full((B, E.nres), float("nan"), dtype=torch.float64).pin_memory()
+    jp = torch.full((B, E.V), float("nan"), dtype=torch.float64).pin_memory()
+    r2, j2, rc2 = E.eval_batch(xp.numpy(), out=(rp.numpy(), jp.numpy()))
+    assert rc2 == 0 and np.array_equal(r2, res) and np.array_equal(j2, jv)
+    jpage = np.full((B, E.V), np.nan)
+    r3, j3, rc3 = E.eval_batch(xp.numpy(), out=(rp.numpy(), jpage))       # one pageable buffer: staged
+    assert rc3 == 0 and np.array_equal(j3, jv) and np.array_equal(r3, res)
+    Xn = xp.numpy().copy(); Xn[250, 7] = np.nan
+    xp2 = torch.from_numpy(Xn).pin_memory()
+    r4, j4, rc4 = E.eval_batch(xp2.numpy(), out=(rp.numpy(), jp.numpy()))
+    assert rc4 == 1 and np.array_equal(r4[:250], res[:250]) and np.array_equal(j4[251:], jv[251:])
