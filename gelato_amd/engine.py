@@ -113,6 +113,11 @@ class Engine:
         if getattr(self, "_h", None):
             lib().gel_problem_destroy(self._h)
             self._h = None
+            # the pinned buffers died with the handle: drop the views this object handed out of them (arrays a caller still holds
+            # point at freed memory, like any view of a closed resource)
+            self.__dict__.pop("_pinned", None)
+            self.__dict__.pop("_cb_out", None)
+            self._vals = None
 
     def __del__(self):
         try:
