@@ -555,10 +555,14 @@ def main():
             rp = torch.empty((Bp, E.nres), dtype=torch.float64).pin_memory()
             jp = torch.empty((Bp, E.V), dtype=torch.float64).pin_memory()
             E.eval_batch(xp.numpy(), out=(rp.numpy(), jp.numpy()))
-            t0 = time.perf_counter()
-            E.eval_batch(xp.numpy(), out=(rp.numpy(), jp.numpy()))
-            dtp = time.perf_counter() - t0
+            dts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                E.eval_batch(xp.numpy(), out=(rp.numpy(), jp.numpy()))
+                dts.append(time.perf_counter() - t0)
+            dtp = min(dts)
             out["host_batch_pcie_inclusive"].update({"pinned_caller_buffers": {"batch": Bp, "evals_per_s": Bp / dtp, "ms": 1e3 * dtp,
+                                                                                "ms_of_three_calls": [1e3 * v for v in dts],
                                                                                 "GBps_over_pcie": Bp * 8 * (E.nvars + E.nres + E.V) / dtp / 1e9}})
             del xp, rp, jp
         except Exception as ex:  # noqa: BLE001
