@@ -458,7 +458,9 @@ int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_ja
     // so it may live in host memory too.
     gel::ProblemDev dv = p->dev;
     dv.flag = p->h_flag;
-    if (coo && B == 1 && want_jac) { dv.coo_full = p->h_full; dv.coo = p->d_coo; *coo_io = true; }
+    // COO-direct output exists in the latency form only: a problem of more than 256 work items takes a cooperative form even for one
+    // vector (gel::eval_form) and keeps the compact path
+    if (coo && B == 1 && want_jac && gel::eval_form(dv, 1, want_res, true).split) { dv.coo_full = p->h_full; dv.coo = p->d_coo; *coo_io = true; }
     dv.split_vel = 1;   // a whole evaluation: every part of every work item is in this launch
     HIPCHK(gel::launch_eval(dv, B, xin, want_res ? (res_to ? res_to : p->h_res) : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
     HIPCHK(spin_wait(p->stream));
@@ -1885,7 +1887,9 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
   dv.flag = p->h_flag;
   const bool want_jac = io->vals_full != nullptr;
   const bool fused = io->res || want_jac;
-  const bool coo = want_jac && coo_direct(p);
+  // GEL_CB_MODE=3 (measurement switch): the three launches of rounds 1-2, back to back on the handle's stream (compact path)
+  static const int cb_mode = [] { const char* e = getenv("GEL_CB_MODE"); return e ? atoi(e) : 0; }();
+  const bool coo = want_jac && cb_mode != 3 && coo_direct(p);
   if (coo) {
     if ((rc = ensure_full(p))) return rc;
     dv.coo_full = p->h_full; dv.coo = p->d_coo;
@@ -1901,8 +1905,6 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
       out.con[k] = (io->aero_con[k] && n) ? p->h_aero + off_c[k] : nullptr;
       out.jac[k] = (out.con[k] && io->aero_jac[k]) ? p->h_aero + off_j[k] : nullptr;
     }
-  // GEL_CB_MODE=3 (measurement switch): the three launches of rounds 1-2, back to back on the handle's stream
-  static const int cb_mode = [] { const char* e = getenv("GEL_CB_MODE"); return e ? atoi(e) : 0; }();
   if (cb_mode == 3 || !fused) {
     if (fused) HIPCHK(gel::launch_eval(dv, 1, xin, res_to, want_jac ? p->h_jv : nullptr, p->stream));
     if (rows) HIPCHK(gel::launch_rows(dv, (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, 1, xin, p->h_rows,
