@@ -469,11 +469,27 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   const Tables tb = stage_tables(P, lds);
   const int lane = (int)(threadIdx.x & 63);
   const int sw = ROLES ? (int)(threadIdx.x >> 6) : -1;   // ROLES: 0 centre + light sweeps, 1..3 position sweep sw - 1
-  const long long wid = ROLES ? (long long)vblk : (long long)vblk * kAeroWaves + (threadIdx.x >> 6);
-  if (wid >= (long long)B * tiles) return;             // after the tables' barrier
-  const int b = (int)(wid / tiles), tile = (int)(wid - (long long)b * tiles);
-  const int ni_raw = tile * 64 + lane;
-  const bool live = ni_raw < nnodes;
+  const long long wid = ROLES ? (long long)vblk : (long long)vblk * kAeroWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // FLAT (batch launches, tiles == 0) [r5]: a wavefront takes 64 consecutive entries of the (vector, node) sequence of the whole batch,
+  // whichever vectors they belong to -- 325 constrained nodes per vector are 5.08 wavefronts' worth, not six tiles with the last one
+  // 59 / 64 empty.  A wavefront then straddles at most two vectors (nnodes >= 64), so the vector is a per-lane value.
+  const bool flat = !ROLES && tiles == 0;
+  int b, ni_raw;
+  bool live;
+  if (flat) {
+    const long long total = (long long)B * nnodes, f0 = wid * 64;
+    if (f0 >= total) return;                           // after the tables' barrier
+    const int b0 = (int)(f0 / nnodes), r0 = (int)(f0 - (long long)b0 * nnodes);
+    const bool wrap = r0 + lane >= nnodes;
+    live = f0 + lane < total;
+    b = live ? (wrap ? b0 + 1 : b0) : b0;
+    ni_raw = live ? (wrap ? r0 + lane - nnodes : r0 + lane) : nnodes;
+  } else {
+    if (wid >= (long long)B * tiles) return;           // after the tables' barrier
+    b = (int)(wid / tiles);
+    ni_raw = (int)(wid - (long long)b * tiles) * 64 + lane;
+    live = ni_raw < nnodes;
+  }
   const int ni = live ? ni_raw : nnodes - 1;
   const AeroNodeDev Nd = nodes[ni];
   const PhaseDev& ph = P.phases[Nd.phase];
@@ -503,7 +519,24 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   // ---- centre (con_aero.py:39-87: scale, evaluate)
   PosCentre pc;
   PosPart pp;
-  EarthAngle ea;
+  EarthAngle ea{1.0, 0.0, 1.0, 0.0};
+  // Calm air [r5]: where both wind components of every lane are exactly zero (below and above the measured part of the wind table: in
+  // the shipped example below 1 km and from 23 km up) the rotation of the zero vector into ECI is the zero vector -- wind_eci_or_calm()
+  // skips its ~70 instructions, four times per tile -- and the Earth angle, which enters the air-relative velocity only through that
+  // rotation (aero_vair2), is not formed at all (as in the fused kernel).  A sweep whose perturbed point leaves the calm (a step across
+  // the table's end: the recomputing fallback) forms it on first need, from the node's time read again.
+  bool have_ea = false;
+#define GEL_AERO_NEED_EA(wn_, we_)                                                                                     \
+  do {                                                                                                                 \
+    if (!have_ea && __builtin_amdgcn_ballot_w64(!((wn_) == 0.0 && (we_) == 0.0)) != 0) {                                \
+      const int kn_ = nodes[ni].k, phn_ = nodes[ni].phase;                                                             \
+      const double to_ = xb[11 * M + 2 * N + phn_], tf_ = xb[11 * M + 2 * N + phn_ + 1];                               \
+      const double tau_ = (kn_ == 0) ? 0.0 : P.tau[P.phases[phn_].toff + kn_ - 1];                                     \
+      /* PSparams.time_nodes (SectionParameters.py:77-81): node 0 is t0 itself; t in seconds here (con_aero.py:45) */   \
+      ea = earth_angle(((kn_ == 0) ? to_ : (tau_ * (tf_ - to_) / 2 + (tf_ + to_) / 2)) * P.ut);                         \
+      have_ea = true;                                                                                                  \
+    }                                                                                                                  \
+  } while (0)
   double chk = 0.0;
   {
     double r[3], v[3], q[4], w[3], a0[3], dir[3];
@@ -514,13 +547,8 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     PosCentreTail pt;
     pp = pos_part<true, PosCentreSink, false>(r, tb, 0.0, nullptr, PosCentreSink{&pc}, &pt);
     pos_centre_tail(pt, pp.rho, pp.P, tb, pc, pp.wn, pp.we);
-    {
-      const double to = xb[11 * M + 2 * N + Nd.phase], tf = xb[11 * M + 2 * N + Nd.phase + 1];
-      const double tau = (Nd.k == 0) ? 0.0 : P.tau[ph.toff + Nd.k - 1];
-      // PSparams.time_nodes (SectionParameters.py:77-81): node 0 is t0 itself; t in seconds here (con_aero.py:45)
-      ea = earth_angle(((Nd.k == 0) ? to : (tau * (tf - to) / 2 + (tf + to) / 2)) * P.ut);
-    }
-    wind_eci(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
+    GEL_AERO_NEED_EA(pp.wn, pp.we);
+    wind_eci_or_calm(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
     const double nv2 = aero_vair2(r, v, w, a0);
     thrust_dir(q, dir);
     const double ind = frsqrt(fmax(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2], 1.0e-300));
@@ -534,14 +562,17 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
 #pragma unroll
     for (int kind = 0; kind < 3; kind++) {
       const double il = frcp(Nd.limit[kind]);
-      AP_SET(AP_ILIM + kind, il);
+      AP_SET(AP_ILIM + kind, il * P.inv_dx);   // 1 / (limit dx): what every gradient entry of the kind is scaled by
       const int row = Nd.row[kind];
       {
         const bool has = live && O.jac[kind] && row >= 0;
+        // FLAT: the vector's gradient values start b R (8 + nq) doubles into the kind's buffer (unsigned 32-bit byte offsets: the
+        // launcher keeps to the per-vector mapping where a batch's gradients exceed 4 GB); -1 = no entry
+        const unsigned vb = flat ? (unsigned)b * (unsigned)(O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)) * 8) : 0u;
         ipark[kind * 64] = 8 * Nd.nk[kind];
-        ipark[AP_AIDX(kind, 3) * 64] = has ? 8 * (3 * Nd.row0[kind] + Nd.k) : -1;
-        ipark[AP_AIDX(kind, 2) * 64] = has ? 8 * (2 * Nd.row0[kind] + Nd.k) : -1;
-        if (kind != 1) ipark[AP_AIDX(kind, 4) * 64] = has ? 8 * (4 * Nd.row0[kind] + Nd.k) : -1;
+        ipark[AP_AIDX(kind, 3) * 64] = has ? (int)(vb + 8u * (unsigned)(3 * Nd.row0[kind] + Nd.k)) : -1;
+        ipark[AP_AIDX(kind, 2) * 64] = has ? (int)(vb + 8u * (unsigned)(2 * Nd.row0[kind] + Nd.k)) : -1;
+        if (kind != 1) ipark[AP_AIDX(kind, 4) * 64] = has ? (int)(vb + 8u * (unsigned)(4 * Nd.row0[kind] + Nd.k)) : -1;
       }
       if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
       const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
@@ -555,7 +586,6 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     for (int c = 0; c < 3; c++) { AP_SET(AP_W + c, w[c]); AP_SET(AP_A0 + c, a0[c]); AP_SET(AP_DIR + c, dir[c]); }
     AP_SET(AP_RHO, pp.rho); AP_SET(AP_NV2, nv2);
   }
-  const double inv_dx = P.inv_dx;   // 1 / dx, divided on the host (same bits)
   // One gradient entry of every kind that has this node, jac = -(f_p - f_c)/dx (con_aero.py:437-463), from the perturbed point's
   // air velocity a (squared norm nv2), body axis d (1/|d| = ind) and density: alpha_p - alpha_c in exact-difference form
   // (aero_dalpha; a wavefront with a lane it does not cover takes two acos like the reference), q_p - q_c as it is, and
@@ -579,11 +609,11 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     _Pragma("unroll") for (int kind = 0; kind < 3; kind++) {                                                      \
       if ((skip_q) && kind == 1) continue;                 /* dynamic pressure has no quaternion block */        \
       const int a8_ = ipark[AP_AIDX(kind, width) * 64];                                                           \
-      if (a8_ < 0) continue;                                                                                      \
+      if (a8_ == -1) continue;                                                                                    \
       const int nq = (kind == 1) ? 0 : 4;                                                                         \
       const int bo = ((boff) < 0) ? (6 + nq) : (boff);                                                            \
       const double df_ = (kind == 0) ? t_ : ((kind == 1) ? dq_ : qp_ * t_ + dq_ * ac_);                           \
-      const double gv = (zero) ? 0.0 : -(df_ * AP_GET(AP_ILIM + kind)) * inv_dx;                                  \
+      const double gv = (zero) ? 0.0 : -(df_ * AP_GET(AP_ILIM + kind));                                           \
       gel_au2 gd_;                                                                                                \
       __builtin_memcpy(&gd_, &gv, 8);                                                                             \
       __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], ((col) == 0) ? a8_ : a8_ + (col) * ipark[kind * 64], 8 * bo * O.nrows[kind], ROLES ? 2 : 0); /* ROLES = the one-vector callback: streamed to pinned host memory */ \
@@ -595,7 +625,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   __amdgpu_buffer_rsrc_t jrs[3];
 #pragma unroll
   for (int kind = 0; kind < 3; kind++)
-    jrs[kind] = __builtin_amdgcn_make_buffer_rsrc(O.jac[kind] ? (void*)(O.jac[kind] + (size_t)b * O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4))) : (void*)nullptr,
+    jrs[kind] = __builtin_amdgcn_make_buffer_rsrc(O.jac[kind] ? (void*)(O.jac[kind] + (flat ? (size_t)0 : (size_t)__builtin_amdgcn_readfirstlane(b) * O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)))) : (void*)nullptr,
                                                   0, -1, 0x00020000);
   if (want_jac) {
     // ---- t0 / tf columns
@@ -624,7 +654,8 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
 #define GEL_AERO_POS_TAIL(c, rp, pq)                                                                 \
   do {                                                                                               \
     double wq_[3], a_[3];                                                                            \
-    wind_eci(rp, ea, (pq).shp, (pq).chp, (pq).inv_p, (pq).wn, (pq).we, wq_);                         \
+    GEL_AERO_NEED_EA((pq).wn, (pq).we);                                                              \
+    wind_eci_or_calm(rp, ea, (pq).shp, (pq).chp, (pq).inv_p, (pq).wn, (pq).we, wq_);                 \
     const double vq_[3] = {xb[4 * M + 3 * xi] * P.uv, xb[4 * M + 3 * xi + 1] * P.uv, xb[4 * M + 3 * xi + 2] * P.uv}; \
     const double nv2_ = aero_vair2(rp, vq_, wq_, a_);                                                \
     const double dd_[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};                  \
@@ -701,6 +732,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     }
   }
 #undef GEL_AERO_EMIT
+#undef GEL_AERO_NEED_EA
 #undef AP_AIDX
 #undef AP_GET
 #undef AP_SET
@@ -720,9 +752,18 @@ hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes
   if (B <= 0 || nnodes <= 0) return hipSuccess;
   AeroOut O;
   for (int k = 0; k < 3; k++) { O.con[k] = out.con[k]; O.jac[k] = out.jac[k]; O.nrows[k] = out.nrows[k]; }
-  const int tiles = (nnodes + 63) / 64;
+  int tiles = (nnodes + 63) / 64;
   const size_t lds = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + (size_t)kAeroWaves * kAeroParkSlots * 64);
-  const unsigned grid = (unsigned)(((long long)B * tiles + kAeroWaves - 1) / kAeroWaves);
+  long long waves = (long long)B * tiles;
+  // flat (vector, node) mapping (tiles = 0 tells the kernel): no mostly-empty last tile per vector; needs every wavefront inside two
+  // vectors and the batch's gradient values of a kind inside 32-bit byte offsets
+  long long maxbytes = 0;
+  for (int k = 0; k < 3; k++) maxbytes = std::max(maxbytes, (long long)B * O.nrows[k] * (8 + ((k == 1) ? 0 : 4)) * 8);
+  if (B > 1 && nnodes >= 64 && (nnodes & 63) != 0 && maxbytes < (1LL << 32) - (1LL << 24)) {
+    waves = ((long long)B * nnodes + 63) / 64;
+    tiles = 0;
+  }
+  const unsigned grid = (unsigned)((waves + kAeroWaves - 1) / kAeroWaves);
   hipLaunchKernelGGL(aero_kernel, dim3(grid), dim3(64 * kAeroWaves), lds, s, P, nnodes, nodes, tiles, B, d_x, O);
   return hipGetLastError();
 }
