@@ -45,19 +45,14 @@ static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wav
 // wavefronts of its workgroup still write their tiles.
 constexpr int kCoopStageOff = PK_LV0 * 64;
 static_assert(kWaveLds - kCoopStageOff >= 64 * 11, "the cooperative hand-over area must fit behind the early park slots");
-#ifndef GEL_XLDS_PIPE
-#define GEL_XLDS_PIPE 1  // longer phases: double-buffered LDS slabs of state rows (1) or operands from global memory (0)
-#endif
-#ifndef GEL_XLDS_PIPE_FROM
-#define GEL_XLDS_PIPE_FROM 68  // ... from this many nodes per phase on (below: one slab, staged at once)
-#endif
+constexpr int kXldsPipeFrom = 68;  // phases of this many nodes and more: state rows in double-buffered 44-row LDS slabs (below: one slab, staged at once)
 // Residual-only instantiations park PK_Q0 .. PK_LV2 only: their region is the D.X operand image (cooperative LDS-staged
 // form: a 68-row slab, or two 36-row vectors when two decision vectors share a wavefront), the hand-over area over it and
 // then, once the wavefront has taken its rows, the park over that -- 6 KB instead of 9.5 KB per wavefront.
 constexpr int kSlabRowsMax = 68, kPackRows = 36, kParkRes = (PK_LV2 + 1) * 64;
 constexpr int kPipeSlabK = 11;   // k-steps per double-buffered slab of the long-phase form (44 state rows)
 constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack, bool split = false) {
-  return jac ? kWaveLds : (!mfma ? kParkRes : (split ? 64 * kStageLd /* one wavefront's own result tile */ : (pack ? kParkRes + 4 * 64 /* operand image (792), then park + the tile of the transposed residual stores */ : (GEL_XLDS_PIPE ? 2 * 4 * kPipeSlabK * 11 : kSlabRowsMax * 11))));
+  return jac ? kWaveLds : (!mfma ? kParkRes : (split ? 64 * kStageLd /* one wavefront's own result tile */ : (pack ? kParkRes + 4 * 64 /* operand image (792), then park + the tile of the transposed residual stores */ : 2 * 4 * kPipeSlabK * 11)));
 }
 static_assert(wave_lds_doubles(false, true, false, true) >= kParkRes, "residual-only split form: park over the result tile");
 static_assert(wave_lds_doubles(false, true, true) >= 64 * 11 && wave_lds_doubles(false, true, false) >= 64 * 11, "hand-over area");
@@ -86,16 +81,6 @@ constexpr int kSlotPT = 0, kSlotVM = 3, kSlotVP = 6;
 
 typedef double gel_double4 __attribute__((ext_vector_type(4)));
 
-// k-steps of D.X operands in flight ahead of the matrix pipe (cooperative form).  Measured (dense-6x64, B = 16384,
-// same box): the residual-only launch is 5 % shorter with 4 than with 1; the fused launch is 2-3 % LONGER (its other
-// wavefronts already cover the latency, and the extra live registers cost more than the overlap gains).
-#ifndef GEL_DX_PF_JAC
-#define GEL_DX_PF_JAC 1
-#endif
-#ifndef GEL_DX_PF_RES
-#define GEL_DX_PF_RES 4
-#endif
-
 #ifndef GEL_CA_CACHE
 #define GEL_CA_CACHE 1  // the Mach interval of a node's first CA lookup serves its other aerodynamic-force evaluations
 #endif
@@ -113,10 +98,6 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_PACK_A_PRELOAD 1  // two vectors per wavefront: all (<= 9) A slabs of D.X requested before the operand barrier
 #endif
 
-
-#ifndef GEL_COOP_XLDS
-#define GEL_COOP_XLDS 1  // cooperative D.X: state rows staged in LDS (1) or fetched per k-step from global memory (0)
-#endif
 
 #ifndef GEL_STORE_AUX
 #define GEL_STORE_AUX 2  // cache policy of the Jacobian stores: 2 = nt (A/B: 0 plain, 1 sc0, 16 sc1, 18 sc1+nt)
@@ -164,7 +145,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // its wavefronts share the A operand (D) and form the product together (see phase A).
   constexpr bool COOP = MFMA && !SPLIT;
   static_assert(!COOP || kBlock == 256, "the cooperative D.X form is written for four wavefronts per workgroup");
-  static_assert(!PACK || (COOP && GEL_COOP_XLDS != 0), "two vectors per wavefront exist in the cooperative LDS-staged form only");
+  static_assert(!PACK || COOP, "two vectors per wavefront exist in the cooperative form only");
   constexpr int kVecWg = PACK ? 8 : 4;   // decision vectors per workgroup
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int half = PACK ? (lane >> 5) : 0;
@@ -411,7 +392,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // 8-byte global loads in the matrix loop.  Measured against fetching B per k-step from global memory (same box,
   // B = 16384 / 65536): fused launch -2 % at 6x64, residual-only -9 % at 3x32; with two slabs (n = 128) the extra
   // workgroup barriers cost what the loads save (residual-only +10 %), so longer phases keep the global form.
-  const bool XLDS = PACK || (COOP && (GEL_COOP_XLDS != 0) && (n < 68 || GEL_XLDS_PIPE));   // wave-uniform: the node's own state row comes from LDS
+  constexpr bool XLDS = COOP;   // the cooperative forms stage the state rows in LDS: the node's own state row comes from there
   double me = 0.0, re[3] = {0.0, 0.0, 0.0};
   if (!XLDS) { me = xm[xj]; re[0] = xr[3 * xj]; re[1] = xr[3 * xj + 1]; re[2] = xr[3 * xj + 2]; }
   const double tau = P.tau[ph.toff + jc];
@@ -460,7 +441,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     // D.X rows (lib/con_dynamics.py:54,146,256,524)
     double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
     if (rb) {
-      if (XLDS && (PACK || n < GEL_XLDS_PIPE_FROM || !GEL_XLDS_PIPE)) {
+      if (XLDS && (PACK || n < kXldsPipeFrom)) {
         // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP, operands as in the branch below, but B comes from LDS: every wavefront
         // stages ITS OWN vector's n + 1 <= 68 state rows (17 k-steps) -- lane = row, the eleven interleaved columns (mass |
         // pos xyz | vel xyz | quat wxyz) side by side, [row][11] at the start of its region -- and all four read the 44
@@ -618,9 +599,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
 #pragma unroll
         for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
-#if GEL_XLDS_PIPE
       } else if (XLDS) {
-        // Longer phases (GEL_XLDS_PIPE_FROM nodes and more): the LDS-staged product in slabs of 44 state rows (11 k-steps), double
+        // Longer phases (kXldsPipeFrom nodes and more): the LDS-staged product in slabs of 44 state rows (11 k-steps), double
         // buffered -- the rows of slab s + 1 are requested before slab s is multiplied and written to the other buffer after,
         // one workgroup barrier per slab.  11 row-coalesced loads per wavefront and slab instead of 3 scattered 8-byte
         // loads per lane and k-step (the texture addresser sees ~5x fewer line accesses at 128 nodes).
@@ -696,90 +676,6 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #undef GEL_PIPE_LOAD
 #undef GEL_PIPE_WRITE
         lds_double* wg_lds = regions + kHO;
-#pragma unroll
-        for (int ct = 0; ct < 3; ct++) {
-          const int c = 16 * ct + c16;
-          const int vb = c / 11, col = c - 11 * vb;
-          if (c < 44) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) wg_lds[vb * kWL + (16 * wv + kq + 4 * i) * 11 + col] = acc[ct][i];
-          }
-        }
-        __syncthreads();
-        if (ghost) return;
-        lds_double* row = wave_lds + kHO + lane * 11;
-        lm = row[0];
-#pragma unroll
-        for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
-#pragma unroll
-        for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
-#endif
-      } else if (COOP && !PACK) {
-        // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP: A = the work item's rows of D, shared by all four wavefronts;
-        // B = the 11 state columns of the workgroup's four decision vectors side by side (44 of 48 columns used,
-        // against 11 of 16 when every wavefront multiplies alone).  Wavefront w forms row tile w (16 nodes) for all
-        // three column tiles: 3 x ceil((n+1)/4) v_mfma_f64_16x16x4_f64 instead of 4 x, and it fetches a quarter of
-        // D (one coalesced 512-byte row-tile slab per k-step, ProblemDev::Dst).  Operand layout
-        // (cdna_hip_programming.md section 3): A lane l = A[row l&15][k l>>4], B lane l = B[k l>>4][col l&15],
-        // C/D reg i of lane l = C[row (l>>4)+4i][col l&15].
-        const int c16 = lane & 15, kq = lane >> 4;
-        const double* bp[3];
-        unsigned bs[3];
-#pragma unroll
-        for (int ct = 0; ct < 3; ct++) {
-          const int c = 16 * ct + c16;            // packed column: vector c / 11, state column c % 11
-          const int vb = min(c / 11, 3);          // columns 44..47 are padding: computed on vector 3, never read
-          const int col = (c < 44) ? c - 11 * vb : 0;
-          const double* xo = x + (size_t)min(b0 + vb, B - 1) * P.nvars;
-          // state column = one of the 11 interleaved columns (mass | pos xyz | vel xyz | quat wxyz)
-          bp[ct] = xo + ph.xa; bs[ct] = 1;
-          if (col >= 1 && col < 4) { bp[ct] = xo + M + 3 * ph.xa + (col - 1); bs[ct] = 3; }
-          if (col >= 4 && col < 7) { bp[ct] = xo + 4 * M + 3 * ph.xa + (col - 4); bs[ct] = 3; }
-          if (col >= 7) { bp[ct] = xo + 7 * M + 4 * ph.xa + (col - 7); bs[ct] = 4; }
-        }
-        gel_double4 acc[3];
-#pragma unroll
-        for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
-        // columns past n hold zeros in Dst, so B is only clamped, never masked
-        const double* ap = P.Dst + (size_t)dsw * 4 + wv * 64 + lane;
-        const unsigned un = (unsigned)n;
-        double xn3[3] = {0, 0, 0};
-        if (tail1) {
-#pragma unroll
-          for (int ct = 0; ct < 3; ct++) xn3[ct] = bp[ct][un * bs[ct]];
-        }
-        // Software pipeline: the operands of k-step ks + kPF are requested while k-step ks multiplies.  Without
-        // it every k-step waits a full memory latency (x comes from HBM on first touch) before its three MFMAs.
-        // Requests past the last k-step repeat it (valid addresses, results unused).
-        constexpr int kPF = JAC ? GEL_DX_PF_JAC : GEL_DX_PF_RES;
-        double ra[kPF], rb0[kPF], rb1[kPF], rb2[kPF];
-#define GEL_DX_LOAD(slot, kstep)                                  \
-  do {                                                            \
-    const int _ks = min((kstep), ksteps - 1);                     \
-    const unsigned _k = min(4u * _ks + kq, un);                   \
-    ra[slot] = ap[_ks * 256];                                     \
-    rb0[slot] = bp[0][_k * bs[0]];                                \
-    rb1[slot] = bp[1][_k * bs[1]];                                \
-    rb2[slot] = bp[2][_k * bs[2]];                                \
-  } while (0)
-#pragma unroll
-        for (int i = 0; i < kPF; i++) GEL_DX_LOAD(i, i);
-        for (int ks = 0; ks < ksteps; ks += kPF) {
-#pragma unroll
-          for (int i = 0; i < kPF; i++) {
-            if (ks + i < ksteps) {  // wave-uniform
-              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i], rb0[i], acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i], rb1[i], acc[1], 0, 0, 0);
-              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i], rb2[i], acc[2], 0, 0, 0);
-            }
-            GEL_DX_LOAD(i, ks + i + kPF);
-          }
-        }
-#undef GEL_DX_LOAD
-        GEL_DX_TAIL_ACC(xn3[ct]);
-        stage_tables_commit(P, lds, tab_mine);
-        // hand-over: the rows of vector vb go to wavefront vb's own region ([node][11] behind its early park slots)
-        lds_double* wg_lds = (lds_double*)lds + park_off + kHO;
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
           const int c = 16 * ct + c16;
