@@ -405,12 +405,17 @@ static hipError_t spin_wait(hipStream_t s) {
 // The engine's own full COO value array and residual vector in pinned host memory (one-vector latency path): the constants are
 // laid down here, once; the COO-direct kernel and the host's scatter of the few entries left to it rewrite the x-dependent ones.
 int ensure_full(gel_problem* p) {
-  if (p->h_full) return GEL_OK;
+  if (p->h_full && p->cb_res && p->cb_x[0] && p->cb_x[1]) return GEL_OK;
   HIPCHK(hipSetDevice(p->device));
-  HIPCHK(hipHostMalloc((void**)&p->h_full, std::max<size_t>(1, p->cval.size()) * 8));
-  std::memcpy(p->h_full, p->cval.data(), p->cval.size() * 8);
-  HIPCHK(hipHostMalloc((void**)&p->cb_res, (size_t)11 * p->dims.N * 8));
-  for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void**)&p->cb_x[i], (size_t)p->dims.num_vars * 8));
+  // each buffer on its own: a failed allocation leaves the others as they are and the next call tries again (no half-made set is
+  // ever handed out: gel_pinned_buffers and the zero-copy checks only run after this function has returned GEL_OK)
+  if (!p->h_full) {
+    HIPCHK(hipHostMalloc((void**)&p->h_full, std::max<size_t>(1, p->cval.size()) * 8));
+    std::memcpy(p->h_full, p->cval.data(), p->cval.size() * 8);
+  }
+  if (!p->cb_res) HIPCHK(hipHostMalloc((void**)&p->cb_res, (size_t)11 * p->dims.N * 8));
+  for (int i = 0; i < 2; i++)
+    if (!p->cb_x[i]) HIPCHK(hipHostMalloc((void**)&p->cb_x[i], (size_t)p->dims.num_vars * 8));
   return GEL_OK;
 }
 // GEL_NO_COO_DIRECT=1 (measurement switch): the compact layout + the host scatter of every x-dependent entry, as before round 5
