@@ -588,11 +588,12 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   }
   // One gradient entry of every kind that has this node, jac = -(f_p - f_c)/dx (con_aero.py:437-463), from the perturbed point's
   // air velocity a (squared norm nv2), body axis d (1/|d| = ind) and density: alpha_p - alpha_c in exact-difference form
-  // (aero_dalpha; a wavefront with a lane it does not cover takes two acos like the reference), q_p - q_c as it is, and
+  // (aero_dalpha; a lane it does not cover takes two acos like the reference -- per lane, so that a node's values do not depend on
+  // which nodes share its wavefront: the flat mapping puts two vectors' nodes into one), q_p - q_c as it is, and
   //   alpha:   d f = t / limit        q:   d f = (q_p - q_c) / limit        q alpha:   d f = (q_p t + (q_p - q_c) alpha_c) / limit
   // (q_p alpha_p - q_c alpha_c, regrouped).  Block offset `boff` in units of R rows (0 position, 3 velocity, 6 quaternion, -1 = t:
   // 6 + nq), `width` columns per row, column `col`; zero: the entry is an exact zero.
-#define GEL_AERO_EMIT(boff, width, col, a, nv2, d, ind, rho, skip_q, zero)                                        \
+#define GEL_AERO_EMIT(boff, width, col, a, nv2, d, ind, rho, skip_q, zero, skip_lane)                                      \
   do {                                                                                                            \
     double t_ = 0.0, dq_ = 0.0, qp_ = 0.0;                                                                        \
     const double ac_ = AP_GET(AP_AC);                                                                             \
@@ -602,14 +603,17 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       dq_ = qp_ - qc_;                                                                                            \
       if (need_alpha) {                                                                                           \
         const double cp_ = aero_cos(a, nv2, d, ind);                                                              \
-        if (__builtin_amdgcn_ballot_w64(!aero_dalpha(cp_, nv2, AP_GET(AP_CC), AP_GET(AP_IS), ipark[11 * 64] != 0, t_)) != 0) \
-          t_ = aero_acos(cp_, nv2) - ac_;                                                                         \
+        const bool okd_ = aero_dalpha(cp_, nv2, AP_GET(AP_CC), AP_GET(AP_IS), ipark[11 * 64] != 0, t_);           \
+        if (__builtin_amdgcn_ballot_w64(!okd_) != 0) {                                                            \
+          const double t2_ = aero_acos(cp_, nv2) - ac_;                                                           \
+          t_ = okd_ ? t_ : t2_;                                                                                   \
+        }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
     _Pragma("unroll") for (int kind = 0; kind < 3; kind++) {                                                      \
       if ((skip_q) && kind == 1) continue;                 /* dynamic pressure has no quaternion block */        \
       const int a8_ = ipark[AP_AIDX(kind, width) * 64];                                                           \
-      if (a8_ == -1) continue;                                                                                    \
+      if (a8_ == -1 || (skip_lane)) continue;                                                                     \
       const int nq = (kind == 1) ? 0 : 4;                                                                         \
       const int bo = ((boff) < 0) ? (6 + nq) : (boff);                                                            \
       const double df_ = (kind == 0) ? t_ : ((kind == 1) ? dq_ : qp_ * t_ + dq_ * ac_);                           \
@@ -644,14 +648,14 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
         wind_eci(r, eq, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, wq);
         const double nvq = aero_vair2(r, vq, wq, aq);
         const double dq[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};
-        GEL_AERO_EMIT(-1, 2, c, aq, nvq, dq, AP_GET(AP_IND), pp.rho, false, false);
+        GEL_AERO_EMIT(-1, 2, c, aq, nvq, dq, AP_GET(AP_IND), pp.rho, false, false, false);
       } else {
         const double none[3] = {0.0, 0.0, 0.0};
-        GEL_AERO_EMIT(-1, 2, c, none, 0.0, none, 0.0, 0.0, false, true);
+        GEL_AERO_EMIT(-1, 2, c, none, 0.0, none, 0.0, 0.0, false, true, false);
       }
     }
     // ---- position sweeps
-#define GEL_AERO_POS_TAIL(c, rp, pq)                                                                 \
+#define GEL_AERO_POS_TAIL(c, rp, pq, skip_)                                                          \
   do {                                                                                               \
     double wq_[3], a_[3];                                                                            \
     GEL_AERO_NEED_EA((pq).wn, (pq).we);                                                              \
@@ -659,10 +663,11 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
     const double vq_[3] = {xb[4 * M + 3 * xi] * P.uv, xb[4 * M + 3 * xi + 1] * P.uv, xb[4 * M + 3 * xi + 2] * P.uv}; \
     const double nv2_ = aero_vair2(rp, vq_, wq_, a_);                                                \
     const double dd_[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};                  \
-    GEL_AERO_EMIT(0, 3, c, a_, nv2_, dd_, AP_GET(AP_IND), (pq).rho, false, false);                   \
+    GEL_AERO_EMIT(0, 3, c, a_, nv2_, dd_, AP_GET(AP_IND), (pq).rho, false, false, skip_);                  \
   } while (0)
     const unsigned mine = ROLES ? ((sw == 0) ? 0u : (1u << (sw - 1))) : 7u;   // this wavefront's position sweeps
     unsigned todo = P.fd_recompute ? mine : 0u;   // sweeps with a lane the difference form does not cover (wave-uniform)
+    unsigned bad = P.fd_recompute ? 7u : 0u;      // this lane's sweeps among them: only these take the recomputed values
     if (!P.fd_recompute) {
 #if GEL_AERO_UNROLL
 #pragma unroll
@@ -679,11 +684,12 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
         for (int d = 0; d < 3; d++) rp[d] = (d == c) ? (re[d] + dx) * P.up : r[d];
         const double dlt = (c == 0) ? rp[0] - r[0] : ((c == 1) ? rp[1] - r[1] : rp[2] - r[2]);   // exact
         PosPart pq;
-        if (__builtin_amdgcn_ballot_w64(!pos_delta(r, c, dlt, pp, pc, tb, pq)) != 0) { todo |= 1u << c; continue; }
-        GEL_AERO_POS_TAIL(c, rp, pq);
+        const bool okp = pos_delta(r, c, dlt, pp, pc, tb, pq);
+        if (__builtin_amdgcn_ballot_w64(!okp) != 0) { todo |= 1u << c; if (!okp) bad |= 1u << c; }
+        GEL_AERO_POS_TAIL(c, rp, pq, !okp);
       }
     }
-    if (todo) {   // the chain once more on the perturbed position, for the whole wavefront (like the reference)
+    if (todo) {   // the chain once more on the perturbed position (like the reference), kept by the lanes that need it
       asm volatile("" ::: "memory");
 #pragma unroll 1
       for (int c = 0; c < 3; c++) {
@@ -692,7 +698,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
 #pragma unroll
         for (int d = 0; d < 3; d++) rp[d] = ((d == c) ? xb[M + 3 * xi + d] + dx : xb[M + 3 * xi + d]) * P.up;
         const PosPart pf = pos_part<false, NoSink, false>(rp, tb, 0.0);
-        GEL_AERO_POS_TAIL(c, rp, pf);
+        GEL_AERO_POS_TAIL(c, rp, pf, !((bad >> c) & 1u));
       }
     }
 #undef GEL_AERO_POS_TAIL
@@ -711,7 +717,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       const double wc[3] = {AP_GET(AP_W), AP_GET(AP_W + 1), AP_GET(AP_W + 2)};
       const double dc[3] = {AP_GET(AP_DIR), AP_GET(AP_DIR + 1), AP_GET(AP_DIR + 2)};
       const double nv2 = aero_vair2(r, vp, wc, a);
-      GEL_AERO_EMIT(3, 3, c, a, nv2, dc, AP_GET(AP_IND), AP_GET(AP_RHO), false, false);
+      GEL_AERO_EMIT(3, 3, c, a, nv2, dc, AP_GET(AP_IND), AP_GET(AP_RHO), false, false, false);
     }
     // ---- quaternion sweeps: only the body axis changes
     if (need_alpha && !(ROLES && sw != 0)) {
@@ -727,7 +733,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
         thrust_dir(qp, dp);
         const double indp = frsqrt(fmax(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2], 1.0e-300));
         const double ac[3] = {AP_GET(AP_A0), AP_GET(AP_A0 + 1), AP_GET(AP_A0 + 2)};
-        GEL_AERO_EMIT(6, 4, c, ac, AP_GET(AP_NV2), dp, indp, AP_GET(AP_RHO), true, false);
+        GEL_AERO_EMIT(6, 4, c, ac, AP_GET(AP_NV2), dp, indp, AP_GET(AP_RHO), true, false, false);
       }
     }
   }

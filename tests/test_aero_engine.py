@@ -267,3 +267,42 @@ def test_callback_form_of_the_aero_rows_equals_the_batch_form(flags):
             assert not t_block.any()                     # the exact value
         elif kind == "q":
             assert t_block.any()                         # the sweeps are run: rounding noise around zero, like the reference's
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B", [("mixed-6x64", 7), ("stress-12x128", 3), ("mixed-6x64", 130)])
+def test_flat_batch_mapping_equals_the_one_vector_calls(name, B):
+    """Batch launches take 64 consecutive (vector, node) entries per wavefront (325 constrained nodes per vector at mixed-6x64: a
+    wavefront straddles two vectors; calm tiles below 1 km and above 23 km skip the wind rotation): every vector's constraint
+    values and gradient values equal the bits of its own one-vector call (one tile per wavefront, the callback's form), through host
+    buffers and through device pointers; a values-only call leaves the gradient buffers alone."""
+    import torch
+    from gelato_amd import Engine, con_dynamics, pack_x, problem
+    pdict, unitdict, _c, xdict = problem.make_problem(name)
+    E = Engine(con_dynamics.problem_arrays(pdict, unitdict))
+    S = pdict["num_sections"]
+    for kind, lim in (("alpha", 0.2), ("q", 4.0e4), ("qalpha", 5.0e3)):
+        E.aero_configure(kind, [(i, 1, lim) for i in range(S - 1) if pdict["params"][i]["reference_area"] != 0.0])
+    nrows = sum(E.aero_dims(k)[0] for k in KINDS)
+    assert nrows // 3 >= 64 and (nrows // 3) % 64 != 0          # the flat mapping is what this batch takes
+    X = problem.synthetic_batch(pack_x(xdict), E.M, min(B, 9), seed=31)
+    X = np.tile(X, (B // len(X) + 1, 1))[:B]
+    con, jac, rc = E.eval_aero_all(X)
+    assert rc == 0
+    for b in sorted({0, 1, B // 2, B - 1}):
+        c1, j1, rc1 = E.eval_aero_all(X[b])
+        assert rc1 == 0
+        for kind in KINDS:
+            assert np.array_equal(con[kind][b], c1[kind][0]) and np.array_equal(jac[kind][b], j1[kind][0]), (kind, b)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    dX = torch.from_numpy(X).to(dev)
+    dims = [E.aero_dims(k) for k in KINDS]
+    dcon = [torch.full((B, d[0]), float("nan"), dtype=torch.float64, device=dev) for d in dims]
+    djac = [torch.full((B, sum(d[1])), float("nan"), dtype=torch.float64, device=dev) for d in dims]
+    E.eval_aero_all_device(B, dX.data_ptr(), [t.data_ptr() for t in dcon], None, s)
+    assert E.sync(s) == 0 and all(torch.isnan(t).all() for t in djac)
+    E.eval_aero_all_device(B, dX.data_ptr(), [t.data_ptr() for t in dcon], [t.data_ptr() for t in djac], s)
+    assert E.sync(s) == 0
+    for i, kind in enumerate(KINDS):
+        assert np.array_equal(dcon[i].cpu().numpy(), con[kind]) and np.array_equal(djac[i].cpu().numpy(), jac[kind])
