@@ -11,6 +11,8 @@ Same ``(xdict, pdict, unitdict, condition)`` signature; ``condition["AOA_max"]``
 does: keyed by section name, ``{"value": ..., "range": "all" | "initial"}``; sections are visited in order
 and the last one is never constrained (``range(num_sections - 1)``).
 """
+import copy
+
 import numpy as np
 
 from . import con_dynamics
@@ -44,7 +46,15 @@ def _spec(pdict, condition, kind):
 
 def _configured(pdict, unitdict, condition, kind):
     st = con_dynamics._state(pdict, unitdict)
+    # the kind's table is compared with a private deep copy of the one its key was last built from (one dict comparison instead
+    # of the loop over the sections, per kind and callback)
+    seen = st.__dict__.setdefault("aero_seen", {})
+    tab = condition.get(_KINDS[kind])
+    last = seen.get(kind)
+    if last is not None and tab == last[0]:
+        return st, last[1]
     key = _spec_key(pdict, condition, kind)
+    seen[kind] = (copy.deepcopy(tab), len(key))
     cache = st.__dict__.setdefault("aero_spec", {})
     if cache.get(kind) != key:
         st.engine.aero_configure(kind, np.array(key, dtype=np.float64).reshape(-1, 3))
@@ -100,10 +110,17 @@ def _jacobian(xdict, pdict, unitdict, condition, kind):
     pat, offs, shapes = meta
     share = pdict.get("gelato_amd_share_values")      # the engine's own value array (rewritten by the next evaluation) instead of copies
     vals = jv[kind]
+    if share:      # the block dicts hold views of the engine's array: built once per array, like con_dynamics.jacobians
+        made = st.__dict__.setdefault("aero_shared", {}).get(kind)
+        if made is not None and made[0] is vals and made[1] is meta:
+            return dict(made[2])
     jac = {}
     for v, var in enumerate(eng.AERO_VARS):
         a, b = offs[v]
         jac[var] = {"coo": [pat[v][0], pat[v][1], vals[a:b] if share else vals[a:b].copy()], "shape": shapes[v]}
+    if share:
+        st.aero_shared[kind] = (vals, meta, jac)
+        return dict(jac)
     return jac
 
 

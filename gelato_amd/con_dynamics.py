@@ -63,6 +63,7 @@ class _State:
         self._pinned_cond = None
         self._pinned_user = None
         self._pinned_aero = None
+        self._pinned_fr = None
         self._jd = None
         # two persistent packed-x buffers (and their ctypes pointers), used in turn: the one that is not the cached frame's receives
         # the next decision vector, so the frame's x stays intact for the comparison that decides whether the frame can be reused
@@ -78,6 +79,9 @@ class _State:
         the knot / terminal / user row table and the aero path constraints -- whatever is configured on the handle -- in
         ONE round trip (gel_eval_callback); the other functions of the callback read their share.  A derivative asked
         for after a values-only frame of the same xdict re-evaluates with derivatives."""
+        fr = self._pinned_fr
+        if fr is not None and xdict is self._pinned and (fr["jac"] or not need_jac) and self._frame_sig == self.engine._cfg_gen:
+            return fr                       # the callback's own frame: its status is in already
         fr = self._frame
         if xdict is self._pinned and self._pinned_x is not None:
             x = self._pinned_x
@@ -96,6 +100,8 @@ class _State:
         elif fr["x"] is not x and xdict is self._pinned:
             self._pinned_x = fr["x"]      # equal content: keep handing out the frame's own buffer for this callback
         self.status |= fr["rc"]             # also when the cached frame is handed out again
+        if xdict is self._pinned:
+            self._pinned_fr = fr
         return fr
 
     def residuals(self, xdict):
@@ -143,7 +149,7 @@ def begin_callback(pdict, xdict):
     if st is not None:
         st.status = 0
         st._pinned, st._pinned_x, st._pinned_cond = xdict, None, None
-        st._pinned_user = st._pinned_aero = None
+        st._pinned_user = st._pinned_aero = st._pinned_fr = None
         # the user module's device rows are registered BEFORE the first function of the callback asks for the row table
         # (equality_init comes before equality_user in objfunc): a table pinned without them would hand equality_user the
         # rows of another group
@@ -157,7 +163,7 @@ def end_callback(pdict):
     if st is None:
         return 0
     st._pinned, st._pinned_x, st._pinned_cond = None, None, None
-    st._pinned_user = st._pinned_aero = None
+    st._pinned_user = st._pinned_aero = st._pinned_fr = None
     return st.status
 
 

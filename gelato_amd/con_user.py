@@ -53,8 +53,12 @@ def _device_rows(pdict):
     m = _user()
     eq = list(getattr(m, "EQUALITY_ROWS", None) or ())
     ineq = list(getattr(m, "INEQUALITY_ROWS", None) or ())
+    last = pdict.get("gelato_amd_user_rows_seen")      # (eq, ineq) as they were when the rows were last registered
+    if last is not None and last[0] == eq and last[1] == ineq and "gelato_amd_user_rows" in pdict:
+        return eq, ineq
+    pdict["gelato_amd_user_rows_seen"] = ([tuple(r) for r in eq], [tuple(r) for r in ineq])   # (rows given as lists: compared in full every time)
     rows = tuple(tuple(r) for r in eq + ineq)
-    if tuple(tuple(r) for r in (pdict.get("gelato_amd_user_rows") or ())) != rows:
+    if "gelato_amd_user_rows" not in pdict or tuple(tuple(r) for r in (pdict["gelato_amd_user_rows"] or ())) != rows:
         pdict["gelato_amd_user_rows"] = rows
     return eq, ineq
 
