@@ -200,6 +200,33 @@ def test_con_aero_shim_like_reference():
     assert np.array_equal(funcs["ineqcon_alpha"], con_aero.inequality_max_alpha(xd, pdict, unitdict, full))
     assert funcs["ineqcon_qalpha"].shape == (17,) and list(fs["ineqcon_qalpha"]) == VARS
     assert "eqcon_dyn_vel" in funcs and "eqcon_dyn_vel" in fs
+    # a table edited IN PLACE between two calls is seen (the functions compare it with their own copy of the one last configured)
+    c17 = con_aero.inequality_max_qalpha(xd, pdict, unitdict, cond)
+    cond["Q_alpha_max"]["ZEROLIFT_START"]["range"] = "initial"
+    assert con_aero.inequality_length_max_qalpha(xd, pdict, unitdict, cond) == 1
+    c1 = con_aero.inequality_max_qalpha(xd, pdict, unitdict, cond)
+    assert c1.shape == (1,) and c1[0] == c17[0]
+    cond["Q_alpha_max"]["ZEROLIFT_START"]["value"] = 15000.0
+    ch = con_aero.inequality_max_qalpha(xd, pdict, unitdict, cond)
+    assert abs((1.0 - ch[0]) - 2.0 * (1.0 - c1[0])) <= 1e-12 * abs(1.0 - c1[0])      # con = 1 - q alpha / limit
+    cond["Q_alpha_max"]["MECO"] = {"value": 30000.0, "range": "initial"}
+    assert con_aero.inequality_length_max_qalpha(xd, pdict, unitdict, cond) == 2
+    del cond["Q_alpha_max"]["MECO"]
+    cond["Q_alpha_max"]["ZEROLIFT_START"].update(value=30000.0, range="all")
+    assert np.array_equal(con_aero.inequality_max_qalpha(xd, pdict, unitdict, cond), c17)
+    # shared value arrays: the block dicts are built once per configuration and follow the evaluations in place
+    fresh = con_aero.inequality_jac_max_qalpha(xd, pdict, unitdict, cond)
+    pdict["gelato_amd_share_values"] = True
+    sh1 = con_aero.inequality_jac_max_qalpha(xd, pdict, unitdict, cond)
+    xd2 = {k: v * (1.0 + 1e-7) for k, v in xd.items()}
+    sh2 = con_aero.inequality_jac_max_qalpha(xd2, pdict, unitdict, cond)
+    assert all(sh1[v]["coo"][2] is sh2[v]["coo"][2] for v in VARS) and sh1 is not sh2
+    assert not np.array_equal(sh2["velocity"]["coo"][2], fresh["velocity"]["coo"][2])
+    sh3 = con_aero.inequality_jac_max_qalpha(xd, pdict, unitdict, cond)
+    assert all(np.array_equal(sh3[v]["coo"][2], fresh[v]["coo"][2]) and not np.shares_memory(sh3[v]["coo"][2], fresh[v]["coo"][2]) for v in VARS)
+    cond["Q_alpha_max"]["ZEROLIFT_START"]["range"] = "initial"          # another configuration: new blocks, not the cached ones
+    sh4 = con_aero.inequality_jac_max_qalpha(xd, pdict, unitdict, cond)
+    assert sh4["velocity"]["coo"][2].size == 3 and sh4["velocity"]["shape"][0] == 1
 
 
 @pytest.mark.gpu
