@@ -94,6 +94,10 @@ SIGNATURES = {
     "gel_launch_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _ip]),
     "gel_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gel_jac_fd": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+    "gel_jac_fd_block_dims": (C.c_int, [C.c_void_p, C.c_int32, _lp, _lp, _lp, _lp]),
+    "gel_jac_fd_block_cols": (C.c_int, [C.c_void_p, C.c_int32, _ip]),
+    "gel_jac_fd_blocks": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+    "gel_jac_fd_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gel_aero_configure": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _ip, _ip, _dp]),
     "gel_aero_dims": (C.c_int, [C.c_void_p, C.c_int32, _ip, _lp]),
     "gel_aero_pattern": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _ip, _ip]),

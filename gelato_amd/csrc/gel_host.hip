@@ -359,6 +359,18 @@ int upload(T** d, const std::vector<T>& h) {
   return GEL_OK;
 }
 
+// global column of every local column of phase i as a one-phase problem: [mass n+1 | pos 3(n+1) | vel 3(n+1) | quat 4(n+1) | u 2n | t0 tf]
+static void phase_columns(const gel_problem* p, int i, std::vector<int32_t>& colmap) {
+  const HostPhase& h = p->ph[i];
+  const int n = h.n, M = (int)p->dims.M, N = (int)p->dims.N;
+  for (int k = 0; k <= n; k++) colmap.push_back(h.xa + k);                                  // mass
+  for (int k = 0; k < 3 * (n + 1); k++) colmap.push_back(M + 3 * h.xa + k);                  // position
+  for (int k = 0; k < 3 * (n + 1); k++) colmap.push_back(4 * M + 3 * h.xa + k);              // velocity
+  for (int k = 0; k < 4 * (n + 1); k++) colmap.push_back(7 * M + 4 * h.xa + k);              // quaternion
+  for (int k = 0; k < 2 * n; k++) colmap.push_back(11 * M + 2 * h.ua + k);                   // u
+  colmap.push_back(11 * M + 2 * N + i); colmap.push_back(11 * M + 2 * N + i + 1);            // t0, tf
+}
+
 #define NEED_DEVICE(p)                                                                              \
   do {                                                                                              \
     if ((p)->device == GEL_DEVICE_NONE)                                                             \
@@ -973,13 +985,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
       p->sub_nchunks.push_back(cnt);
       c0 += cnt;
       p->sub_col0.push_back((int32_t)colmap.size());
-      const int n = h.n;
-      for (int k = 0; k <= n; k++) colmap.push_back(h.xa + k);                                  // mass
-      for (int k = 0; k < 3 * (n + 1); k++) colmap.push_back(M + 3 * h.xa + k);                  // position
-      for (int k = 0; k < 3 * (n + 1); k++) colmap.push_back(4 * M + 3 * h.xa + k);              // velocity
-      for (int k = 0; k < 4 * (n + 1); k++) colmap.push_back(7 * M + 4 * h.xa + k);              // quaternion
-      for (int k = 0; k < 2 * n; k++) colmap.push_back(11 * M + 2 * h.ua + k);                   // u
-      colmap.push_back(11 * M + 2 * N + i); colmap.push_back(11 * M + 2 * N + i + 1);            // t0, tf
+      phase_columns(p, i, colmap);
     }
     if ((rc = upload(&p->d_subphases, sub)) || (rc = upload(&p->d_subchunks, subchunks)) || (rc = upload(&p->d_colmap, colmap))) {
       gel_problem_destroy(p);
@@ -1389,69 +1395,104 @@ int gel_sync(gel_problem* p, void* stream) {
   return GEL_OK;
 }
 
-int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) {
+// ---- generic forward difference, phase by phase (lib/jac_fd.py:29-62 on the four defect residuals) ----
+// working set: x, the perturbed local vectors of the LARGEST phase (reused phase after phase), the residuals of every phase's
+// perturbed vectors (kept while x stays the same: the four groups are asked for one after the other)
+static int jfd_allocate(gel_problem* p) {
+  if (p->jfd_x) return GEL_OK;
+  const size_t nv = (size_t)p->dims.num_vars;
+  size_t xp_max = 0, res_tot = 0;
+  p->sub_res0.clear();
+  for (int i = 0; i < p->dims.S; i++) {
+    const size_t n = p->ph[i].n, nloc = 13 * n + 13;
+    xp_max = std::max(xp_max, (nloc + 1) * nloc);
+    p->sub_res0.push_back(res_tot);
+    res_tot += (nloc + 1) * 11 * n;
+  }
+  if (hipMalloc((void**)&p->jfd_x, nv * 8) != hipSuccess || hipMalloc((void**)&p->jfd_Xp, xp_max * 8) != hipSuccess ||
+      hipMalloc((void**)&p->jfd_res, res_tot * 8) != hipSuccess) {
+    hipFree(p->jfd_x); hipFree(p->jfd_Xp); hipFree(p->jfd_res);
+    p->jfd_x = p->jfd_Xp = p->jfd_res = nullptr;   // all or nothing: a later call must not find a partial set
+    return fail(GEL_ERR_ALLOC, "gel_jac_fd: device allocation failed");
+  }
+  return GEL_OK;
+}
+
+// one residual evaluation per (phase, local column) of the vector at d_x: launches only
+static int jfd_evaluate(gel_problem* p, const double* d_x, hipStream_t s) {
+  for (int i = 0; i < p->dims.S; i++) {
+    const int n = p->ph[i].n, nloc = 13 * n + 13;
+    gel::ProblemDev dv = p->dev;   // the phase as a one-phase problem: same tables, D, tau; local index space
+    dv.S = 1; dv.N = n; dv.M = n + 1; dv.nvars = nloc; dv.V = 0;
+    dv.phases = p->d_subphases + i;
+    dv.chunks = p->d_subchunks + p->sub_chunk0[i]; dv.nchunks = p->sub_nchunks[i]; dv.chunk0 = 0;
+    HIPCHK(gel::launch_perturb_local(nloc, p->dx, d_x, p->d_colmap + p->sub_col0[i], p->jfd_Xp, s));
+    HIPCHK(gel::launch_eval(dv, nloc + 1, p->jfd_Xp, p->jfd_res + p->sub_res0[i], nullptr, s));
+  }
+  return GEL_OK;
+}
+
+static inline int jfd_w(int group) { return (group == 0) ? 1 : (group == 3) ? 4 : 3; }   // rows per node of the group
+
+// the group's quotients from the residuals of jfd_evaluate: dense [num_rows[group]][num_vars] (zeros, then every phase's block at its
+// rows and mapped columns) or the blocks alone, one after the other, [w n_i][13 n_i + 13] each; -> doubles written
+static int jfd_quotients(gel_problem* p, int group, int blocks, double* d_J, hipStream_t s, size_t* count) {
+  const size_t nv = (size_t)p->dims.num_vars, nrows = (size_t)p->dims.num_rows[group];
+  const int w = jfd_w(group);
+  if (!blocks) HIPCHK(hipMemsetAsync(d_J, 0, nrows * nv * 8, s));
+  size_t off = 0;
+  for (int i = 0; i < p->dims.S; i++) {
+    const int n = p->ph[i].n, nloc = 13 * n + 13;
+    const int roff_loc = (group == 0) ? 0 : (group == 1) ? n : (group == 2) ? 4 * n : 7 * n;
+    if (blocks)
+      HIPCHK(gel::launch_quotient_local(nloc, 11 * n, roff_loc, w * n, p->dx, p->jfd_res + p->sub_res0[i], d_J + off, (long long)nloc, 0,
+                                        nullptr, s));
+    else
+      HIPCHK(gel::launch_quotient_local(nloc, 11 * n, roff_loc, w * n, p->dx, p->jfd_res + p->sub_res0[i], d_J, (long long)nv,
+                                        w * p->ph[i].ua, p->d_colmap + p->sub_col0[i], s));
+    off += (size_t)w * n * nloc;
+  }
+  *count = blocks ? off : nrows * nv;
+  return GEL_OK;
+}
+
+static size_t jfd_block_doubles(const gel_problem* p, int group) {
+  size_t tot = 0;
+  for (int i = 0; i < p->dims.S; i++) tot += (size_t)jfd_w(group) * p->ph[i].n * (13 * (size_t)p->ph[i].n + 13);
+  return tot;
+}
+
+static int jfd_host(gel_problem* p, int32_t group, const double* x, double* J, int blocks) {
   if (!p || !x || !J || group < 0 || group >= GEL_NUM_GROUPS) return fail(GEL_ERR_ARG, "bad argument");
   NEED_DEVICE(p);
   HIPCHK(hipSetDevice(p->device));
   int rc = ensure_slots(p);  // the two pinned staging slots also carry J back to the caller
   if (rc) return rc;
+  if ((rc = jfd_allocate(p))) return rc;
   const size_t nv = (size_t)p->dims.num_vars, nrows = (size_t)p->dims.num_rows[group];
-  const int S = p->dims.S;
-  // working set: x, the perturbed local vectors of the LARGEST phase (reused phase after phase), the residuals of every
-  // phase's perturbed vectors (kept while x stays the same: the four groups are asked for one after the other), dense J
-  if (!p->jfd_x) {
-    size_t xp_max = 0, res_tot = 0;
-    p->sub_res0.clear();
-    for (int i = 0; i < S; i++) {
-      const size_t n = p->ph[i].n, nloc = 13 * n + 13;
-      xp_max = std::max(xp_max, (nloc + 1) * nloc);
-      p->sub_res0.push_back(res_tot);
-      res_tot += (nloc + 1) * 11 * n;
-    }
-    if (hipMalloc((void**)&p->jfd_x, nv * 8) != hipSuccess || hipMalloc((void**)&p->jfd_Xp, xp_max * 8) != hipSuccess ||
-        hipMalloc((void**)&p->jfd_res, res_tot * 8) != hipSuccess) {
-      hipFree(p->jfd_x); hipFree(p->jfd_Xp); hipFree(p->jfd_res);
-      p->jfd_x = p->jfd_Xp = p->jfd_res = nullptr;   // all or nothing: a later call must not find a partial set
-      return fail(GEL_ERR_ALLOC, "gel_jac_fd: device allocation failed");
-    }
-  }
-  if (p->jfd_J_cap < nrows * nv) {
+  const size_t need = blocks ? jfd_block_doubles(p, group) : nrows * nv;
+  if (p->jfd_J_cap < need) {
     hipFree(p->jfd_J);
     p->jfd_J = nullptr; p->jfd_J_cap = 0;
-    HIPCHK(hipMalloc((void**)&p->jfd_J, nrows * nv * 8));
-    p->jfd_J_cap = nrows * nv;
+    HIPCHK(hipMalloc((void**)&p->jfd_J, need * 8));
+    p->jfd_J_cap = need;
   }
-  // one residual evaluation per (phase, local column) -- unless the same x was just differenced
+  // the perturbed evaluations -- unless the same x was just differenced
   if (p->jfd_last_x.size() != nv || std::memcmp(p->jfd_last_x.data(), x, nv * 8) != 0) {
     p->jfd_last_x.clear();
     HIPCHK(hipMemcpyAsync(p->jfd_x, x, nv * 8, hipMemcpyHostToDevice, p->stream));
-    for (int i = 0; i < S; i++) {
-      const int n = p->ph[i].n, nloc = 13 * n + 13;
-      gel::ProblemDev dv = p->dev;   // the phase as a one-phase problem: same tables, D, tau; local index space
-      dv.S = 1; dv.N = n; dv.M = n + 1; dv.nvars = nloc; dv.V = 0;
-      dv.phases = p->d_subphases + i;
-      dv.chunks = p->d_subchunks + p->sub_chunk0[i]; dv.nchunks = p->sub_nchunks[i]; dv.chunk0 = 0;
-      HIPCHK(gel::launch_perturb_local(nloc, p->dx, p->jfd_x, p->d_colmap + p->sub_col0[i], p->jfd_Xp, p->stream));
-      HIPCHK(gel::launch_eval(dv, nloc + 1, p->jfd_Xp, p->jfd_res + p->sub_res0[i], nullptr, p->stream));
-    }
+    if ((rc = jfd_evaluate(p, p->jfd_x, p->stream))) return rc;
     HIPCHK(hipMemcpyAsync(p->h_flag, p->d_flag, 4, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     p->jfd_status = GEL_OK;
     if (*p->h_flag) { *p->h_flag = 0; HIPCHK(hipMemsetAsync(p->d_flag, 0, 4, p->stream)); p->jfd_status = GEL_NONFINITE; }
     p->jfd_last_x.assign(x, x + nv);
   }
-  // dense J of the group: zeros, then every phase's block of quotients at its rows and (mapped) columns
-  HIPCHK(hipMemsetAsync(p->jfd_J, 0, nrows * nv * 8, p->stream));
-  const int w = (group == 0) ? 1 : (group == 3) ? 4 : 3;                 // rows per node of the group
-  for (int i = 0; i < S; i++) {
-    const int n = p->ph[i].n, nloc = 13 * n + 13;
-    const int roff_loc = (group == 0) ? 0 : (group == 1) ? n : (group == 2) ? 4 * n : 7 * n;
-    HIPCHK(gel::launch_quotient_local(nloc, 11 * n, roff_loc, w * n, p->dx, p->jfd_res + p->sub_res0[i], p->jfd_J,
-                                      (long long)nv, w * p->ph[i].ua, p->d_colmap + p->sub_col0[i], p->stream));
-  }
+  size_t total = 0;
+  if ((rc = jfd_quotients(p, group, blocks, p->jfd_J, p->stream, &total))) return rc;
   HIPCHK(hipStreamSynchronize(p->stream));
   // J -> caller through the two pinned slots: D2H of piece i+1 overlaps the host copy of piece i
-  const size_t total = nrows * nv, piece = (size_t)p->pipe_evals * (size_t)std::max<int64_t>(p->dims.num_var_entries, 1);
+  const size_t piece = (size_t)p->pipe_evals * (size_t)std::max<int64_t>(p->dims.num_var_entries, 1);
   size_t pend_off[2] = {0, 0}, pend_n[2] = {0, 0};
   for (size_t off = 0, i = 0; off < total || pend_n[0] || pend_n[1]; i++) {
     gel_problem::Slot& sl = p->slot[i & 1];
@@ -1468,6 +1509,46 @@ int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) {
     }
   }
   return p->jfd_status;
+}
+
+int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J) { return jfd_host(p, group, x, J, 0); }
+
+int gel_jac_fd_blocks(gel_problem* p, int32_t group, const double* x, double* blocks) { return jfd_host(p, group, x, blocks, 1); }
+
+int gel_jac_fd_block_dims(const gel_problem* p, int32_t group, int64_t* rows, int64_t* cols, int64_t* row0, int64_t* offset) {
+  if (!p || group < 0 || group >= GEL_NUM_GROUPS) return fail(GEL_ERR_ARG, "bad argument");
+  int64_t off = 0;
+  for (int i = 0; i < p->dims.S; i++) {
+    const int64_t r = (int64_t)jfd_w(group) * p->ph[i].n, c = 13 * (int64_t)p->ph[i].n + 13;
+    if (rows) rows[i] = r;
+    if (cols) cols[i] = c;
+    if (row0) row0[i] = (int64_t)jfd_w(group) * p->ph[i].ua;
+    if (offset) offset[i] = off;
+    off += r * c;
+  }
+  if (offset) offset[p->dims.S] = off;
+  return GEL_OK;
+}
+
+int gel_jac_fd_block_cols(const gel_problem* p, int32_t phase, int32_t* cols) {
+  if (!p || !cols || phase < 0 || phase >= p->dims.S) return fail(GEL_ERR_ARG, "bad argument");
+  std::vector<int32_t> c;
+  phase_columns(p, phase, c);
+  std::memcpy(cols, c.data(), sizeof(int32_t) * c.size());
+  return GEL_OK;
+}
+
+int gel_jac_fd_device(gel_problem* p, int32_t group, const double* d_x, double* d_J, int32_t blocks, void* stream) {
+  if (!p || !d_x || !d_J || group < 0 || group >= GEL_NUM_GROUPS) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  HIPCHK(hipSetDevice(p->device));
+  int rc = jfd_allocate(p);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  p->jfd_last_x.clear();   // the residuals kept for gel_jac_fd's host callers are overwritten
+  if ((rc = jfd_evaluate(p, d_x, s))) return rc;
+  size_t total = 0;
+  return jfd_quotients(p, group, blocks ? 1 : 0, d_J, s, &total);
 }
 
 // --------------------------- RHS / point hooks ---------------------------

@@ -173,7 +173,7 @@ __global__ void perturb_local_kernel(int nloc, double dx, const double* __restri
   Xp[t] = v;
 }
 
-// J[(row0 + r) * ldJ + colmap[c]] = (res[c + 1][roff + r] - res[0][roff + r]) / dx     (tiled transpose through LDS)
+// J[(row0 + r) * ldJ + colmap[c]] = (res[c + 1][roff + r] - res[0][roff + r]) / dx     (tiled transpose through LDS; no colmap: c itself)
 __global__ void quotient_local_kernel(int nloc, int nres, int roff, int nrows, double dx, const double* __restrict__ res,
                                       double* __restrict__ J, long long ldJ, int row0, const int32_t* __restrict__ colmap) {
   __shared__ double tile[32][33];
@@ -185,7 +185,7 @@ __global__ void quotient_local_kernel(int nloc, int nres, int roff, int nrows, d
   __syncthreads();
   for (int k = threadIdx.y; k < 32; k += blockDim.y) {  // write: column fast (local columns of one variable are contiguous globally)
     const int r = r0 + k, c = c0 + threadIdx.x;
-    if (c < nloc && r < nrows) J[(size_t)(row0 + r) * ldJ + colmap[c]] = (tile[threadIdx.x][k] - res[roff + r]) / dx;
+    if (c < nloc && r < nrows) J[(size_t)(row0 + r) * ldJ + (colmap ? colmap[c] : c)] = (tile[threadIdx.x][k] - res[roff + r]) / dx;
   }
 }
 

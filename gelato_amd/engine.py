@@ -337,6 +337,34 @@ class Engine:
         rc = check(lib().gel_jac_fd(self._h, gi, _d(x), _d(J)))
         return J, rc
 
+    def jac_fd_block_dims(self, group):
+        """-> (rows [S], cols [S], row0 [S], offset [S + 1]) of the group's per-phase blocks, (cols of phase i: global column of each
+        local column) -- the phase's rows see only these columns (every other column of lib/jac_fd.py's dense result is zero)."""
+        key = ("jfd_dims", group)
+        if key not in self.__dict__:
+            S = self.S
+            r, c, r0, off = (np.zeros(S + (1 if k == 3 else 0), dtype=np.int64) for k in range(4))
+            check(lib().gel_jac_fd_block_dims(self._h, GROUPS.index(group), *(a.ctypes.data_as(C.POINTER(C.c_int64)) for a in (r, c, r0, off))))
+            cols = []
+            for i in range(S):
+                ci = np.zeros(int(c[i]), dtype=np.int32)
+                check(lib().gel_jac_fd_block_cols(self._h, i, ci.ctypes.data_as(_ip)))
+                cols.append(ci)
+            self.__dict__[key] = (r, c, r0, off, cols)
+        return self.__dict__[key]
+
+    def jac_fd_blocks(self, group, x):
+        """the group's forward-difference Jacobian as per-phase blocks: [(row0, global cols, block [rows, cols])], rc"""
+        r, c, r0, off, cols = self.jac_fd_block_dims(group)
+        x = _f64(x)
+        buf = np.empty(int(off[-1]))
+        rc = check(lib().gel_jac_fd_blocks(self._h, GROUPS.index(group), _d(x), _d(buf)))
+        return [(int(r0[i]), cols[i], buf[int(off[i]):int(off[i + 1])].reshape(int(r[i]), int(c[i]))) for i in range(self.S)], rc
+
+    def jac_fd_device(self, group, d_x, d_J, blocks=False, stream=0):
+        """device pointers (ints): x [nvars] -> dense J [nrows[group]][nvars] or the blocks (jac_fd_block_dims), all in HBM"""
+        check(lib().gel_jac_fd_device(self._h, GROUPS.index(group), d_x, d_J, 1 if blocks else 0, stream or None))
+
     # ---- aero path constraints (lib/con_aero.py): kind in AERO_KINDS ----
     AERO_KINDS = ["alpha", "q", "qalpha"]
     AERO_VARS = ["position", "velocity", "quaternion", "t"]

@@ -17,7 +17,7 @@ depend on, lib/jac_fd.py:54-60).
 import numpy as np
 
 from . import con_dynamics
-from .engine import XKEYS, pack_x
+from .engine import GROUPS, XKEYS, pack_x
 
 
 def _jac_fd_user_callable(con, xdict, pdict, unitdict, condition):
@@ -42,7 +42,15 @@ def jac_fd(con, xdict, pdict, unitdict, condition):
     if group is None:
         return _jac_fd_user_callable(con, xdict, pdict, unitdict, condition)
     eng = con_dynamics.engine_of(pdict, unitdict)
-    J, rc = eng.jac_fd(group, pack_x(xdict))
+    # a phase's rows see only the phase's own columns: the quotients cross PCIe as per-phase blocks (a sixth of the dense matrix at
+    # 6 x 64) and are laid into the zero matrices here
+    blocks, rc = eng.jac_fd_blocks(group, pack_x(xdict))
     con_dynamics.note_status(pdict, rc)
+    J = np.zeros((eng.nrows[GROUPS.index(group)], eng.nvars))
+    for row0, cols, blk in blocks:
+        # the local columns of one variable are consecutive globally: six slices per phase
+        edges = np.flatnonzero(np.diff(cols) != 1) + 1
+        for a, b in zip(np.concatenate([[0], edges]), np.concatenate([edges, [len(cols)]])):
+            J[row0:row0 + blk.shape[0], cols[a]:cols[a] + (b - a)] = blk[:, a:b]
     cols = eng.split_x(range(eng.nvars))
     return {k: J[:, cols[k].start:cols[k].stop] for k in XKEYS if k in xdict}

@@ -218,6 +218,19 @@ int gel_sync(gel_problem* p, void* stream); /* waits; returns GEL_NONFINITE if a
  *      applied to the four defect residuals; used as the cross-check of the
  *      structured Jacobians).  J [num_rows[group]][num_vars], row-major. ---- */
 int gel_jac_fd(gel_problem* p, int32_t group, const double* x, double* J);
+/* The same quotients without the zeros.  Each phase's rows see only the phase's own 13 n + 13 columns (every other column of
+ * the reference's dense result, lib/jac_fd.py:54-60, is an exact zero): block i = [rows[i] = w n_i][cols[i] = 13 n_i + 13],
+ * row-major, at offset[i] doubles of `blocks` (offset[S] = total), its first row at row row0[i] of the group, its local column c
+ * at global column gel_jac_fd_block_cols(phase)[c] (local layout [mass n+1 | position 3(n+1) | velocity 3(n+1) | quaternion
+ * 4(n+1) | u 2n | t0 tf]).  6 x 64, velocity rows: 7.8 MB instead of 46.7 MB across PCIe. */
+int gel_jac_fd_block_dims(const gel_problem* p, int32_t group, int64_t* rows /* [S] or NULL */, int64_t* cols /* [S] or NULL */,
+                          int64_t* row0 /* [S] or NULL */, int64_t* offset /* [S + 1] or NULL */);
+int gel_jac_fd_block_cols(const gel_problem* p, int32_t phase, int32_t* cols /* [13 n + 13] */);
+int gel_jac_fd_blocks(gel_problem* p, int32_t group, const double* x, double* blocks /* [offset[S]] */);
+/* Device-resident form: x and the result stay in HBM (blocks = 0: dense [num_rows[group]][num_vars]; 1: the blocks), launches
+ * only, on `stream` (NULL = the handle's); NaN / Inf is reported by the next gel_sync.  One call in flight per handle (the
+ * perturbed vectors and their residuals live in the handle). */
+int gel_jac_fd_device(gel_problem* p, int32_t group, const double* d_x, double* d_J, int32_t blocks, void* stream);
 
 /* ---- aero path constraints (replace lib/con_aero.py:90-252 inequality_max_alpha /
  *      _q / _qalpha, :254-309 inequality_length_*, :311-756 inequality_jac_max_*).

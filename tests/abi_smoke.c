@@ -98,8 +98,18 @@ int main(int argc, char** argv) {
   double* x = malloc(sizeof(double) * dm.num_vars);
   double* res = malloc(sizeof(double) * 11 * dm.N);
   double* vals = malloc(sizeof(double) * dm.total_nnz);
+  /* the forward-difference blocks: described by any handle */
+  int64_t brow[2], bcol[2], brow0[2], boff[3];
+  CHECK(gel_jac_fd_block_dims(p, 2, brow, bcol, brow0, boff) == GEL_OK && brow[0] == 15 && bcol[0] == 78 && brow0[1] == 15 &&
+        boff[2] == boff[1] + brow[1] * bcol[1]);
+  {
+    int32_t bc[78];
+    CHECK(gel_jac_fd_block_cols(p, 0, bc) == GEL_OK && bc[0] == 0 && bc[6] == dm.M && bc[77] == dm.num_vars - 2);
+    CHECK(gel_jac_fd_block_cols(p, 2, bc) == GEL_ERR_ARG);
+  }
   if (!gpu) {
     CHECK(gel_eval_residual(p, x, res) == GEL_ERR_HIP); /* host-only handles never evaluate */
+    CHECK(gel_jac_fd_blocks(p, 2, x, vals) == GEL_ERR_HIP && gel_jac_fd_device(p, 2, x, vals, 1, NULL) == GEL_ERR_HIP);
     CHECK(gel_eval_shard_packed_device(p, 1, x, res, 0, 1, 2, NULL) == GEL_ERR_HIP);
     {
       static double tx[77], table[77 * GEL_OUTPUT_COLUMNS];
@@ -127,6 +137,19 @@ int main(int argc, char** argv) {
   for (int64_t k = 0; k < dm.total_nnz; k++) CHECK(isfinite(vals[k]));
   /* phase 0 is a hold phase: its quaternion defect is q[j+1] - q[0] = 0 for this constant attitude */
   for (int j = 0; j < 5 * 4; j++) CHECK(res[7 * N + j] == 0.0);
+  {
+    /* velocity rows by forward difference: the blocks are the dense matrix without its zeros */
+    double* J = calloc((size_t)3 * N * dm.num_vars, sizeof(double));
+    double* blk = malloc(sizeof(double) * boff[2]);
+    int32_t bc[13 * 70 + 13];
+    CHECK(gel_jac_fd(p, 2, x, J) == GEL_OK && gel_jac_fd_blocks(p, 2, x, blk) == GEL_OK);
+    for (int ph = 0; ph < 2; ph++) {
+      CHECK(gel_jac_fd_block_cols(p, ph, bc) == GEL_OK);
+      for (int64_t r = 0; r < brow[ph]; r++)
+        for (int64_t c = 0; c < bcol[ph]; c++) CHECK(blk[boff[ph] + r * bcol[ph] + c] == J[(brow0[ph] + r) * dm.num_vars + bc[c]]);
+    }
+    free(J); free(blk);
+  }
   /* a NaN in x is reported, not swallowed */
   x[M + 4] = NAN;
   CHECK(gel_eval_residual(p, x, res) == GEL_NONFINITE);

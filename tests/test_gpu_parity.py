@@ -690,6 +690,30 @@ def test_jac_fd_vs_golden_oracle_and_structured():
             r, c, v = blk["coo"]
             dense[r, c + off[var]] += v
         assert np.max(np.abs(dense - J)) <= 1e-5         # structured COO == generic FD
+        # the same quotients without the zeros: per-phase blocks, to the host and resident on the device -- the dense matrix's bits
+        import torch
+        blocks, rcb = E.jac_fd_blocks(grp, x)
+        assert rcb == 0
+        rebuilt = np.zeros_like(J)
+        r_, c_, r0_, off_, cols_ = E.jac_fd_block_dims(grp)
+        assert int(off_[-1]) == sum(b.size for _, _, b in blocks) and sum(int(v) for v in r_) == J.shape[0]
+        for row0, cols, blk in blocks:
+            assert len(set(cols.tolist())) == len(cols)
+            rebuilt[row0:row0 + blk.shape[0], cols] = blk
+        assert np.array_equal(rebuilt, J)
+        dev = torch.device("cuda:0")
+        s = torch.cuda.current_stream().cuda_stream
+        dx_ = torch.from_numpy(x).to(dev)
+        dJ = torch.full(J.shape, float("nan"), dtype=torch.float64, device=dev)
+        E.jac_fd_device(grp, dx_.data_ptr(), dJ.data_ptr(), False, s)
+        assert E.sync(s) == 0 and np.array_equal(dJ.cpu().numpy(), J)
+        dB = torch.full((int(off_[-1]),), float("nan"), dtype=torch.float64, device=dev)
+        E.jac_fd_device(grp, dx_.data_ptr(), dB.data_ptr(), True, s)
+        assert E.sync(s) == 0
+        hb = dB.cpu().numpy()
+        assert all(np.array_equal(hb[int(off_[i]):int(off_[i + 1])].reshape(blk.shape), blk) for i, (_, _, blk) in enumerate(blocks))
+        J2, _ = E.jac_fd(grp, x)                        # the host form after a device call (its kept residuals were overwritten)
+        assert np.array_equal(J2, J)
 
 
 # --------------------------------------------------------------------------

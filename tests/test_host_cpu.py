@@ -244,3 +244,30 @@ def test_a_replaced_shard_plan_is_refused_not_used():
     sh2b.check_current(); sh2.check_current()
     with pytest.raises(RuntimeError, match="replaced"):
         sh8.check_current()
+
+
+@pytest.mark.parametrize("name", ["example", "mixed-6x64", "stress-12x128"])
+def test_jac_fd_blocks_cover_the_reference_pattern(name):
+    """gel_jac_fd_blocks leaves out only exact zeros: every (row, column) of the reference's own sparsity pattern of a group
+    (lib/con_dynamics.py:75-76,108-113) lies inside the block of the row's phase; blocks tile the group's rows; a phase's columns are
+    its own state nodes, controls and knot times."""
+    from gelato_amd.engine import BLOCKS, GROUPS
+    pdict, unitdict, _c, xdict = problem.make_problem(name)
+    pdict["device"] = -1
+    E = con_dynamics.engine_of(pdict, unitdict)
+    voff = {"mass": 0, "position": E.M, "velocity": 4 * E.M, "quaternion": 7 * E.M, "u": 11 * E.M, "t": 11 * E.M + 2 * E.N}
+    pat = E.pattern()
+    for gi, grp in enumerate(GROUPS):
+        rows, cols, row0, off, cmap = E.jac_fd_block_dims(grp)
+        assert row0[0] == 0 and np.array_equal(row0[1:], np.cumsum(rows)[:-1]) and int(rows.sum()) == E.nrows[gi]
+        assert np.array_equal(off, np.concatenate([[0], np.cumsum(rows * cols)]))
+        n = np.asarray(E.num_nodes)
+        assert np.array_equal(cols, 13 * n + 13) and all(len(set(c.tolist())) == len(c) and c.max() < E.nvars for c in cmap)
+        phase_of_row = np.repeat(np.arange(E.S), rows)
+        inside = [set(c.tolist()) for c in cmap]
+        for b, (g, var) in enumerate(BLOCKS):
+            if g != grp:
+                continue
+            r, c = pat[b]
+            assert all((int(ci) + voff[var]) in inside[phase_of_row[int(ri)]] for ri, ci in zip(r[::7], c[::7]))
+    assert int(off[-1]) * 2 < E.nrows[3] * E.nvars                   # equal phases: 1/S of the dense matrix (0.167 at 6 x 64)

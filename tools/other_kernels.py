@@ -97,6 +97,24 @@ def main():
     dt = (time.perf_counter() - t0) / 3
     out["jac_fd_vel"] = {"wall_ms": 1e3 * dt, "rows": int(J.shape[0]), "columns": int(J.shape[1]),
                          "dense_bytes_to_host": int(J.nbytes)}
+    # the same quotients as per-phase blocks (host arrays out), and resident on the device (dense and blocks)
+    x1 = x0 * (1.0 + 1e-9)
+    E.jac_fd_blocks("vel", x0)
+    t0 = time.perf_counter()
+    for i in range(3):
+        blocks, _ = E.jac_fd_blocks("vel", x0 if i & 1 else x1)          # a new x every call: the perturbed evaluations are run
+    dtb = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    for i in range(3):
+        J, _ = E.jac_fd("vel", x0 if i & 1 else x1)
+    dtd = (time.perf_counter() - t0) / 3
+    nb = sum(b.nbytes for _, _, b in blocks)
+    dx1 = torch.from_numpy(x0).to(dev)
+    dJ = torch.empty(J.shape, dtype=torch.float64, device=dev)
+    msd = ev(lambda: E.jac_fd_device("vel", dx1.data_ptr(), dJ.data_ptr(), False, s), 5)
+    msb = ev(lambda: E.jac_fd_device("vel", dx1.data_ptr(), dJ.data_ptr(), True, s), 5)
+    out["jac_fd_vel"].update({"note": "wall_ms: the same x again (residuals kept)", "new_x_dense_wall_ms": 1e3 * dtd, "new_x_blocks_wall_ms": 1e3 * dtb,
+                              "block_bytes_to_host": int(nb), "device_resident_dense_ms": msd, "device_resident_blocks_ms": msb})
     print(json.dumps(out))
 
 
