@@ -66,12 +66,15 @@ struct LinRowDev { int32_t idx0, idx1; double coef0, coef1, c0; };  // (coef0 x[
 // difference: bit 2 clear: (value(x + dx e_c) - value(x)) / dx;  set: ((f(x + dx e_c) - f(x)) / dx) / p[0], negated with bit 3
 struct FnRowDev { int32_t fn, node, tcol, mode; double p[8]; };
 
+constexpr int kLongPhaseFrom = 68;   // phases of this many nodes and more take the slab loop of the cooperative form (gel_eval_kernel.h)
+
 struct ProblemDev {
   int32_t S, N, M, nvars;
   int32_t Kw, Kc;
   int32_t nchunks;           // sum over phases of ceil(n/64): wavefront work items per eval
   int32_t use_mfma;          // D.X on v_mfma_f64_16x16x4_f64 instead of VALU FMAs
   int32_t pack;              // every phase has at most 32 nodes: the cooperative form carries two decision vectors per wavefront
+  int32_t longp;             // some phase has kXldsPipeFrom (68) nodes or more: the cooperative form with the slab loop
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
   int32_t unit0, nunits;     // split form only: first unit and number of units (unit = 4 * work item + part)
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)

@@ -45,18 +45,18 @@ static_assert(kWaveLds >= 64 * kStageLd, "the MFMA staging tile must fit the wav
 // wavefronts of its workgroup still write their tiles.
 constexpr int kCoopStageOff = PK_LV0 * 64;
 static_assert(kWaveLds - kCoopStageOff >= 64 * 11, "the cooperative hand-over area must fit behind the early park slots");
-constexpr int kXldsPipeFrom = 68;  // phases of this many nodes and more: state rows in double-buffered 44-row LDS slabs (below: one slab, staged at once)
+constexpr int kXldsPipeFrom = kLongPhaseFrom;  // phases of this many nodes and more: state rows in double-buffered 44-row LDS slabs (below: one slab, staged at once)
 // Residual-only instantiations park PK_Q0 .. PK_LV2 only: their region is the D.X operand image (cooperative LDS-staged
 // form: a 68-row slab, or two 36-row vectors when two decision vectors share a wavefront), the hand-over area over it and
 // then, once the wavefront has taken its rows, the park over that -- 6 KB instead of 9.5 KB per wavefront.
 constexpr int kSlabRowsMax = 68, kPackRows = 36, kParkRes = (PK_LV2 + 1) * 64;
-constexpr int kPipeSlabK = 11;   // k-steps per double-buffered slab of the long-phase form (44 state rows)
-constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack, bool split = false) {
-  return jac ? kWaveLds : (!mfma ? kParkRes : (split ? 64 * kStageLd /* one wavefront's own result tile */ : (pack ? kParkRes + 4 * 64 /* operand image (792), then park + the tile of the transposed residual stores */ : 2 * 4 * kPipeSlabK * 11)));
+constexpr int kPipeSlabK = 8;    // k-steps per double-buffered slab of the long-phase form (32 state rows)
+constexpr int wave_lds_doubles(bool jac, bool mfma, bool pack, bool split = false, bool longp = true) {
+  return jac ? kWaveLds : (!mfma ? kParkRes : (split ? 64 * kStageLd /* one wavefront's own result tile */ : (pack ? kParkRes + 4 * 64 /* operand image (792), then park + the tile of the transposed residual stores */ : (longp ? 2 * 4 * kPipeSlabK * 11 + 64 * kPipeSlabK /* two images of a slab's state rows + the A ring */ : kSlabRowsMax * 11))));
 }
 static_assert(wave_lds_doubles(false, true, false, true) >= kParkRes, "residual-only split form: park over the result tile");
-static_assert(wave_lds_doubles(false, true, true) >= 64 * 11 && wave_lds_doubles(false, true, false) >= 64 * 11, "hand-over area");
-static_assert(wave_lds_doubles(false, true, true) >= kParkRes && wave_lds_doubles(false, true, false) >= kParkRes, "residual-only park");
+static_assert(wave_lds_doubles(false, true, true) >= 64 * 11 && wave_lds_doubles(false, true, false) >= 64 * 11 && wave_lds_doubles(false, true, false, false, false) >= 64 * 11, "hand-over area");
+static_assert(wave_lds_doubles(false, true, true) >= kParkRes && wave_lds_doubles(false, true, false) >= kParkRes && wave_lds_doubles(false, true, false, false, false) >= kParkRes, "residual-only park");
 
 // Compact Jacobian slots of a node (gel_host.hip walk_pattern() maps them to the reference's COO entries).  Only
 // DISTINCT x-dependent values are stored: a tf column that is the exact negative of its t0 column, the node-uniform
@@ -115,7 +115,7 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 // that are not cooperative a workgroup may have any number of wavefronts (each its own work item).
 // SPLITB (split form): k-steps of D.X whose state column is requested at once -- 17 (a whole 64-node phase) inside callback_kernel,
 // which has registers to spare; 9 in the stand-alone launch, which is held to 128 VGPRs.
-template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, int SPLITB = 9>
+template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, int SPLITB = 9, bool LONGP = true>
 __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const double* __restrict__ x, double* __restrict__ res,
                                           double* __restrict__ jvar, const unsigned vblk) {
   extern __shared__ double lds[];
@@ -130,7 +130,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   const int lane = threadIdx.x & 63;
   // explicit LDS address space: ds_read/ds_write (lgkmcnt), never flat_* (which also ticks vmcnt)
   typedef __attribute__((address_space(3))) double lds_double;
-  constexpr int kWL = wave_lds_doubles(JAC, MFMA, PACK, SPLIT);   // this instantiation's region per wavefront
+  constexpr int kWL = wave_lds_doubles(JAC, MFMA, PACK, SPLIT, LONGP);   // this instantiation's region per wavefront
   constexpr int kHO = JAC ? kCoopStageOff : 0;             // where the cooperative hand-over area starts in it
   static_assert(!(MFMA && !SPLIT) || kWL - kHO >= 64 * 11, "the cooperative hand-over area must fit the region");
   lds_double* wave_lds = (lds_double*)lds + park_off + (threadIdx.x >> 6) * kWL;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     // D.X rows (lib/con_dynamics.py:54,146,256,524)
     double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
     if (rb) {
-      if (XLDS && (PACK || n < kXldsPipeFrom)) {
+      if (XLDS && (PACK || !LONGP || n < kXldsPipeFrom)) {   // !LONGP: the launcher vouches that no phase is longer
         // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP, operands as in the branch below, but B comes from LDS: every wavefront
         // stages ITS OWN vector's n + 1 <= 68 state rows (17 k-steps) -- lane = row, the eleven interleaved columns (mass |
         // pos xyz | vel xyz | quat wxyz) side by side, [row][11] at the start of its region -- and all four read the 44
@@ -600,81 +600,133 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #pragma unroll
         for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
       } else if (XLDS) {
-        // Longer phases (kXldsPipeFrom nodes and more): the LDS-staged product in slabs of 44 state rows (11 k-steps), double
-        // buffered -- the rows of slab s + 1 are requested before slab s is multiplied and written to the other buffer after,
-        // one workgroup barrier per slab.  11 row-coalesced loads per wavefront and slab instead of 3 scattered 8-byte
-        // loads per lane and k-step (the texture addresser sees ~5x fewer line accesses at 128 nodes).
+        // Longer phases (kXldsPipeFrom nodes and more): the product in slabs of 32 state rows (8 k-steps) with BOTH operands
+        // brought into LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) --
+        //   * the state rows of slab s + 1, per vector as they lie in x, [mass R | position 3R | velocity 3R | quaternion 4R]
+        //     (R = 32 rows: 176 contiguous 16-byte pieces, three instructions per wavefront), into the other of two images
+        //     while slab s is multiplied;
+        //   * the A operands in a ring of one slab's k-steps (this wavefront's row tile, 512 B per k-step, two k-steps per
+        //     instruction): a pair of slots is refilled with the next slab's values as soon as it has been multiplied, a whole
+        //     slab before it is needed.
+        // Vector-memory results return in order; the register-staged form before this one requested the A operand one k-step
+        // ahead, behind the next slab's state rows (HBM), and the compiler -- unable to count across the lane-conditional
+        // staging loads -- waited for every outstanding load before every k-step (upper bound of those stalls at 12 x 128:
+        // 21 % of the launch).  Here nothing the compiler tracks is in flight: the waits are counted by hand (queue order:
+        // refills of the previous slab, three row pieces, refills of this slab), the barrier is the bare instruction.
         const int c16 = lane & 15, kq = lane >> 4;
         constexpr int kPipeK = kPipeSlabK, kPipeRows = 4 * kPipeK, kPipeBuf = kPipeRows * 11;
-        static_assert(!COOP || PACK || 2 * kPipeBuf <= kWL, "two slab buffers must fit the wave's region");
+        constexpr int kRingOff = 2 * kPipeBuf, kPairs = kPipeK / 2;
+        static_assert(kPipeK == 8, "the piece tables below are written for 32-row slabs");
+        static_assert(!COOP || PACK || !LONGP || kRingOff + 64 * kPipeK <= kWL, "two images and the A ring must fit the wave's region");
+        constexpr int kBP = kPipeRows, kBV = 4 * kPipeRows, kBQ = 7 * kPipeRows;   // blocks of an image
         lds_double* regions = (lds_double*)lds + park_off;
-        int xoff[3];
+        int xoff[3], xstr[3];
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
           const int c = 16 * ct + c16;
-          const int vb = min(c / 11, 3);
-          xoff[ct] = vb * kWL + ((c < 44) ? c - 11 * vb : 0) + kq * 11;
+          const int vb = min(c / 11, 3), col = (c < 44) ? c - 11 * vb : 0;
+          const int base = (col == 0) ? 0 : ((col < 4) ? kBP + col - 1 : ((col < 7) ? kBV + col - 4 : kBQ + col - 7));
+          const int stride = (col == 0) ? 1 : ((col < 7) ? 3 : 4);
+          xoff[ct] = vb * kWL + base + stride * kq;      // row kq of the lane's column
+          xstr[ct] = stride;                             // doubles from a row of the column to the next
         }
         gel_double4 acc[3];
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
-        const double* ap = P.Dst + (size_t)dsw * 4 + wv * 64 + lane;
+        typedef const __attribute__((address_space(1))) void* gel_gptr;
+        typedef __attribute__((address_space(3))) void* gel_lptr;
+        // piece tables: 16-byte piece 64 i + lane of an image <- doubles s_i + slab * a_i of this vector
+        const int xa0 = ph.xa;
+        const int s0 = (lane < 16) ? xa0 + 2 * lane : M + 3 * xa0 + 2 * (lane - 16);
+        const int s1 = (lane < 48) ? 4 * M + 3 * xa0 + 2 * lane : 7 * M + 4 * xa0 + 2 * (lane - 48);
+        const int s2 = 7 * M + 4 * xa0 + 2 * (16 + lane);
+        const int a0 = (lane < 16) ? kPipeRows : 3 * kPipeRows, a1 = (lane < 48) ? 3 * kPipeRows : 4 * kPipeRows, a2 = 4 * kPipeRows;
+#define GEL_PIPE_ROWS(slab, buf)                                                                                   \
+  do {                                                                                                             \
+    lds_double* _img = wave_lds + (buf) * kPipeBuf;                                                                \
+    __builtin_amdgcn_global_load_lds((gel_gptr)(xb + s0 + (slab) * a0), (gel_lptr)_img, 16, 0, 0);                 \
+    __builtin_amdgcn_global_load_lds((gel_gptr)(xb + s1 + (slab) * a1), (gel_lptr)(_img + 128), 16, 0, 0);         \
+    if (lane < 48) __builtin_amdgcn_global_load_lds((gel_gptr)(xb + s2 + (slab) * a2), (gel_lptr)(_img + 256), 16, 0, 0); \
+  } while (0)
+        // A operands: Dst[((item + k) * 4 + row tile) * 64 + lane]; lanes 0..31 fetch k-step k, lanes 32..63 k-step k + 1
+        const double* ap2 = P.Dst + (size_t)dsw * 4 + wv * 64 + (lane & 31) * 2;
+        const int khalf = lane >> 5, kmax = ((n + 4) >> 2) - 1;          // the host lays down (n + 4) / 4 k-steps per work item
+#define GEL_PIPE_A(pair, k)                                                                                        \
+  __builtin_amdgcn_global_load_lds((gel_gptr)(ap2 + (size_t)min((k) + khalf, kmax) * 256), (gel_lptr)(wave_lds + kRingOff + 128 * (pair)), 16, 0, 0)
+#define GEL_PIPE_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+        GEL_PIPE_ROWS(0, 0);
+#pragma unroll
+        for (int pr = 0; pr < kPairs; pr++) GEL_PIPE_A(pr, 2 * pr);
+        stage_tables_commit(P, lds, tab_mine);
+        GEL_PIPE_WAIT(0);
+        __syncthreads();
         const int nslab = (((n + 4) >> 2) + kPipeK - 1) / kPipeK;   // slabs that hold rows 0 .. n (the tail row and the last node's own row included)
         const int own = jc + 1;
-        double st[11];
-        const bool stager = lane < kPipeRows;
-#define GEL_PIPE_LOAD(slab)                                                              \
-  do {                                                                                   \
-    const int _k = (slab) * kPipeRows + lane;                                            \
-    const bool _in = stager && _k <= n;                                                  \
-    const int _xk = ph.xa + (_in ? _k : 0);                                              \
-    st[0] = _in ? xm[_xk] : 0.0;                                                         \
-    _Pragma("unroll") for (int c = 0; c < 3; c++) { st[1 + c] = _in ? xr[3 * _xk + c] : 0.0; st[4 + c] = _in ? xv[3 * _xk + c] : 0.0; } \
-    _Pragma("unroll") for (int c = 0; c < 4; c++) st[7 + c] = _in ? xq[4 * _xk + c] : 0.0; \
-  } while (0)
-#define GEL_PIPE_WRITE(buf)                                                              \
-  do {                                                                                   \
-    if (stager) {                                                                        \
-      lds_double* _d = wave_lds + (buf) * kPipeBuf + lane * 11;                          \
-      _Pragma("unroll") for (int c = 0; c < 11; c++) _d[c] = st[c];                      \
-    }                                                                                    \
-  } while (0)
-        GEL_PIPE_LOAD(0);
-        double a = ap[0];
-        GEL_PIPE_WRITE(0);
-        stage_tables_commit(P, lds, tab_mine);
-        __syncthreads();
+        const lds_double* ring = wave_lds + kRingOff + lane;
         for (int sl = 0; sl < nslab; sl++) {
           const int bo = (sl & 1) * kPipeBuf;
-          if (sl + 1 < nslab) GEL_PIPE_LOAD(sl + 1);      // in flight while this slab multiplies
-          const int k0 = sl * kPipeK, kcount = min(kPipeK, ksteps - k0);
-          for (int ks = 0; ks < kcount; ks++) {
-            const double a_next = ap[min(k0 + ks + 1, ksteps - 1) * 256];
-            const int ro = bo + ks * 44;
-            const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl2, acc[2], 0, 0, 0);
-            a = a_next;
+          const bool more = sl + 1 < nslab;                 // wave-uniform
+          const int k0 = sl * kPipeK;
+          if (more) GEL_PIPE_ROWS(sl + 1, (sl + 1) & 1);    // in flight while this slab multiplies
+          int p0 = xoff[0] + bo, p1 = xoff[1] + bo, p2 = xoff[2] + bo;   // running operand addresses (not 24 hoisted ones)
+#pragma unroll
+          for (int pr = 0; pr < kPairs; pr++) {
+            // this pair's refill was the pr-th of the previous slab: behind it in the queue are that slab's later refills
+            // (kPairs - 1 - pr), this slab's three row pieces and its earlier refills (pr) -- or, in the last slab, only the former
+            if (more) GEL_PIPE_WAIT(kPairs + 2); else GEL_PIPE_WAIT(kPairs - 1 - pr);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int ks = 2 * pr + h;
+              if (k0 + ks < ksteps) {                        // wave-uniform
+                const double a = ring[64 * ks];
+                const double bl0 = regions[p0], bl1 = regions[p1], bl2 = regions[p2];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl2, acc[2], 0, 0, 0);
+              }
+              p0 += 4 * xstr[0]; p1 += 4 * xstr[1]; p2 += 4 * xstr[2];
+              asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));       // keep them running
+            }
+            if (more) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the pair's slots have been read
+              GEL_PIPE_A(pr, k0 + kPipeK + 2 * pr);
+            }
           }
           {
             const int ol = own - sl * kPipeRows;          // the node's own state row, if it lies in this slab
             if (ol >= 0 && ol < kPipeRows) {
-              lds_double* src = wave_lds + bo + ol * 11;
-              me = src[0];
+              const lds_double* img = wave_lds + bo;
+              me = img[ol];
 #pragma unroll
-              for (int c = 0; c < 3; c++) { re[c] = src[1 + c]; ve[c] = src[4 + c]; }
+              for (int c = 0; c < 3; c++) { re[c] = img[kBP + 3 * ol + c]; ve[c] = img[kBV + 3 * ol + c]; }
 #pragma unroll
-              for (int c = 0; c < 4; c++) q[c] = src[7 + c];
+              for (int c = 0; c < 4; c++) q[c] = img[kBQ + 4 * ol + c];
             }
           }
           if (n >= sl * kPipeRows && n < (sl + 1) * kPipeRows)      // wave-uniform: the tail row lies in this slab's image
-            GEL_DX_TAIL_ACC(regions[xoff[ct] + bo + (n - sl * kPipeRows - kq) * 11]);
-          if (sl + 1 < nslab) GEL_PIPE_WRITE((sl + 1) & 1);
-          __syncthreads();                                // slab sl is consumed everywhere, slab sl + 1 is in place
+            GEL_DX_TAIL_ACC(regions[xoff[ct] + bo + (n - sl * kPipeRows - kq) * xstr[ct]]);
+          if (more) {
+            GEL_PIPE_WAIT(kPairs);                         // the next slab's rows have landed (behind them: this slab's refills)
+            if (!tail1 && sl + 2 == nslab && lane < 3) {
+              // rows past n of the last k-step multiply columns of D that hold zeros: they must not hold another phase's numbers
+              // (a NaN there would reach this phase's rows)
+              const int rz = n + 1 + lane - (sl + 1) * kPipeRows;
+              if (rz < kPipeRows && n + 1 + lane < 4 * ksteps) {
+                lds_double* img = wave_lds + ((sl + 1) & 1) * kPipeBuf;
+                img[rz] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { img[kBP + 3 * rz + c] = 0.0; img[kBV + 3 * rz + c] = 0.0; }
+#pragma unroll
+                for (int c = 0; c < 4; c++) img[kBQ + 4 * rz + c] = 0.0;
+              }
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();                     // slab sl is consumed everywhere, slab sl + 1 is in place
         }
-#undef GEL_PIPE_LOAD
-#undef GEL_PIPE_WRITE
+#undef GEL_PIPE_ROWS
+#undef GEL_PIPE_A
+#undef GEL_PIPE_WAIT
         lds_double* wg_lds = regions + kHO;
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
@@ -1321,10 +1373,12 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   if (bad) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 
-template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false>
+// LONGP: the problem has a phase of kXldsPipeFrom nodes or more (the cooperative form then carries the slab loop; problems
+// without one run an instantiation that does not, so that the long-phase code cannot cost them a register)
+template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, bool LONGP = true>
 __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : ((JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_PACKJAC : GEL_MIN_WAVES_PER_SIMD)) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
-  eval_body<JAC, MFMA, SPLIT, PACK>(P, B, x, res, jvar, blockIdx.x);
+  eval_body<JAC, MFMA, SPLIT, PACK, 9, LONGP>(P, B, x, res, jvar, blockIdx.x);
 }
 
 }  // namespace gel

@@ -1018,6 +1018,7 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     for (int i = 0; i < S; i++) nmax = std::max(nmax, p->ph[i].n);
     dv.use_mfma = (d->flags & GEL_FLAG_DX_VALU) ? 0 : 1;
     dv.pack = (nmax <= 32) && !(d->flags & GEL_FLAG_NO_PACK);
+    dv.longp = (nmax >= gel::kLongPhaseFrom) ? 1 : 0;
   }
   dv.fd_recompute = p->fd_recompute ? 1 : 0;
   {

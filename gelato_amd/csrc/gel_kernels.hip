@@ -1240,13 +1240,13 @@ EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
   return f;
 }
 
-template <bool JAC, bool PACK>
+template <bool JAC, bool PACK, bool LONGP>
 static void launch_coop(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
   const unsigned nb = (unsigned)((B + (PACK ? 7 : 3)) / (PACK ? 8 : 4));
   // vector-group major order deals the groups to the eight XCDs in blocks of eight (short last block: idle workgroups leave at once)
   const unsigned grid = P.vmajor ? (unsigned)P.nchunks * 8u * ((nb + 7u) / 8u) : (unsigned)P.nchunks * nb;
-  const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(JAC, true, PACK) * (kBlock / 64));
-  hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+  const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(JAC, true, PACK, false, LONGP) * (kBlock / 64));
+  hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK, LONGP>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
 }
 
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
@@ -1254,10 +1254,12 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
   const EvalForm f = eval_form(P, B, d_res != nullptr, d_jvar != nullptr);
   if (f.mfma && !f.split) {
     // cooperative D.X form (matrix pipe, not split): one workgroup = one work item x four (PACK: eight) decision vectors
-    if (f.jac && f.pack) launch_coop<true, true>(P, B, d_x, d_res, d_jvar, s);
-    else if (f.jac) launch_coop<true, false>(P, B, d_x, d_res, d_jvar, s);
-    else if (f.pack) launch_coop<false, true>(P, B, d_x, d_res, d_jvar, s);
-    else launch_coop<false, false>(P, B, d_x, d_res, d_jvar, s);
+    if (f.jac && f.pack) launch_coop<true, true, false>(P, B, d_x, d_res, d_jvar, s);
+    else if (f.jac && P.longp) launch_coop<true, false, true>(P, B, d_x, d_res, d_jvar, s);
+    else if (f.jac) launch_coop<true, false, false>(P, B, d_x, d_res, d_jvar, s);
+    else if (f.pack) launch_coop<false, true, false>(P, B, d_x, d_res, d_jvar, s);
+    else if (P.longp) launch_coop<false, false, true>(P, B, d_x, d_res, d_jvar, s);
+    else launch_coop<false, false, false>(P, B, d_x, d_res, d_jvar, s);
     return hipGetLastError();
   }
   const unsigned grid = (unsigned)((f.waves * 64 + kBlock - 1) / kBlock);
