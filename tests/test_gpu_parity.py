@@ -1175,10 +1175,13 @@ def test_random_problem_structures_values(seed):
     assert rc == 0 and np.array_equal(res[B - 1], res1) and np.array_equal(E.expand(jv[B - 1]), vals1)
 
 
-@pytest.mark.parametrize("nn", [(68,), (131,), (200, 5), (87, 129, 64)])
+@pytest.mark.parametrize("nn", [(68,), (131,), (200, 5), (87, 129, 64), (96,), (128, 7), (69, 70, 71), (160,), (100, 95), (72, 64, 127)])
 def test_long_phases_slab_staged_product(nn):
-    """Phases of 68 nodes and more form D.X from double-buffered 44-row slabs of state rows: 2 .. 5 slabs, ragged last
-    slabs and ragged last chunks, against the oracle and -- the same vector inside a batch -- against the split form."""
+    """Phases of 68 nodes and more form D.X from 32-row slabs of state rows and a ring of A operands, both brought into LDS by
+    LDS-DMA under hand-counted waits: 3 .. 7 slabs, ragged last slabs and ragged last chunks, a last state row that is multiplied
+    on the vector unit (n a multiple of four) and lies in the last slab or in one of its own (n a multiple of 32), rows past the
+    phase that are zeroed (n + 1 not a multiple of four) -- against the oracle and, the same vector inside a batch, against the
+    split form."""
     import states
     prob, x = states.long_state(nn)
     E, P = make_pair(prob)
@@ -1192,6 +1195,40 @@ def test_long_phases_slab_staged_product(nn):
         assert np.array_equal(res[0], res1) and not np.array_equal(res[B // 2], res1)
         r2, _, rc = E.eval_batch(X, want_jac=False)                  # the residual-only launch stages the same way
         assert rc == 0 and np.array_equal(r2, res)
+
+
+@pytest.mark.parametrize("nn", [(70, 5), (69, 9, 4), (71, 3)])
+def test_long_phase_rows_do_not_see_the_next_phase(nn):
+    """The image of a long phase's last slab holds rows past the phase -- the next phase's first state rows, as they lie in x.  The
+    last k-step multiplies them by columns of D that hold zeros, which is only harmless if they are numbers: they are zeroed in
+    the image, so a NaN in the NEXT phase's first rows leaves this phase's residual rows and Jacobian values what they were."""
+    import states
+    prob, x = states.long_state(nn)
+    E, P = make_pair(prob)
+    B = 260
+    X = np.tile(x, (B, 1))
+    res0, jv0, rc = E.eval_batch(X)
+    assert rc == 0 and E.launch_info(B)[2] == 0
+    n0 = nn[0]
+    Xn = X.copy()
+    for k in range(3):                                   # the first three state rows of phase 1: mass, position, velocity, quaternion
+        row = n0 + 1 + k
+        Xn[:, row] = np.nan
+        Xn[:, E.M + 3 * row:E.M + 3 * row + 3] = np.nan
+        Xn[:, 4 * E.M + 3 * row:4 * E.M + 3 * row + 3] = np.inf
+        Xn[:, 7 * E.M + 4 * row:7 * E.M + 4 * row + 4] = np.nan
+    res1, jv1, rc1 = E.eval_batch(Xn)
+    assert rc1 == 1                                      # phase 1 itself is not finite, and says so
+    N = E.N
+    rows0 = np.concatenate([np.arange(n0), N + np.arange(3 * n0), 4 * N + np.arange(3 * n0), 7 * N + np.arange(4 * n0)])
+    assert np.array_equal(res1[:, rows0], res0[:, rows0]) and np.isfinite(res0[:, rows0]).all()
+    full0, full1 = E.expand(jv0[:2]), E.expand(jv1[:2])
+    pat = E.pattern()
+    off = 0
+    for b_, (r, c) in enumerate(pat):                   # every Jacobian value of phase 0's rows (block-local row numbering)
+        sel = r < (E.block_shape[b_][0] // N) * n0
+        assert np.array_equal(full1[:, off:off + len(r)][:, sel], full0[:, off:off + len(r)][:, sel]), b_
+        off += len(r)
 
 
 def test_path_sincos_and_log_accuracy():
