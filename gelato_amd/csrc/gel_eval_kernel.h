@@ -1373,8 +1373,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   if (bad) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 
-// LONGP: the problem has a phase of kXldsPipeFrom nodes or more (the cooperative form then carries the slab loop; problems
-// without one run an instantiation that does not, so that the long-phase code cannot cost them a register)
+// LONGP = false: the launcher vouches that no phase has kXldsPipeFrom nodes or more, and the instantiation is without the slab
+// loop (used by the residual-only cooperative form, which then needs 72 VGPRs instead of 118)
 template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, bool LONGP = true>
 __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : ((JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_PACKJAC : GEL_MIN_WAVES_PER_SIMD)) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {

@@ -1255,8 +1255,10 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
   if (f.mfma && !f.split) {
     // cooperative D.X form (matrix pipe, not split): one workgroup = one work item x four (PACK: eight) decision vectors
     if (f.jac && f.pack) launch_coop<true, true, false>(P, B, d_x, d_res, d_jvar, s);
-    else if (f.jac && P.longp) launch_coop<true, false, true>(P, B, d_x, d_res, d_jvar, s);
-    else if (f.jac) launch_coop<true, false, false>(P, B, d_x, d_res, d_jvar, s);
+    // one Jacobian instantiation for long and short phases (without the slab loop it measured 0.4 % SLOWER at 6 x 64, with 52
+    // fewer instructions per wavefront); the residual-only form of a problem without a long phase drops to 72 VGPRs without it
+    // (7 waves/SIMD: -10 % launch time at 6 x 64)
+    else if (f.jac) launch_coop<true, false, true>(P, B, d_x, d_res, d_jvar, s);
     else if (f.pack) launch_coop<false, true, false>(P, B, d_x, d_res, d_jvar, s);
     else if (P.longp) launch_coop<false, false, true>(P, B, d_x, d_res, d_jvar, s);
     else launch_coop<false, false, false>(P, B, d_x, d_res, d_jvar, s);
