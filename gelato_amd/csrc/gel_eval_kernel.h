@@ -85,11 +85,10 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_CA_CACHE 1  // the Mach interval of a node's first CA lookup serves its other aerodynamic-force evaluations
 #endif
 #ifndef GEL_XLDS_A_PF_JAC
-#define GEL_XLDS_A_PF_JAC 17  // LDS-staged cooperative D.X, one vector per wavefront: A slabs in flight, fused launch.  17 = all of a
-                              // 64-node phase, requested before the operand barrier: their (L2) round trips run under the state
-                              // rows' (HBM) one instead of one per k-step in a row -- a wavefront's vector-memory results come
-                              // back in order behind every older request of its CU, so even an L2 hit costs 600-1000 cycles
-                              // under the store stream and 17 of them in a row were 20 % of a wavefront's life (round 4 stamps)
+#define GEL_XLDS_A_PF_JAC 4   // LDS-staged cooperative D.X, one vector per wavefront: A slabs in flight, fused launch.  A ring of four,
+                              // the first four requested before the operand barrier.  In-process A/B at mixed-6x64 (tools/ab_inproc.py,
+                              // round 5, 0.1 % spread): against all 17 of a 64-node phase at once (round 4's choice, made with a
+                              // harness that could not see it) -1.2 %; 2 / 3 / 5 / 8 in flight +0.4 .. +0.6 % over 4, 6 level
 #endif
 #ifndef GEL_XLDS_A_PF_RES
 #define GEL_XLDS_A_PF_RES 4  // ... residual-only launch (6x64: +11 % over 1; the fused launch does not care: +-1 % for 1..8)
@@ -1060,10 +1059,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         }
         if (rb) {  // velocity defect (:216-289); its D.X row leaves slots LV0-2, which then serve as the tile of the transposed store
 #ifndef GEL_RES_XPOSE_VEL_AIR
-#define GEL_RES_XPOSE_VEL_AIR 0   // with derivatives this store keeps the strided form: the three residuals at once are three more values
-                                  // live at the register peak of the kernel, and the allocator answers with reloads inside the light
-                                  // sweeps (20 B of scratch against 12 B whose reloads sit on rare paths only).  Pooled A/B (three
-                                  // processes per build, 1-s turns): within +-1 % of the tile form on mixed / dense / 12 x 128
+#define GEL_RES_XPOSE_VEL_AIR 1   // the velocity defect of an aerodynamic phase through the tile as well (with the max-ilp scheduling
+                                  // strategy the three values live at the register peak cost no scratch any more): in-process A/B
+                                  // -0.35 % at mixed-6x64, level at dense / 12 x 128 (round 5)
 #endif
           if (!JAC || GEL_RES_XPOSE_VEL_AIR) {
             double cv[3];

@@ -8,7 +8,7 @@ mkdir -p ../../build/variants
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}; [ "$flags" = "$spec" ] && flags=""
   rm -f ../../build/variants/libgel_$name.so
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=on -mllvm -disable-machine-licm $flags \
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=on -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp $flags \
      -shared -o ../../build/variants/libgel_$name.so gel_kernels.hip gel_host.hip > ../../build/variants/$name.log 2>&1 \
      && echo "built $name [$flags]" || { echo "FAILED $name (build/variants/$name.log):"; tail -5 ../../build/variants/$name.log; } ) &
 done

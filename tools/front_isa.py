@@ -8,7 +8,7 @@ rows = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 lst = sys.argv[3] if len(sys.argv) > 3 else "/tmp/gel_front.s"
 if len(sys.argv) <= 3:
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=on", "-mllvm",
-                    "-disable-machine-licm", "--cuda-device-only", "-S", "gel_kernels.hip", "-o", lst], cwd=root, check=True, stderr=subprocess.DEVNULL)
+                    "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "--cuda-device-only", "-S", "gel_kernels.hip", "-o", lst], cwd=root, check=True, stderr=subprocess.DEVNULL)
 L = open(lst).read().split("\n")
 start = [i for i, l in enumerate(L) if l.startswith(prefix) and ": ;" in l][0]
 end = next(i for i in range(start, len(L)) if L[i].startswith(".Lfunc_end"))

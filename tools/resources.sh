@@ -1,7 +1,7 @@
 #!/bin/bash
 # (here, no GPU) registers / scratch / LDS / occupancy of every kernel of gel_kernels.hip.  Usage: tools/resources.sh [extra -D flags]
 cd "$(dirname "$0")/../gelato_amd/csrc" || exit 1
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=on -mllvm -disable-machine-licm "$@" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=on -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp "$@" \
   -Rpass-analysis=kernel-resource-usage -c gel_kernels.hip -o /tmp/gel_kernels_res.o 2>&1 | python3 -c "
 import sys, re
 cur = None
