@@ -1231,6 +1231,23 @@ def test_long_phase_rows_do_not_see_the_next_phase(nn):
         off += len(r)
 
 
+def test_jac_fd_of_a_long_phase_problem():
+    """The phase-by-phase forward difference evaluates every phase as a one-phase problem: a long phase's sub-problem takes the
+    slab loop on a local decision vector (its rows past the phase lie in that vector's own control block)."""
+    import states
+    prob, x = states.long_state((70, 5))
+    E, P = make_pair(prob)
+    for grp in ("mass", "vel"):
+        J, rc = E.jac_fd(grp, x)
+        assert rc == 0 and np.isfinite(J).all()
+        assert np.abs(J - P.jac_fd(grp, x)).max() <= 1e-5 * max(1.0, np.abs(J).max())
+        blocks, _ = E.jac_fd_blocks(grp, x)
+        rebuilt = np.zeros_like(J)
+        for row0, cols, blk in blocks:
+            rebuilt[row0:row0 + blk.shape[0], cols] = blk
+        assert np.array_equal(rebuilt, J)
+
+
 def test_path_sincos_and_log_accuracy():
     """gel::fsincos (|x| <= 3 pi/4: latitudes, half Earth angles) and gel::flog_ratio (0.5 < x < 2: temperature ratios
     inside a layer) against numpy: at most 1 ulp resp. 2 ulp off the correctly rounded value, and not more often
