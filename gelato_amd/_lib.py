@@ -86,6 +86,7 @@ SIGNATURES = {
     "gel_pinned_buffers": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4),
     "gel_fill_full_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gel_update_full_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gel_eval_full_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gel_shard_plan": (C.c_int, [C.c_void_p, C.c_int32, _ip, _lp, _lp, _lp]),
     "gel_eval_shard_packed_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "gel_shard_unpack_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),

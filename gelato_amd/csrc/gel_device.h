@@ -75,6 +75,7 @@ struct ProblemDev {
   int32_t use_mfma;          // D.X on v_mfma_f64_16x16x4_f64 instead of VALU FMAs
   int32_t pack;              // every phase has at most 32 nodes: the cooperative form carries two decision vectors per wavefront
   int32_t longp;             // some phase has kXldsPipeFrom (68) nodes or more: the cooperative form with the slab loop
+  int32_t cached_out;        // this launch's Jacobian values are read again at once (gel_eval_full_device): ordinary stores if they fit the Infinity Cache
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
   int32_t unit0, nunits;     // split form only: first unit and number of units (unit = 4 * work item + part)
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)

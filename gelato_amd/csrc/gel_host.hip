@@ -1373,6 +1373,18 @@ int gel_update_full_device(gel_problem* p, int32_t B, const double* d_jvar, doub
   return GEL_OK;
 }
 
+int gel_eval_full_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar, double* d_jfull, void* stream) {
+  if (!p || !d_x || !d_jvar || !d_jfull || B < 1) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  gel::ProblemDev dv = p->dev;
+  dv.cached_out = 1;   // the compact values are read again by the update below: kept in the caches when the launch fits them
+  HIPCHK(gel::launch_eval(dv, B, d_x, d_res, d_jvar, s));
+  HIPCHK(gel::launch_update_full(p->dims.total_nnz, p->dims.num_var_entries, p->nvar_entries, B, p->d_vdst, p->d_vsrc,
+                                 p->nvar_lines, p->d_vline, p->d_src, p->d_cval, d_jvar, d_jfull, s));
+  return GEL_OK;
+}
+
 int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream) {
   if (!p || !d_jvar || !d_jfull || B < 1) return fail(GEL_ERR_ARG, "bad argument");
   NEED_DEVICE(p);

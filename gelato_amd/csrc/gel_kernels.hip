@@ -1240,13 +1240,13 @@ EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac) {
   return f;
 }
 
-template <bool JAC, bool PACK, bool LONGP>
+template <bool JAC, bool PACK, bool LONGP, bool NTS = true>
 static void launch_coop(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
   const unsigned nb = (unsigned)((B + (PACK ? 7 : 3)) / (PACK ? 8 : 4));
   // vector-group major order deals the groups to the eight XCDs in blocks of eight (short last block: idle workgroups leave at once)
   const unsigned grid = P.vmajor ? (unsigned)P.nchunks * 8u * ((nb + 7u) / 8u) : (unsigned)P.nchunks * nb;
   const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(JAC, true, PACK, false, LONGP) * (kBlock / 64));
-  hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK, LONGP>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
+  hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK, LONGP, NTS>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
 }
 
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
@@ -1254,11 +1254,15 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
   const EvalForm f = eval_form(P, B, d_res != nullptr, d_jvar != nullptr);
   if (f.mfma && !f.split) {
     // cooperative D.X form (matrix pipe, not split): one workgroup = one work item x four (PACK: eight) decision vectors
-    if (f.jac && f.pack) launch_coop<true, true, false>(P, B, d_x, d_res, d_jvar, s);
+    // Jacobian values of a launch that fits the Infinity Cache (256 MB) and is read again at once (gel_eval_full_device: the update of
+    // a full COO buffer) by ordinary stores: the reader finds them there (fused + update at B = 1024: 0.26 -> 0.165 ms).  A launch on
+    // its own is better off streaming them past the caches even when it is small (B = 256 on repeat: ordinary stores +9 %)
+    const bool small = P.cached_out && (double)B * 8.0 * ((double)P.V + 11.0 * P.N) <= 192.0e6;
+    if (f.jac && f.pack) { if (small) launch_coop<true, true, false, false>(P, B, d_x, d_res, d_jvar, s); else launch_coop<true, true, false, true>(P, B, d_x, d_res, d_jvar, s); }
     // one Jacobian instantiation for long and short phases (without the slab loop it measured 0.4 % SLOWER at 6 x 64, with 52
     // fewer instructions per wavefront); the residual-only form of a problem without a long phase drops to 72 VGPRs without it
     // (7 waves/SIMD: -10 % launch time at 6 x 64)
-    else if (f.jac) launch_coop<true, false, true>(P, B, d_x, d_res, d_jvar, s);
+    else if (f.jac) { if (small) launch_coop<true, false, true, false>(P, B, d_x, d_res, d_jvar, s); else launch_coop<true, false, true, true>(P, B, d_x, d_res, d_jvar, s); }
     else if (f.pack) launch_coop<false, true, false>(P, B, d_x, d_res, d_jvar, s);
     else if (P.longp) launch_coop<false, false, true>(P, B, d_x, d_res, d_jvar, s);
     else launch_coop<false, false, false>(P, B, d_x, d_res, d_jvar, s);

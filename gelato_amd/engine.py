@@ -273,6 +273,11 @@ class Engine:
         """only the x-dependent entries of d_jfull [B][total_nnz] from d_jvar [B][V] (the buffer holds the constants already)"""
         check(lib().gel_update_full_device(self._h, B, d_jvar, d_jfull, stream or None))
 
+    def eval_full_device(self, B, d_x, d_res, d_jvar, d_jfull, stream=0):
+        """one evaluation with every COO value valid in d_jfull [B][total_nnz] afterwards (fill_full_device once before): the fused
+        launch + the update in place; a launch that fits the Infinity Cache keeps its compact values there for the update"""
+        check(lib().gel_eval_full_device(self._h, B, d_x, d_res or None, d_jvar, d_jfull, stream or None))
+
     def launch_info(self, B, want_res=True, want_jac=True):
         """-> [jacobian, mfma, split, wavefronts, pack] of the kernel form a launch of B vectors takes"""
         info = (C.c_int32 * 5)()

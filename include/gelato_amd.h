@@ -176,6 +176,12 @@ int gel_pinned_buffers(gel_problem* p, double** res, double** vals_full, double*
  * every evaluation.  Bit-identical to gel_expand_full_device as long as nothing else writes the buffer. */
 int gel_fill_full_device(gel_problem* p, int32_t B, double* d_jfull, void* stream);
 int gel_update_full_device(gel_problem* p, int32_t B, const double* d_jvar, double* d_jfull, void* stream);
+/* One evaluation with EVERY COO value valid in HBM afterwards: the fused launch (d_res may be NULL) followed by the update of
+ * d_jfull [B][total_nnz] (laid down once by gel_fill_full_device) from the compact values it has just written to d_jvar [B][V].
+ * A launch whose output fits the Infinity Cache writes the compact values with ordinary instead of non-temporal stores, so that
+ * the update finds them there (6 x 64, B = 1024: 0.26 -> 0.165 ms, 6.2 M evals/s).  Same bits as gel_eval_batch_device +
+ * gel_update_full_device. */
+int gel_eval_full_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar, double* d_jfull, void* stream);
 /* multi-GPU sharding of ONE batch (the defect path is block-diagonal per phase, lib/con_dynamics.py:46,132,237,320,512,554,
  * and its forward-difference columns are independent).  A work item = one 64-node chunk of one phase;
  * unit = 4 * work_item + part, part 0 = everything of the work item except its three position

@@ -111,6 +111,7 @@ int main(int argc, char** argv) {
     CHECK(gel_eval_residual(p, x, res) == GEL_ERR_HIP); /* host-only handles never evaluate */
     CHECK(gel_jac_fd_blocks(p, 2, x, vals) == GEL_ERR_HIP && gel_jac_fd_device(p, 2, x, vals, 1, NULL) == GEL_ERR_HIP);
     CHECK(gel_eval_shard_packed_device(p, 1, x, res, 0, 1, 2, NULL) == GEL_ERR_HIP);
+    CHECK(gel_eval_full_device(p, 1, x, res, vals, vals, NULL) == GEL_ERR_HIP);
     {
       static double tx[77], table[77 * GEL_OUTPUT_COLUMNS];
       CHECK(gel_output_table(p, x, tx, 42.5, 143.4, table) == GEL_ERR_HIP);

@@ -647,6 +647,20 @@ def test_device_pointer_api_and_full_expansion():
             E.expand_full_device(Bu, dj.data_ptr(), dref.data_ptr(), s)
             assert E.sync(s) == 0
             assert torch.equal(dupd, dref)
+        # ... and in one call (evaluation + update; a launch that fits the Infinity Cache writes its compact values with ordinary
+        # stores): the same residual rows, compact values and COO values, with and without residual rows
+        dr2 = torch.full_like(dr, float("nan"))
+        dj2 = torch.full_like(dj, float("nan"))
+        dupd2 = torch.full((Bu, E.total_nnz), float("nan"), dtype=torch.float64, device=dev)
+        E.fill_full_device(Bu, dupd2.data_ptr(), s)
+        E.eval_full_device(Bu, dXs.data_ptr(), dr2.data_ptr(), dj2.data_ptr(), dupd2.data_ptr(), s)
+        assert E.sync(s) == 0 and torch.equal(dr2, dr) and torch.equal(dj2, dj) and torch.equal(dupd2, dref)
+        dupd2.fill_(float("nan"))
+        E.fill_full_device(Bu, dupd2.data_ptr(), s)
+        E.eval_full_device(Bu, dXu.data_ptr(), 0, dj2.data_ptr(), dupd2.data_ptr(), s)
+        E.eval_batch_device(Bu, dXu.data_ptr(), 0, dj.data_ptr(), s)
+        E.expand_full_device(Bu, dj.data_ptr(), dref.data_ptr(), s)
+        assert E.sync(s) == 0 and torch.equal(dj2, dj) and torch.equal(dupd2, dref)
 
 
 def test_nonfinite_input_sets_status():
