@@ -66,7 +66,10 @@ struct LinRowDev { int32_t idx0, idx1; double coef0, coef1, c0; };  // (coef0 x[
 // difference: bit 2 clear: (value(x + dx e_c) - value(x)) / dx;  set: ((f(x + dx e_c) - f(x)) / dx) / p[0], negated with bit 3
 struct FnRowDev { int32_t fn, node, tcol, mode; double p[8]; };
 
-constexpr int kLongPhaseFrom = 68;   // phases of this many nodes and more take the slab loop of the cooperative form (gel_eval_kernel.h)
+#ifndef GEL_LONG_PHASE_FROM
+#define GEL_LONG_PHASE_FROM 68
+#endif
+constexpr int kLongPhaseFrom = GEL_LONG_PHASE_FROM;   // phases of this many nodes and more take the slab loop of the cooperative form (gel_eval_kernel.h)
 
 struct ProblemDev {
   int32_t S, N, M, nvars;
@@ -76,6 +79,12 @@ struct ProblemDev {
   int32_t pack;              // every phase has at most 32 nodes: the cooperative form carries two decision vectors per wavefront
   int32_t longp;             // some phase has kXldsPipeFrom (68) nodes or more: the cooperative form with the slab loop
   int32_t cached_out;        // this launch's Jacobian values are read again at once (gel_eval_full_device): ordinary stores if they fit the Infinity Cache
+  // one-vector launches that tell the host themselves when their results have arrived (pinned host memory): every workgroup counts
+  // itself in done_ctr (device memory) after a system-scope release of its stores, the last one stores done_seq to done_flag
+  // (pinned host word the host spins on) -- the host does not wait for the end-of-kernel signal (4 us later at 6 x 64).  null: off
+  int32_t* done_ctr;
+  int32_t* done_flag;
+  int32_t done_total, done_seq;
   int32_t chunk0;            // first work item of this launch (phase-sharded launches), else 0
   int32_t unit0, nunits;     // split form only: first unit and number of units (unit = 4 * work item + part)
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)

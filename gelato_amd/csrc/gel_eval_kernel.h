@@ -1371,6 +1371,21 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   if (bad) *(volatile int32_t*)P.flag = 1;  // every writer stores the same 1
 }
 
+// Last thing a workgroup of a self-signalling launch does (ProblemDev::done_flag): its wavefronts' stores released at system scope,
+// itself counted; the last workgroup of the grid resets the counter and hands the launch's sequence number to the host.
+__device__ __forceinline__ void signal_done(const ProblemDev& P) {
+  if (!P.done_flag) return;                       // wave-uniform (kernel argument)
+  __threadfence_system();                         // this wavefront's results (pinned host memory) are visible system-wide ...
+  __syncthreads();                                // ... and so are those of the workgroup's other wavefronts
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(P.done_ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == P.done_total - 1) {
+      __hip_atomic_store(P.done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch (which the host starts after the flag)
+      __hip_atomic_store(P.done_flag, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // LONGP = false: the launcher vouches that no phase has kXldsPipeFrom nodes or more, and the instantiation is without the slab
 // loop (used by the residual-only cooperative form, which then needs 72 VGPRs instead of 118)
 // NTS = false: the Jacobian values by ordinary stores instead of non-temporal ones -- launches whose output fits the Infinity Cache
@@ -1380,6 +1395,7 @@ template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, bool LONGP
 __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : ((JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_PACKJAC : GEL_MIN_WAVES_PER_SIMD)) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
   eval_body<JAC, MFMA, SPLIT, PACK, 9, LONGP, NTS>(P, B, x, res, jvar, blockIdx.x);
+  if constexpr (SPLIT) signal_done(P);   // latency form only: the throughput forms never signal
 }
 
 }  // namespace gel

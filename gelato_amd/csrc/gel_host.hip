@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -192,6 +194,9 @@ struct gel_problem {
   std::vector<int32_t> sub_chunk0, sub_nchunks, sub_col0;     // [S] first work item, work items, first colmap entry
   std::vector<size_t> sub_res0;                               // [S] first double of the phase's residuals in jfd_res
   std::vector<double> jfd_last_x;                             // empty = nothing cached
+  int32_t* d_done = nullptr;                                  // self-signalling one-vector launches (ProblemDev::done_flag): device counter,
+  volatile int32_t* h_done = nullptr;                         // pinned host word, sequence number of the last armed launch
+  int32_t done_seq = 0;
   int jfd_status = GEL_OK;
   // knot / terminal / user rows (gel_rows_configure)
   std::vector<gel::LinRowDev> lin_rows;
@@ -406,6 +411,34 @@ int ensure_capacity(gel_problem* p, int B) {
 // hipStreamQuery 39.1 us per Engine.eval, hipStreamSynchronize 37.3 us, the same after hipSetDeviceFlags(hipDeviceScheduleSpin) 37.0 us
 // -- this runtime's synchronise spins on the completion signal itself before it sleeps, and a query is a full API call per poll
 // (rounds 1-4 measured the opposite on an earlier runtime and polled).  GEL_WAIT_MODE=0 restores the polling loop (measurement switch).
+// Self-signalling one-vector launches: the kernel's last workgroup stores the launch's sequence number to a pinned host word once
+// every workgroup's results are visible system-wide (gel_eval_kernel.h signal_done); the host spins on that word instead of waiting
+// for the end-of-kernel signal, which the runtime hands over 4 us later at 6 x 64 (29 -> 25 us launch-to-results).  The stream still
+// holds the kernel's tail; whatever is launched next on it is ordered behind.  GEL_DONE_FLAG=0: off (measurement switch).
+static bool done_flag_on() {
+  static const bool on = [] { const char* e = getenv("GEL_DONE_FLAG"); return !e || atoi(e) != 0; }();
+  return on;
+}
+static void arm_done(gel_problem* p, gel::ProblemDev& dv) {
+  if (!p->d_done || !p->h_done || !done_flag_on()) return;
+  dv.done_ctr = p->d_done;
+  dv.done_flag = const_cast<int32_t*>(p->h_done);
+  dv.done_seq = ++p->done_seq;
+}
+static hipError_t spin_wait(hipStream_t s);
+static hipError_t wait_done(gel_problem* p, const gel::ProblemDev& dv) {
+  if (dv.done_flag) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 1;; it++) {
+      if (*p->h_done == dv.done_seq) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
+      __builtin_ia32_pause();
+      // a launch that never signals (it should not happen) falls back to the runtime's wait after 5 ms
+      if ((it & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+  }
+  return spin_wait(p->stream);
+}
+
 static hipError_t spin_wait(hipStream_t s) {
   static const int mode = [] { const char* e = getenv("GEL_WAIT_MODE"); return e ? atoi(e) : 1; }();
   if (mode) return hipStreamSynchronize(s);
@@ -479,8 +512,9 @@ int run_host(gel_problem* p, int B, const double* x, bool want_res, bool want_ja
     // vector (gel::eval_form) and keeps the compact path
     if (coo && B == 1 && want_jac && gel::eval_form(dv, 1, want_res, true).split) { dv.coo_full = p->h_full; dv.coo = p->d_coo; *coo_io = true; }
     dv.split_vel = 1;   // a whole evaluation: every part of every work item is in this launch
+    if (gel::eval_form(dv, B, want_res, want_jac).split) arm_done(p, dv);   // the latency form tells the host itself when its results are there
     HIPCHK(gel::launch_eval(dv, B, xin, want_res ? (res_to ? res_to : p->h_res) : nullptr, want_jac ? p->h_jv : nullptr, p->stream));
-    HIPCHK(spin_wait(p->stream));
+    HIPCHK(wait_done(p, dv));
     if (*p->h_flag) { *p->h_flag = 0; return GEL_NONFINITE; }
     return GEL_OK;
   }
@@ -993,6 +1027,8 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     }
   }
   if (hipMalloc((void**)&p->d_flag, 4) != hipSuccess || hipMemset(p->d_flag, 0, 4) != hipSuccess ||
+      hipMalloc((void**)&p->d_done, 4) != hipSuccess || hipMemset(p->d_done, 0, 4) != hipSuccess ||
+      hipHostMalloc((void**)&p->h_done, 4) != hipSuccess ||
       hipHostMalloc((void**)&p->h_flag, 4) != hipSuccess || hipStreamCreate(&p->stream) != hipSuccess) {
     gel_problem_destroy(p);
     return fail(GEL_ERR_HIP, "device allocation failed");
@@ -1055,6 +1091,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->h_rows) hipHostFree(p->h_rows);
   hipFree(p->d_lin_rows); hipFree(p->d_fn_rows); hipFree(p->d_rows_x); hipFree(p->d_rows_out);
   hipFree(p->jfd_x); hipFree(p->jfd_Xp); hipFree(p->jfd_res); hipFree(p->jfd_J);
+  hipFree(p->d_done); if (p->h_done) hipHostFree(const_cast<int32_t*>(p->h_done));
   hipFree(p->d_subphases); hipFree(p->d_subchunks); hipFree(p->d_colmap);
   delete p;
   return GEL_OK;
@@ -2011,12 +2048,13 @@ int gel_eval_callback(gel_problem* p, const double* x, const gel_callback_io* io
     if (aero) HIPCHK(gel::launch_aero(dv, (int)p->aero_nodes.size(), p->d_aero_nodes, 1, xin, out, p->stream));
   } else {
     // ONE launch: defect groups, aero kinds and row table as workgroup ranges of one grid (gel_kernels.hip callback_kernel)
+    arm_done(p, dv);
     HIPCHK(gel::launch_callback(dv, want_jac, xin, res_to, want_jac ? p->h_jv : nullptr,
                                 aero ? (int)p->aero_nodes.size() : 0, p->d_aero_nodes, aero ? &out : nullptr,
                                 (int)nlin, p->d_lin_rows, (int)nfn, p->d_fn_rows, rows ? p->h_rows : nullptr,
                                 (rows && io->rows_jfn) ? p->h_rows + R : nullptr, p->stream));
   }
-  HIPCHK(hipStreamSynchronize(p->stream));   // the ONE wait of the callback (a sleeping wait: polling hipStreamQuery measured slower)
+  HIPCHK(wait_done(p, dv));   // the ONE wait of the callback: the kernel's own word where it signals, else the runtime's synchronise
   if (io->res && !own_res) std::memcpy(io->res, p->h_res, (size_t)11 * p->dims.N * 8);
   if (want_jac) {
     if (coo) finish_full(p, io->vals_full, io->fill_constants);

@@ -1002,6 +1002,7 @@ __global__ __launch_bounds__(256) void callback_kernel(ProblemDev P, const doubl
   if (b < (unsigned)A.nb_eval) eval_body<JAC, MFMA, true, false, 17>(P, 1, x, res, jvar, b);
   else if (b < (unsigned)(A.nb_eval + A.nb_aero)) aero_body<true>(P, A.nnodes, A.nodes, A.tiles, 1, x, A.O, b - (unsigned)A.nb_eval);
   else rows_body(P, A.nlin, A.lin, A.nfn, A.fr, 1, A.lin_blocks, x, A.con, A.jfn, b - (unsigned)(A.nb_eval + A.nb_aero));
+  signal_done(P);
 }
 
 hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_x, double* d_res, double* d_jvar,
@@ -1026,6 +1027,7 @@ hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_
   const size_t lds_aero = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + (size_t)kAeroWaves * kAeroParkSlots * 64);
   const size_t lds = lds_eval > lds_aero ? lds_eval : lds_aero;
   const dim3 grid((unsigned)(A.nb_eval + A.nb_aero + rows_blocks));
+  if (P.done_flag) P.done_total = (int32_t)grid.x;
   if (want_jac) {
     if (P.use_mfma) hipLaunchKernelGGL((callback_kernel<true, true>), grid, dim3(256), lds, s, P, d_x, d_res, d_jvar, A);
     else hipLaunchKernelGGL((callback_kernel<true, false>), grid, dim3(256), lds, s, P, d_x, d_res, d_jvar, A);
@@ -1274,6 +1276,7 @@ hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_
   if (f.split) {
     ProblemDev Q = P;
     if (Q.nunits <= 0) { Q.unit0 = 4 * P.chunk0; Q.nunits = 4 * P.nchunks; }  // the whole list, split
+    if (Q.done_flag) Q.done_total = (int32_t)grid;
     if (f.mfma)
       hipLaunchKernelGGL((eval_kernel<true, true, true>), dim3(grid), dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
     else

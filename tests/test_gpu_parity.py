@@ -663,6 +663,52 @@ def test_device_pointer_api_and_full_expansion():
         assert E.sync(s) == 0 and torch.equal(dj2, dj) and torch.equal(dupd2, dref)
 
 
+def test_self_signalling_launch_has_delivered_everything_when_it_says_so():
+    """One-vector launches tell the host themselves when their results are in pinned host memory (the last workgroup stores the
+    launch's sequence number after every workgroup's system-scope release) and the host returns on that word, not on the
+    end-of-kernel signal.  Whatever the call hands back must already be final: snapshots taken the moment the call returns equal
+    the buffers after a full synchronise, over many launches whose every value differs from the launch before -- the fused
+    one-vector evaluation, the values-only and the values + derivatives callback with aero rows, and a NaN that must be reported."""
+    from gelato_amd import Engine, con_dynamics, pack_x, problem
+    pdict, unitdict, _c, xdict = problem.make_problem("mixed-6x64")
+    E = Engine(con_dynamics.problem_arrays(pdict, unitdict))
+    S = pdict["num_sections"]
+    for kind, lim in (("alpha", 0.2), ("q", 4.0e4), ("qalpha", 5.0e3)):
+        E.aero_configure(kind, [(i, 1, lim) for i in range(S - 1) if pdict["params"][i]["reference_area"] != 0.0])
+    pres, pvals = E.pinned_buffers()
+    xb, xp = E.pinned_x()
+    x0 = pack_x(xdict)
+    prev_res, prev_vals = None, None
+    for it in range(400):
+        xb[it & 1][:] = x0 * (1.0 + 1e-9 * (it + 1))
+        if it % 3 == 0:
+            res, vals, rc = E.eval(xb[it & 1], out=pvals, res_out=pres)
+            snap = (res.copy(), vals.copy())
+            assert rc == 0 and E.sync() == 0
+            assert np.array_equal(snap[0], pres) and np.array_equal(snap[1], pvals), it
+            if prev_res is not None:
+                assert not np.array_equal(snap[0], prev_res) and not np.array_equal(snap[1][E.var_mask()], prev_vals[E.var_mask()])
+            prev_res, prev_vals = snap
+        else:
+            fr = E.eval_callback(xb[it & 1], it % 3 == 2, xptr=xp[it & 1])
+            snap = {k: fr[k].copy() for k in ("res",)}
+            snap_a = {k: v.copy() for k, v in fr["aero_con"].items()}
+            snap_j = {k: v.copy() for k, v in (fr["aero_jac"] or {}).items()}
+            snap_v = fr["vals"].copy() if fr["vals"] is not None else None
+            assert fr["rc"] == 0 and E.sync() == 0
+            assert np.array_equal(snap["res"], fr["res"]) and all(np.array_equal(snap_a[k], fr["aero_con"][k]) for k in snap_a), it
+            assert all(np.array_equal(snap_j[k], fr["aero_jac"][k]) for k in snap_j), it
+            assert snap_v is None or np.array_equal(snap_v, fr["vals"]), it
+    xb[0][:] = x0
+    xb[0][E.M + 7] = np.nan
+    _, _, rc = E.eval(xb[0], out=pvals, res_out=pres)
+    assert rc == 1
+    fr = E.eval_callback(xb[0], True, xptr=xp[0])
+    assert fr["rc"] == 1
+    xb[0][:] = x0
+    assert E.eval(xb[0], out=pvals, res_out=pres)[2] == 0
+
+
 def test_nonfinite_input_sets_status():
     prob, x0, _ = named_problem("3x32")
     E, _ = make_pair(prob)
