@@ -15,6 +15,7 @@ difference formed in the kernel ("node-function rows"; the user rows of con_user
 con_waypoint.py are more of them in the same table).  The first call for a new xdict evaluates every row in one
 launch; the other calls return slices of it.  xdict is never mutated.
 """
+import copy
 import json
 import math
 
@@ -259,14 +260,15 @@ def rows_of(pdict, unitdict, condition):
         # inside begin_callback() .. end_callback(): the key was checked once for this callback -- and the user rows are still
         # the very tuple it was checked with (con_user._device_rows replaces the tuple object whenever the rows change)
         return st.rows[1]
+    # what the table is built from, compared by value with private copies of what it was last built from (dict comparisons in C: a
+    # JSON dump of the waypoint / antenna tables per callback cost 5 us)
     user = tuple(tuple(r) for r in (pdict.get("gelato_amd_user_rows") or ()))
     key = (id(condition), condition["OptimizationMode"], tuple(condition.get(k) for k in (
         "altitude_perigee", "altitude_apogee", "inclination", "radius", "vel_tangential_geocentric",
-        "flightpath_vel_inertial_geocentric")), user,
-        json.dumps([condition.get("waypoint"), condition.get("antenna")], sort_keys=True))
+        "flightpath_vel_inertial_geocentric")), user, condition.get("waypoint"), condition.get("antenna"))
     cached = st.__dict__.get("rows")
     if cached is None or cached[0] != key:
-        st.rows = (key, _Rows(pdict, unitdict, condition, user))
+        st.rows = (copy.deepcopy(key), _Rows(pdict, unitdict, condition, user))
     if st._pinned is not None:
         st._pinned_cond = condition
         st._pinned_user = pdict.get("gelato_amd_user_rows")
@@ -282,8 +284,8 @@ def _values(xdict, pdict, unitdict, condition, group):
 
 def _const_jac(pdict, unitdict, condition, group):
     j = rows_of(pdict, unitdict, condition).jac[group]
-    if pdict.get("gelato_amd_share_values"):   # constants: the cached arrays themselves (con_dynamics._copy_jac)
-        return {var: {"coo": list(b["coo"]), "shape": b["shape"]} for var, b in j.items()}
+    if pdict.get("gelato_amd_share_values"):   # constants: the cached block dicts themselves (con_dynamics._copy_jac)
+        return dict(j)
     return {var: {"coo": [b["coo"][0], b["coo"][1], b["coo"][2].copy()], "shape": b["shape"]} for var, b in j.items()}
 
 

@@ -130,6 +130,21 @@ def _jac(xdict, pdict, unitdict, condition, group, with_velocity):
             np.repeat(np.arange(n, dtype=np.int32), 3), np.array([3 * node + c for (_, _, node, _) in meta for c in range(3)], dtype=np.int32),
             np.arange(n, dtype=np.int32), np.array([sec for (_, sec, _, _) in meta], dtype=np.int32))
     rows3, cols3, rows1, secs = pat
+    if pdict.get("gelato_amd_share_values"):
+        # shared value arrays (rewritten by the next evaluation, like the defect groups'): the blocks are built once per table and
+        # group, the values copied into their arrays
+        sh = R.__dict__.setdefault("waypoint_shared", {}).get((group, with_velocity))
+        if sh is None:
+            sh = {"position": {"coo": [rows3, cols3, np.empty(3 * n)], "shape": (n, 3 * M)}}
+            if with_velocity:
+                sh["velocity"] = {"coo": [rows3, cols3, np.empty(3 * n)], "shape": (n, 3 * M)}
+            sh["t"] = {"coo": [rows1, secs, np.empty(n)], "shape": (n, S + 1)}
+            R.waypoint_shared[(group, with_velocity)] = sh
+        sh["position"]["coo"][2].reshape(n, 3)[:] = jfn[:, 0:3]
+        if with_velocity:
+            sh["velocity"]["coo"][2].reshape(n, 3)[:] = jfn[:, 3:6]
+        sh["t"]["coo"][2][:] = jfn[:, 6]
+        return dict(sh)
     # fresh arrays per call: ravel() of a column slice copies only when the group has more than one row (a one-row slice is
     # contiguous and would be a view of the buffer the next callback overwrites)
     jac = {"position": {"coo": [rows3, cols3, np.array(jfn[:, 0:3]).ravel()], "shape": (n, 3 * M)}}

@@ -426,3 +426,14 @@ def test_one_row_groups_return_fresh_jacobian_arrays():
             assert np.array_equal(first[var]["coo"][2], keep[var]), (jf.__name__, var, "the first call's values changed under the second")
             assert not np.shares_memory(first[var]["coo"][2], second[var]["coo"][2])
         assert any(not np.array_equal(second[var]["coo"][2], keep[var]) for var in keep)
+    # shared value arrays on request (like the defect groups'): the same numbers, in arrays that the next call rewrites in place
+    pdict["gelato_amd_share_values"] = True
+    for jf in (cw.equality_jac_posLLH, cw.inequality_jac_IIP, cw.inequality_jac_antenna):
+        pdict["gelato_amd_share_values"] = False
+        fresh1, fresh2 = jf(xdict, pdict, unitdict, condition), jf(x2, pdict, unitdict, condition)
+        pdict["gelato_amd_share_values"] = True
+        s1 = jf(xdict, pdict, unitdict, condition)
+        assert list(s1) == list(fresh1) and all(np.array_equal(s1[v]["coo"][2], fresh1[v]["coo"][2]) and s1[v]["shape"] == fresh1[v]["shape"]
+                                                and np.array_equal(s1[v]["coo"][0], fresh1[v]["coo"][0]) and np.array_equal(s1[v]["coo"][1], fresh1[v]["coo"][1]) for v in s1)
+        s2 = jf(x2, pdict, unitdict, condition)
+        assert s2 is not s1 and all(s2[v]["coo"][2] is s1[v]["coo"][2] and np.array_equal(s2[v]["coo"][2], fresh2[v]["coo"][2]) for v in s2)
