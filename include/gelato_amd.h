@@ -169,6 +169,10 @@ int gel_expand_full_device(gel_problem* p, int32_t B, const double* d_jvar, doub
  * next such call (the reference returns fresh arrays, lib/con_dynamics.py:108-113; pyoptsparse copies what it is given at once).
  * *x0, *x1 [num_vars]: two pinned decision-vector buffers; a one-vector call whose x is one of them reads it in place (two, so that a
  * caller can keep the previous vector for comparison while it fills the next).  Any of the four out-pointers may be NULL. */
+/* One-vector calls (gel_eval, gel_eval_jacobian, gel_eval_callback) return when the kernel itself has told the host that its results
+ * are in the pinned buffers (its last workgroup stores a sequence number there after every workgroup's system-scope release), 4-5 us
+ * before the runtime's end-of-kernel signal; the handle's stream may still hold the kernel's tail, and whatever is launched on it
+ * next is ordered behind.  Environment GEL_DONE_FLAG=0: wait for the runtime's signal instead. */
 int gel_pinned_buffers(gel_problem* p, double** res, double** vals_full, double** x0, double** x1);
 /* The same result without rewriting the constants (the reference rebuilds every COO value per call,
  * lib/con_dynamics.py:108-111,491-494,627-630): gel_fill_full_device lays the constant template into d_jfull [B][total_nnz]
