@@ -709,6 +709,36 @@ def test_self_signalling_launch_has_delivered_everything_when_it_says_so():
     assert E.eval(xb[0], out=pvals, res_out=pres)[2] == 0
 
 
+def test_self_signalling_calls_between_other_work_on_the_stream_and_on_two_handles():
+    """The host returns from a one-vector call while the handle's stream still holds the kernel's tail: a batch launched right
+    behind it through the device-pointer API, another one-vector call, and a second handle working in between all see what they
+    should."""
+    import torch
+    from gelato_amd import Engine, con_dynamics, pack_x, problem
+    pd1, ud1, _c, xd1 = problem.make_problem("mixed-6x64")
+    pd2, ud2, _c, xd2 = problem.make_problem("example")
+    E1, E2 = Engine(con_dynamics.problem_arrays(pd1, ud1)), Engine(con_dynamics.problem_arrays(pd2, ud2))
+    x1, x2 = pack_x(xd1), pack_x(xd2)
+    ref1 = E1.eval(x1)[:2]
+    ref2 = E2.eval(x2)[:2]
+    dev = torch.device("cuda:0")
+    B = 64
+    X = np.tile(x1, (B, 1))
+    dX = torch.from_numpy(X).to(dev)
+    dr = torch.empty((B, E1.nres), dtype=torch.float64, device=dev)
+    dj = torch.empty((B, E1.V), dtype=torch.float64, device=dev)
+    for it in range(60):
+        r1, v1, rc1 = E1.eval(x1)
+        E1.eval_batch_device(B, dX.data_ptr(), dr.data_ptr(), dj.data_ptr())      # the handle's own stream, right behind the call
+        r2, v2, rc2 = E2.eval(x2)
+        r1b, v1b, rc1b = E1.eval(x1 * (1.0 + 1e-9))
+        assert rc1 == 0 and rc2 == 0 and rc1b == 0
+        assert np.array_equal(r1, ref1[0]) and np.array_equal(v1, ref1[1]) and np.array_equal(r2, ref2[0]) and np.array_equal(v2, ref2[1])
+        assert not np.array_equal(r1b, r1)
+    assert E1.sync() == 0
+    assert np.array_equal(dr[B - 1].cpu().numpy(), ref1[0]) and np.array_equal(E1.expand(dj[B - 1:].cpu().numpy())[0], ref1[1])
+
+
 def test_nonfinite_input_sets_status():
     prob, x0, _ = named_problem("3x32")
     E, _ = make_pair(prob)
