@@ -208,7 +208,15 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   const int dsw = __builtin_amdgcn_readfirstlane(ck.z);  // first gel_double4 of this work item in Dsw
   const int j = PACK ? (lane & 31) : j0 + lane;  // node inside the phase (PACK: one chunk per phase, j0 = 0)
   const PhaseDev ph = load_phase(P.phases + sec);  // by value, in SGPRs, before any store
-  if (SPLIT && part && (!ph.air || !JAC)) return;  // only aerodynamic phases have the long position sweeps (and only with derivatives)
+  // Latency form of a WHOLE one-vector VALUES-ONLY evaluation (the optimiser's objfunc): the four wavefronts of a workgroup are the
+  // four parts of ONE work item, of which only the lead has anything to do -- so each forms one 16-row tile of D.X (17 instead of 68
+  // matrix instructions in the lead; the state rows cross the bus once, a quarter per wavefront); the tiles meet in the lead's
+  // staging tile at a workgroup barrier and the other parts leave.  6 x 64: values-only callback 24.0 -> 20.4 us, objfunc through
+  // the Python mirrors 36.8 -> 33.3 us.  With derivatives the launch is bounded by the PCIe drain of its 240 KB of results, and the
+  // barriers cost small phases more than the split saves (example: 26.2 -> 29.3 us): the lead multiplies alone there.
+  const bool csplit = SPLIT && MFMA && !JAC && B == 1 && res != nullptr && P.split_vel && !((P.unit0 | P.nunits) & 3);   // wave-uniform (kernel arguments)
+  const bool only_dx = SPLIT && part && (!ph.air || !JAC);
+  if (only_dx && !csplit) return;  // only aerodynamic phases have the long position sweeps (and only with derivatives)
   const bool lead = !(SPLIT && part);     // the wavefront that owns everything but the split-off sweeps
   const int n = ph.n;
   // the matrix pipe reads all 64 lanes: lanes past the end of a ragged phase stay alive (with zero
@@ -439,7 +447,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     bool ref0_done = false;
     // D.X rows (lib/con_dynamics.py:54,146,256,524)
     double lm = 0.0, lr[3] = {0, 0, 0}, lv[3] = {0, 0, 0}, lq[4] = {0, 0, 0, 0};
-    if (rb) {
+    if (rb || csplit) {
       if (XLDS && (PACK || !LONGP || n < kXldsPipeFrom)) {   // !LONGP: the launcher vouches that no phase is longer
         // [64 x (n+1)] . [(n+1) x 44] per WORKGROUP, operands as in the branch below, but B comes from LDS: every wavefront
         // stages ITS OWN vector's n + 1 <= 68 state rows (17 k-steps) -- lane = row, the eleven interleaved columns (mass |
@@ -744,6 +752,86 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
 #pragma unroll
         for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
+      } else if (MFMA && csplit) {
+        // SPLIT, whole one-vector evaluation: this wavefront's row tile (rows 16 part .. + 15) of [64 x (n+1)] . [(n+1) x 11]; A operands
+        // row-tile major (ProblemDev::Dst, 512 B per k-step), B as in the branch below.
+        const int c16 = lane & 15, kq = lane >> 4;
+        const double* bp = xm + ph.xa;
+        int bs = 1;
+        if (c16 >= 1 && c16 < 4) { bp = xr + 3 * ph.xa + (c16 - 1); bs = 3; }
+        if (c16 >= 4 && c16 < 7) { bp = xv + 3 * ph.xa + (c16 - 4); bs = 3; }
+        if (c16 >= 7) { bp = xq + 4 * ph.xa + ((c16 < 11) ? (c16 - 7) : 0); bs = 4; }
+        gel_double4 acc1 = gel_double4{0.0, 0.0, 0.0, 0.0};
+        const double* ap1 = P.Dst + (size_t)dsw * 4 + part * 64 + lane;
+        const unsigned un = (unsigned)n, ubs = (unsigned)bs;
+        if (tail1 && rb) {   // wave-uniform addresses (the lead adds the last state row after the hand-over)
+          xl[0] = xm[ph.xa + n];
+#pragma unroll
+          for (int c = 0; c < 3; c++) { xl[1 + c] = xr[3 * (ph.xa + n) + c]; xl[4 + c] = xv[3 * (ph.xa + n) + c]; }
+#pragma unroll
+          for (int c = 0; c < 4; c++) xl[7 + c] = xq[4 * (ph.xa + n) + c];
+        }
+        constexpr int kSplitB = SPLITB, kSplitA = 4;
+        if (n < kSlabRowsMax) {
+          // phases of at most 67 nodes: the state rows cross the bus ONCE -- every wavefront fetches a quarter of the [68][11] image
+          // (x of a one-vector call sits in pinned HOST memory, which no cache holds: four wavefronts each reading every row was
+          // four times the PCIe traffic), into the region of part 1; one more barrier, then the B operands come from LDS
+          lds_double* img = wave_lds + (1 - part) * kWL;
+          constexpr int kQRows = kSlabRowsMax / 4, kQ = kQRows * 11;   // 17 rows = 187 values per wavefront
+#pragma unroll
+          for (int i = 0; i < (kQ + 63) / 64; i++) {
+            const int e = lane + 64 * i;
+            const int rl = (e * 373) >> 12, c = e - 11 * rl;           // e / 11, e % 11 for e < 192
+            const int r = kQRows * part + rl;
+            if (e < kQ) {
+              const int xr_ = ph.xa + min(r, n);
+              const int off = (c == 0) ? xr_ : ((c < 4) ? M + 3 * xr_ + (c - 1) : ((c < 7) ? 4 * M + 3 * xr_ + (c - 4) : 7 * M + 4 * xr_ + (c - 7)));
+              const double v = xb[off];
+              img[r * 11 + c] = (r <= n) ? v : 0.0;                   // rows past the phase meet zero columns of D: they hold zeros
+            }
+          }
+          double a1[kSplitA];
+#pragma unroll
+          for (int i = 0; i < kSplitA; i++) a1[i] = ap1[min(i, ksteps - 1) * 256];
+          __syncthreads();
+          const int bo = kq * 11 + ((c16 < 11) ? c16 : 0);
+#pragma unroll
+          for (int i = 0; i < kSlabRowsMax / 4; i++) {
+            if (i < ksteps) {   // wave-uniform
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i % kSplitA], img[bo + 44 * i], acc1, 0, 0, 0);
+              a1[i % kSplitA] = ap1[min(i + kSplitA, ksteps - 1) * 256];
+            }
+          }
+        } else {
+          for (int k0 = 0; k0 < ksteps; k0 += kSplitB) {
+            double bl[kSplitB], a1[kSplitA];
+#pragma unroll
+            for (int i = 0; i < kSplitB; i++) bl[i] = bp[min(4u * (k0 + i) + kq, un) * ubs];
+#pragma unroll
+            for (int i = 0; i < kSplitA; i++) a1[i] = ap1[min(k0 + i, ksteps - 1) * 256];
+#pragma unroll
+            for (int i = 0; i < kSplitB; i++) {
+              if (k0 + i < ksteps) {   // wave-uniform
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i % kSplitA], bl[i], acc1, 0, 0, 0);
+                a1[i % kSplitA] = ap1[min(k0 + i + kSplitA, ksteps - 1) * 256];
+              }
+            }
+          }
+        }
+        // the tile into the LEAD's staging tile (the lead is wavefront `part` places before this one), one barrier, the lead takes its rows
+        lds_double* lead_lds = wave_lds - part * kWL;
+#pragma unroll
+        for (int i = 0; i < 4; i++) lead_lds[(16 * part + kq + 4 * i) * kStageLd + c16] = acc1[i];
+        __syncthreads();
+        if (only_dx) return;
+        if (rb) {
+          lds_double* row = wave_lds + lane * kStageLd;
+          lm = row[0];
+#pragma unroll
+          for (int c = 0; c < 3; c++) { lr[c] = row[1 + c]; lv[c] = row[4 + c]; }
+#pragma unroll
+          for (int c = 0; c < 4; c++) lq[c] = row[7 + c];
+        }
       } else if (MFMA) {
         // SPLIT (latency form): one wavefront multiplies alone.
         // [64 x (n+1)] . [(n+1) x 11] per wavefront as 4 row tiles of v_mfma_f64_16x16x4_f64.
