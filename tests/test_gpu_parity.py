@@ -739,6 +739,24 @@ def test_self_signalling_calls_between_other_work_on_the_stream_and_on_two_handl
     assert np.array_equal(dr[B - 1].cpu().numpy(), ref1[0]) and np.array_equal(E1.expand(dj[B - 1:].cpu().numpy())[0], ref1[1])
 
 
+@pytest.mark.parametrize("nn", [(64,), (5, 33, 67), (70, 5), (128, 7), (2, 16, 4)])
+def test_values_only_callback_splits_the_product_over_the_four_wavefronts(nn):
+    """A values-only one-vector launch forms D.X as four row tiles, one per wavefront of the work item, from a state-row image staged
+    once (phases up to 67 nodes) or from direct loads (longer phases): the residual rows are those of the evaluation with
+    derivatives (where the lead wavefront multiplies alone) and of the residual-only batch launch, bit for bit."""
+    import states
+    prob, x = states.long_state(nn)
+    E, _P = make_pair(prob)
+    fr = E.eval_callback(x, False)
+    res_v = fr["res"].copy()
+    fr2 = E.eval_callback(x, True)
+    assert fr["rc"] == 0 and fr2["rc"] == 0 and np.array_equal(res_v, fr2["res"])
+    r1, rc = E.eval_residual(x)
+    assert rc == 0 and np.array_equal(res_v, r1)
+    rb, _, rc = E.eval_batch(np.tile(x, (8, 1)), want_jac=False)
+    assert rc == 0 and np.array_equal(rb[5], res_v)
+
+
 def test_nonfinite_input_sets_status():
     prob, x0, _ = named_problem("3x32")
     E, _ = make_pair(prob)
