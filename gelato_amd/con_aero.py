@@ -69,9 +69,16 @@ def _configure_all(pdict, unitdict, condition):
     # inside begin_callback() .. end_callback() the condition dict is read once (the caller vouches it is not modified, like xdict)
     if st._pinned is not None and st._pinned_aero is not None and st._pinned_aero[0] is condition:
         return st, st._pinned_aero[1]
-    n = {}
-    for kind in _KINDS:
-        st, n[kind] = _configured(pdict, unitdict, condition, kind)
+    # the three tables against private copies of the ones last configured, in one comparison (else kind by kind)
+    tabs = (condition.get("AOA_max"), condition.get("dynamic_pressure_max"), condition.get("Q_alpha_max"))
+    last = st.__dict__.get("aero_seen_all")
+    if last is not None and tabs == last[0]:
+        n = last[1]
+    else:
+        n = {}
+        for kind in _KINDS:
+            st, n[kind] = _configured(pdict, unitdict, condition, kind)
+        st.aero_seen_all = (copy.deepcopy(tabs), n)
     if st._pinned is not None:
         st._pinned_aero = (condition, n)
     return st, n

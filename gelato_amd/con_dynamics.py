@@ -65,6 +65,7 @@ class _State:
         self._pinned_aero = None
         self._pinned_fr = None
         self._jd = None
+        self._rd = None
         # two persistent packed-x buffers (and their ctypes pointers), used in turn: the one that is not the cached frame's receives
         # the next decision vector, so the frame's x stays intact for the comparison that decides whether the frame can be reused
         # (the handle's own pinned buffers where there is a device: the kernel then reads the vector in place)
@@ -105,7 +106,12 @@ class _State:
         return fr
 
     def residuals(self, xdict):
-        return self.engine.split_res(self.frame(xdict, False)["res"])
+        res = self.frame(xdict, False)["res"]
+        # views of the engine's residual vector (rewritten in place by every evaluation): built once per array
+        rd = self._rd
+        if rd is None or rd[0] is not res:
+            rd = self._rd = (res, self.engine.split_res(res))
+        return rd[1]
 
     def jacobians(self, xdict):
         vals = self.frame(xdict, True)["vals"]
