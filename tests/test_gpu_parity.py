@@ -757,6 +757,31 @@ def test_values_only_callback_splits_the_product_over_the_four_wavefronts(nn):
     assert rc == 0 and np.array_equal(rb[5], res_v)
 
 
+def test_placed_batch_buffers_hold_the_same_results():
+    """gelato_amd.placement: candidate allocations of the resident x / res / jvar buffers, the fastest kept -- whichever it is, a launch
+    on it writes the bits a launch on plain buffers writes, and the report names every candidate."""
+    import torch
+    from gelato_amd import problem
+    from gelato_amd.placement import place_batch_buffers
+    prob, x0, _ = named_problem("mixed-6x64")
+    E, _P = make_pair(prob)
+    B = 512
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    dX0 = torch.from_numpy(problem.synthetic_batch(x0, E.M, B, seed=5)).to(dev)
+    dX, dres, djv, rep = place_batch_buffers(E, dX0, tries=3, launches=2, warm=1, stream=s)
+    assert rep["tries"] == 3 and 0 <= rep["chosen"] < 3 and len(rep["candidates"]) == 3 and rep["all_launches"] == 9
+    assert torch.equal(dX, dX0) and dX.data_ptr() != dX0.data_ptr()
+    assert rep["candidates"][rep["chosen"]]["ms_per_launch"] == min(c["ms_per_launch"] for c in rep["candidates"])
+    r = torch.empty_like(dres)
+    j = torch.empty_like(djv)
+    E.eval_batch_device(B, dX0.data_ptr(), r.data_ptr(), j.data_ptr(), s)
+    E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), s)
+    assert E.sync(s) == 0 and torch.equal(r, dres) and torch.equal(j, djv)
+    dX2, dres2, djv2, rep2 = place_batch_buffers(E, dX0, want_jac=False, tries=2, launches=1, warm=0, stream=s)
+    assert djv2 is None and rep2["tries"] == 2 and dres2.shape == (B, E.nres)
+
+
 def test_nonfinite_input_sets_status():
     prob, x0, _ = named_problem("3x32")
     E, _ = make_pair(prob)
