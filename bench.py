@@ -178,7 +178,7 @@ def main():
                     help="engine creation flags (include/gelato_amd.h): 8 = GEL_FLAG_FD_RECOMPUTE, the reference-literal form that "
                          "re-runs the RHS chain on every perturbed column (lib/con_dynamics.py:353-480,580-604); 1 / 2 force D.X onto "
                          "the matrix pipe / the vector unit; 4 = never two vectors per wavefront")
-    ap.add_argument("--placement-tries", type=int, default=5, dest="placement_tries",
+    ap.add_argument("--placement-tries", type=int, default=8, dest="placement_tries",
                     help="candidate placements of the resident batch buffers measured before anything is timed (1: take what the allocator gives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",

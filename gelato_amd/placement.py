@@ -12,7 +12,7 @@ import random
 import torch
 
 
-def place_batch_buffers(engine, x_device, want_jac=True, tries=5, launches=16, warm=8, stream=0, seed=0):
+def place_batch_buffers(engine, x_device, want_jac=True, tries=8, launches=16, warm=8, stream=0, seed=0):
     """x_device: torch tensor [B, nvars] float64 on the engine's device (the master copy; a clone of it is returned).
     -> (dX, dres, djvar | None, report): the set of buffers on which `launches` fused launches ran fastest, and what was measured."""
     B = int(x_device.shape[0])
