@@ -1011,7 +1011,6 @@ int gel_problem_create(const gel_problem_desc* d, gel_problem** out) {
     std::vector<int32_t> colmap;
     int c0 = 0;
     for (int i = 0; i < S; i++) {
-      const HostPhase& h = p->ph[i];
       sub[i].ua = 0; sub[i].xa = 0; sub[i].voff = 0;
       p->sub_chunk0.push_back(c0);
       int cnt = 0;
