@@ -378,7 +378,8 @@ def main():
             d = json.load(open(path))
         except Exception as ex:  # noqa: BLE001
             return None, "unreadable: %s" % ex
-        if d.get("build_so_sha256") != build["so_sha256"]:
+        same_device_code = d.get("build_device_code_sha256") is not None and d.get("build_device_code_sha256") == build.get("device_code_sha256")
+        if d.get("build_so_sha256") != build["so_sha256"] and not same_device_code:      # counters describe the DEVICE code
             return None, ("profiles/%s describes another build (so_sha256 %s..., git %s; loaded: %s...): not reported"
                           % (os.path.basename(path), str(d.get("build_so_sha256"))[:12], str(d.get("build_git_head"))[:10], build["so_sha256"][:12]))
         d["_file"] = os.path.basename(path)

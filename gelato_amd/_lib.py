@@ -148,6 +148,30 @@ def so_sha256(path=None):
     return h.hexdigest()
 
 
+def device_code_sha256(path=None):
+    """sha256 over the gfx950 code objects embedded in the library (the AMDGPU ELF images of its fat binary): what the device executes.
+    A change of the host code alone (a line number in an error string) changes so_sha256 but not this -- hardware counters recorded
+    with one library describe every library with the same device code."""
+    import hashlib, struct
+    b = open(path or SO_PATH, "rb").read()
+    h = hashlib.sha256()
+    off, n = 1, 0
+    while True:
+        i = b.find(b"\x7fELF", off)
+        if i < 0:
+            break
+        if i + 0x40 <= len(b) and struct.unpack_from("<H", b, i + 18)[0] == 224:      # EM_AMDGPU
+            shoff = struct.unpack_from("<Q", b, i + 0x28)[0]
+            shentsize, shnum = struct.unpack_from("<HH", b, i + 0x3A)
+            size = shoff + shentsize * shnum
+            h.update(b[i:i + size])
+            n += 1
+            off = i + max(size, 4)
+        else:
+            off = i + 4
+    return h.hexdigest() if n else None
+
+
 def _write_build_info():
     """Provenance of the in-tree library, written where it is built (this container has the git history, the GPU box does not;
     the file travels with the snapshot): recorded counter files name the build they describe, bench.py ignores the others."""
@@ -174,7 +198,7 @@ def build_info():
     """{"so_sha256": of the library that is LOADED (GELATO_AMD_LIB honoured), "git_head", "git_dirty": of the build that produced
     the in-tree library, if that is the one loaded}"""
     import json
-    out = {"so_sha256": so_sha256(), "git_head": None, "git_dirty": None}
+    out = {"so_sha256": so_sha256(), "git_head": None, "git_dirty": None, "device_code_sha256": device_code_sha256()}
     try:
         rec = json.load(open(BUILD_INFO_PATH))
         if rec.get("so_sha256") == out["so_sha256"]:

@@ -221,6 +221,11 @@ def test_static_counter_files_name_their_build():
         assert "workload" in d and "batch" in d, f
         shas.add(d["build_so_sha256"])
     assert len(shas) == 1
+    # ... and the hash of the gfx950 code objects inside it (what the counters describe): a host-only rebuild keeps them valid
+    dev = {json.load(open(f)).get("build_device_code_sha256") for f in files}
+    assert len(dev) == 1 and (None in dev or all(len(v) == 64 for v in dev))
+    if _lib.so_sha256() in shas and None not in dev:
+        assert _lib.device_code_sha256() in dev
 
 
 def test_a_replaced_shard_plan_is_refused_not_used():
