@@ -776,6 +776,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
           // phases of at most 67 nodes: the state rows cross the bus ONCE -- every wavefront fetches a quarter of the [68][11] image
           // (x of a one-vector call sits in pinned HOST memory, which no cache holds: four wavefronts each reading every row was
           // four times the PCIe traffic), into the region of part 1; one more barrier, then the B operands come from LDS
+          static_assert(!(SPLIT && MFMA && !JAC) || kSlabRowsMax * 11 <= kWL, "the state-row image must fit a wavefront's region");
           lds_double* img = wave_lds + (1 - part) * kWL;
           constexpr int kQRows = kSlabRowsMax / 4, kQ = kQRows * 11;   // 17 rows = 187 values per wavefront
 #pragma unroll
