@@ -239,8 +239,14 @@ def main():
         # data, one process: gelato_amd/placement.py).  Like a consumer that keeps its batch buffers, the bench places them once,
         # before anything is timed: a few candidate allocations, a handful of launches on each, the fastest kept.
         from gelato_amd.placement import place_batch_buffers
-        dX, dres, djv, placement = place_batch_buffers(E, dX, want_jac=not a.residual_only, tries=a.placement_tries, stream=stream,
-                                                      seed=rank)
+        try:
+            dX, dres, djv, placement = place_batch_buffers(E, dX, want_jac=not a.residual_only, tries=a.placement_tries, stream=stream,
+                                                          seed=rank)
+        except Exception as ex:  # noqa: BLE001  (e.g. not enough free memory for a second set of buffers): what the allocator gives
+            torch.cuda.empty_cache()
+            placement = {"error": str(ex)[:200]}
+            dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+            djv = None if a.residual_only else torch.empty((B, E.V), dtype=torch.float64, device=dev)
     else:
         dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
         djv = None if a.residual_only else torch.empty((B, E.V), dtype=torch.float64, device=dev)
@@ -296,7 +302,7 @@ def main():
     WARM_MS = 40.0
     # every launch of this run is under HIP events, group by group: their mean is what a kernel trace of the whole run averages
     # (`roofline.kernel_ms_mean_of_all_launches`, beside the timed region's `kernel_ms`)
-    all_ms, all_n = (placement["all_launches_ms"], placement["all_launches"]) if placement else (0.0, 0)
+    all_ms, all_n = (placement["all_launches_ms"], placement["all_launches"]) if placement and "all_launches" in placement else (0.0, 0)
 
     def untimed(n):
         nonlocal all_ms, all_n
