@@ -3,8 +3,9 @@
 The fused launch streams three arrays at once -- it reads `x [B][nvars]` and writes `res [B][11N]` and `jvar [B][V]` -- and how their
 BASE addresses fall onto the HBM channels against one another moves the launch by up to 7 % (MI355X, 6 x 64, B = 65536: three
 distinct levels, 3.06 / 3.20 / 3.30 ms, for the same kernel and the same data in buffers allocated at different places of ONE
-process; each level reproduces to 0.1 %).  The mapping of address bits to channels is not documented, so the placement is
-chosen by measurement: a few allocations shifted by pads of random size, a handful of launches on each, the fastest kept, the others
+process; each level reproduces to 0.1 %).  It is the PHYSICAL backing that decides, not the virtual address: the 8.9 GB of `jvar`
+freed and allocated again at the SAME virtual address came back at 3.06, 3.27, 3.06, 3.06, 3.27 ms (x alone moves 3 %, res nothing),
+and nothing a process can see predicts it.  So the placement is chosen by measurement: a few allocations shifted by pads of random size, a handful of launches on each, the fastest kept, the others
 freed.  A consumer that keeps its batch buffers for many launches (an optimiser's population, a Monte-Carlo sweep) pays this once.
 """
 import random
