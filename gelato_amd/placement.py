@@ -13,41 +13,66 @@ import random
 import torch
 
 
+def _measure(engine, B, dX, dres, djv, warm, launches, stream):
+    dev = dX.device
+    jp = djv.data_ptr() if djv is not None else 0
+    ew, e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    ew.record(torch.cuda.current_stream(dev))
+    for _ in range(warm):      # untimed: page tables, and the clock's dip after the pause of the allocation
+        engine.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), jp, stream)
+    e0.record(torch.cuda.current_stream(dev))
+    for _ in range(launches):
+        engine.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), jp, stream)
+    e1.record(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / launches, ew.elapsed_time(e1)
+
+
 def place_batch_buffers(engine, x_device, want_jac=True, tries=8, launches=16, warm=8, stream=0, seed=0):
     """x_device: torch tensor [B, nvars] float64 on the engine's device (the master copy; a clone of it is returned).
-    -> (dX, dres, djvar | None, report): the set of buffers on which `launches` fused launches ran fastest, and what was measured."""
+    -> (dX, dres, djvar | None, report): the buffers on which `launches` fused launches ran fastest, and what was measured.
+    Two stages, because the arrays matter independently (jvar most): `tries` candidates of jvar against the first (x, res), then
+    `tries` - 3 candidates of (x, res) against the best jvar."""
     B = int(x_device.shape[0])
     dev = x_device.device
     rng = random.Random(seed)
-    best, report = None, []
+    report = []
     all_ms, all_n = 0.0, 0
-    for t in range(max(1, int(tries))):
-        pad = None
-        if t:      # the first candidate is where the allocator puts the buffers by itself
-            torch.cuda.empty_cache()
-            pad = torch.empty(rng.randrange(64, 4096) * (1 << 17), dtype=torch.float64, device=dev)   # 64 MB .. 4 GB
-        dX = x_device.clone()
-        dres = torch.empty((B, engine.nres), dtype=torch.float64, device=dev)
+
+    def pad():
+        torch.cuda.empty_cache()
+        return torch.empty(rng.randrange(64, 4096) * (1 << 17), dtype=torch.float64, device=dev)   # 64 MB .. 4 GB
+
+    dX = x_device.clone()
+    dres = torch.empty((B, engine.nres), dtype=torch.float64, device=dev)
+    best_j, best = None, None
+    n1 = max(1, int(tries)) if want_jac else 1
+    for t in range(n1):      # stage 1: jvar (the first candidate is where the allocator puts it by itself)
+        p_ = pad() if t else None
         djv = torch.empty((B, engine.V), dtype=torch.float64, device=dev) if want_jac else None
-        del pad
-        jp = djv.data_ptr() if want_jac else 0
-        ew, e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        ew.record(torch.cuda.current_stream(dev))
-        for _ in range(warm):      # untimed: page tables, and the clock's dip after the pause of the allocation
-            engine.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), jp, stream)
-        e0.record(torch.cuda.current_stream(dev))
-        for _ in range(launches):
-            engine.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), jp, stream)
-        e1.record(torch.cuda.current_stream(dev))
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / launches
-        all_ms += ew.elapsed_time(e1)
-        all_n += warm + launches
-        report.append({"ms_per_launch": ms, "x": hex(dX.data_ptr()), "res": hex(dres.data_ptr()), "jvar": hex(jp) if jp else None})
-        if best is None or ms < best[0]:
-            best = (ms, dX, dres, djv, t)
-        del dX, dres, djv
+        del p_
+        ms, tot = _measure(engine, B, dX, dres, djv, warm, launches, stream)
+        all_ms += tot; all_n += warm + launches
+        report.append({"stage": "jvar", "ms_per_launch": ms, "x": hex(dX.data_ptr()), "res": hex(dres.data_ptr()),
+                       "jvar": hex(djv.data_ptr()) if djv is not None else None})
+        if best is None or ms < best:
+            best, best_j, chosen = ms, djv, len(report) - 1
+        del djv
+    bx, br = dX, dres
+    n2 = max(0, int(tries) - (3 if want_jac else 1))
+    for t in range(n2):      # stage 2: x and res against the best jvar
+        p_ = pad()
+        cx = x_device.clone()
+        cr = torch.empty((B, engine.nres), dtype=torch.float64, device=dev)
+        del p_
+        ms, tot = _measure(engine, B, cx, cr, best_j, warm, launches, stream)
+        all_ms += tot; all_n += warm + launches
+        report.append({"stage": "x, res", "ms_per_launch": ms, "x": hex(cx.data_ptr()), "res": hex(cr.data_ptr()),
+                       "jvar": hex(best_j.data_ptr()) if best_j is not None else None})
+        if ms < best:
+            best, bx, br, chosen = ms, cx, cr, len(report) - 1
+        del cx, cr
+    del dX, dres
     torch.cuda.empty_cache()
-    ms, dX, dres, djv, chosen = best
-    return dX, dres, djv, {"tries": len(report), "launches_per_try": launches, "warm_launches_per_try": warm, "chosen": chosen,
-                           "candidates": report, "all_launches": all_n, "all_launches_ms": all_ms}
+    return bx, br, best_j, {"tries": len(report), "launches_per_try": launches, "warm_launches_per_try": warm, "chosen": chosen,
+                            "candidates": report, "all_launches": all_n, "all_launches_ms": all_ms}
