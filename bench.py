@@ -216,6 +216,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        # the communicator is set up lazily by the first collective: here, not by the barrier in front of the timed region (which would
+        # leave the GPU idle for the hundreds of milliseconds of that set-up right before the K timed steps)
+        dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
 
     from gelato_amd import Engine, con_dynamics, pack_x, problem
 
