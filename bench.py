@@ -687,6 +687,55 @@ def main():
                                                           "buffer_placement_ms": [round(c, 4) for c in cand]}
         except Exception as ex:  # noqa: BLE001
             out["aero_constraints"] = {"error": str(ex)}
+        # [r6] defect groups + aero rows of the SAME resident batch: one call whose fused launch writes the aero rows from the
+        # lanes of the aerodynamic phases (gel_eval_batch_aero_device), against the two kernels one after the other
+        try:
+            width, _oc, _oj = E.aero_record_layout()
+            dims = [E.aero_dims(k) for k in E.AERO_KINDS]
+            daero = torch.empty((B, width), dtype=torch.float64, device=dev)
+            dcon = [torch.empty((B, d[0]), dtype=torch.float64, device=dev) for d in dims]
+            djac = [torch.empty((B, sum(d[1])), dtype=torch.float64, device=dev) for d in dims]
+            cp, jp = [t.data_ptr() for t in dcon], [t.data_ptr() for t in djac]
+
+            def fused_call():
+                E.eval_batch_aero_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), daero.data_ptr(), stream)
+
+            def two_calls():
+                E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv.data_ptr(), stream)
+                E.eval_aero_all_device(B, dX.data_ptr(), cp, jp, stream)
+
+            def time_of(fn, n=12, warm=12):
+                for _ in range(warm):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n
+            ms_two = time_of(two_calls)
+            ms_one = time_of(fused_call)
+            ms_two2 = time_of(two_calls)
+            ms_one2 = time_of(fused_call)
+            ms_def = time_of(step)
+            a_bytes = E.algorithmic_bytes + 8 * width
+            out["defect_plus_aero"] = {
+                "batch": B, "aero_rows": rows, "aero_values_per_vector": width,
+                "one_call_ms": min(ms_one, ms_one2), "two_kernels_ms": min(ms_two, ms_two2), "defect_alone_ms": ms_def,
+                "ns_per_vector_one_call": 1e6 * min(ms_one, ms_one2) / B, "ns_per_vector_two_kernels": 1e6 * min(ms_two, ms_two2) / B,
+                "ns_per_vector_defect_alone": 1e6 * ms_def / B,
+                "ms_all_runs": {"one_call": [ms_one, ms_one2], "two_kernels": [ms_two, ms_two2]},
+                # SURVEY 8(d)'s A_min of the defect path + the aero rows and gradient values written once (x is read once for both)
+                "algorithmic_bytes_per_vector": a_bytes,
+                "frac": a_bytes * B / (min(ms_one, ms_one2) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "gel_eval_batch_aero_device: ONE fused launch (defect groups + the aero rows of the aerodynamic phases' nodes 1..n from "
+                        "the same chain) + a small launch for state node 0 of every phase, against gel_eval_batch_device followed by "
+                        "gel_eval_aero_all_device; 12 warm-up + 12 timed calls each, twice, alternating; HIP events; same values bit for bit "
+                        "(tests/test_aero_engine.py)"}
+            del daero, dcon, djac
+        except Exception as ex:  # noqa: BLE001
+            out["defect_plus_aero"] = {"error": str(ex)[:300]}
 
     if not a.no_other_configs and not a.no_extras and not shard and not a.residual_only and a.workload == "mixed-6x64" and a.flags == 0:
         # The other BASELINE.json configurations in front of the driver, after the headline's timed region:

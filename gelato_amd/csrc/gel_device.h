@@ -59,6 +59,22 @@ struct AeroNodeDev {
   double limit[3];
 };
 
+// Aero rows written by the FUSED kernel (gel_eval_kernel.h, AERO instantiation; gel_eval_batch_aero_device): one record per phase.
+// The lanes of an aerodynamic phase's wavefront are its state nodes 1 .. n; where the phase has an "all nodes" spec of a kind they
+// also write that kind's constraint value and gradient entries of their node, from the centre evaluation and the position /
+// velocity / quaternion sweeps they run anyway.  Outputs: ONE record of aero_ld doubles per decision vector,
+// [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha], each part laid out like gel_eval_aero_all's arrays
+// (jac of a kind: position | velocity | quaternion | t blocks of R rows, a spec's entries [column][node]).  Byte offsets are
+// relative to the vector's record and name node 1 (lane 0 of the phase's first chunk), column 0.
+struct AeroPhaseDev {
+  int32_t kinds;       // bit k: nodes 1 .. n of this phase have a row of kind k AND the phase runs the aerodynamic chain
+  int32_t nk8;         // 8 (n + 1): bytes between two columns of a spec's gradient block
+  int32_t con[3];      // kind k: the constraint value
+  int32_t jac[3][4];   // kind k, block (0 position, 1 velocity, 2 quaternion, 3 t): the gradient entry
+  double il[3];        // 1 / limit (limit = units[3] of con_aero.py), divided on the host (the same IEEE quotient the kernels' frcp forms)
+  double ilx[3];       // (1 / limit) * (1 / dx): what every gradient entry of the kind is scaled by
+};
+
 // knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py): see gel_kernels.hip rows_kernel
 struct LinRowDev { int32_t idx0, idx1; double coef0, coef1, c0; };  // (coef0 x[idx0] + coef1 x[idx1]) + c0; idx1 < 0: one term
 // f(position, velocity of state node `node`[, knot time x_t[tcol]]) mapped by `mode` (gel_kernels.hip rows_kernel):
@@ -120,6 +136,11 @@ struct ProblemDev {
   double* coo_full;
   const int32_t* coo;   // [8 * S]
   int32_t split_vel;    // latency form, whole evaluations only: velocity sweep k runs in the wavefront of position sweep k
+  // fused aero rows (AERO instantiation of the cooperative form only; null otherwise): per-phase records, the batch's output
+  // records [B][aero_ld]
+  const AeroPhaseDev* aero_ph;
+  double* aero_out;
+  int64_t aero_ld;
 };
 
 }  // namespace gel

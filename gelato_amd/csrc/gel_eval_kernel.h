@@ -114,7 +114,11 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 // that are not cooperative a workgroup may have any number of wavefronts (each its own work item).
 // SPLITB (split form): k-steps of D.X whose state column is requested at once -- 17 (a whole 64-node phase) inside callback_kernel,
 // which has registers to spare; 9 in the stand-alone launch, which is held to 128 VGPRs.
-template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, int SPLITB = 9, bool LONGP = true, bool NTS = true>
+// AERO (throughput form with derivatives, one vector per wavefront; gel_eval_batch_aero_device): the lanes of an aerodynamic phase
+// also write the aero path constraints of their state node (lib/con_aero.py:89-248,311-371) -- value and forward-difference
+// gradient of the angle of attack, the dynamic pressure and their product -- from the centre evaluation and the position sweeps
+// they run anyway: the geodetic -> atmosphere -> wind chain once per node instead of once here and once in aero_kernel.
+template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, int SPLITB = 9, bool LONGP = true, bool NTS = true, bool AERO = false>
 __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const double* __restrict__ x, double* __restrict__ res,
                                           double* __restrict__ jvar, const unsigned vblk) {
   extern __shared__ double lds[];
@@ -143,6 +147,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // COOP: the throughput form with D.X on the matrix pipe.  A workgroup = ONE work item x FOUR decision vectors;
   // its wavefronts share the A operand (D) and form the product together (see phase A).
   constexpr bool COOP = MFMA && !SPLIT;
+  static_assert(!AERO || (JAC && MFMA && !SPLIT && !PACK), "the aero rows ride in the cooperative form with derivatives, one vector per wavefront");
   static_assert(!COOP || kBlock == 256, "the cooperative D.X form is written for four wavefronts per workgroup");
   static_assert(!PACK || COOP, "two vectors per wavefront exist in the cooperative form only");
   constexpr int kVecWg = PACK ? 8 : 4;   // decision vectors per workgroup
@@ -301,6 +306,20 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     if (!rb) GEL_CHK(_v);                                                                 \
   } while (0)
 #define EMIT(slot, val) EMIT_AT(((int)(slot) - (SPLIT ? (((int)(slot) >= kSlotVP) ? sub_hi : sub_lo) : 0)) * cw8, val)
+  // AERO: this phase's record (scalar loads where a field is used), the vector's output record as a buffer resource (wave-uniform
+  // base; lane offset jvo; field offsets on the scalar unit), streamed like the Jacobian values.  A store of node j0 + lane + 1:
+  // field + column * nk8 + 8 j0 bytes into the record.
+  const AeroPhaseDev* const aph = AERO ? P.aero_ph + sec : nullptr;
+  const int akinds = AERO ? __builtin_amdgcn_readfirstlane(load_const(&aph->kinds)) : 0;   // 0: no aero rows in this phase
+  const __amdgpu_buffer_rsrc_t ars =
+      __builtin_amdgcn_make_buffer_rsrc(AERO ? (void*)(P.aero_out + (size_t)b * P.aero_ld) : (void*)nullptr, 0, -1, 0x00020000);
+#define AEMIT(byteoff, val)                                                              \
+  do {                                                                                  \
+    const double _v = (val);                                                            \
+    gel_u2 _d;                                                                          \
+    __builtin_memcpy(&_d, &_v, 8);                                                      \
+    __builtin_amdgcn_raw_buffer_store_b64(_d, ars, jvo, (byteoff), GEL_STORE_AUX);      \
+  } while (0)
 // (latency form: the rows go to pinned host memory -- streamed, so that they cross PCIe while the wavefront computes on instead of
 // waiting in L2 for the end of the kernel; throughput form: the strided rows' partial lines want to meet in L2 first)
 #define RSTORE(idx, val) do { if (SPLIT) __builtin_nontemporal_store((val), rb + (idx)); else rb[idx] = (val); } while (0)
@@ -1089,7 +1108,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #define GEL_NEED_EARTH_ANGLE(wn_, we_)                                                                                 \
   do {                                                                                                                 \
     if (!have_eh && __builtin_amdgcn_ballot_w64(!((wn_) == 0.0 && (we_) == 0.0)) != 0) {                                \
-      const double tau_ = P.tau[ph.toff + jc];                                                                         \
+      int jl_ = jc;                                                                                                    \
+      if (AERO) asm volatile("" : "+v"(jl_));   /* AERO: the address is formed here, not carried from the top of the kernel */ \
+      const double tau_ = P.tau[ph.toff + jl_];                                                                        \
       const EarthAngle e_ = earth_angle(tau_ * (tf - to) / 2 + (tf + to) / 2);                                         \
       eh.ch = e_.ch; eh.sh = e_.sh; have_eh = true;                                                                    \
     }                                                                                                                  \
@@ -1111,13 +1132,76 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
       PosCentreTail pt;
       double cen_rho = 0.0, cen_P = 0.0, cen_inv_a = 0.0;   // the centre's density, pressure, 1 / speed of sound
       double dir2 = 0.0;   // z component of the thrust direction (x, y are parked)
+      // AERO: what the aero rows of the position sweeps need of the centre -- cos(alpha), alpha, q (parked; 1 / sin(alpha) is formed
+      // again; whether alpha's difference form applies at the centre rides in the SIGN of the parked alpha, which is never negative
+      // itself: acos or the clamp's +0); the Earth angle of con_aero.py, which takes the node's
+      // time in SECONDS (lib/con_aero.py:45; the defect's right-hand side takes the normalised time, lib/con_dynamics.py:246):
+      // half-angle pair, formed on first need like the defect's
+      EarthHalf aeh{1.0, 0.0};
+      bool have_aeh = false;
+#ifndef GEL_AEH
+#define GEL_AEH aeh
+#endif
+#ifndef GEL_X_NOPOS
+#define GEL_X_NOPOS 0
+#endif
+#ifndef GEL_X_NOQUAT
+#define GEL_X_NOQUAT 0
+#endif
+#ifndef GEL_X_NOVEL
+#define GEL_X_NOVEL 0
+#endif
+      const bool aero_on = AERO && akinds != 0;                 // wave-uniform
+      const bool a_need_alpha = AERO && (akinds & 5) != 0;      // an alpha or q-alpha row
+#define GEL_AERO_NEED_EA(wn_, we_)                                                                                     \
+  do {                                                                                                                 \
+    if (!have_aeh && __builtin_amdgcn_ballot_w64(!((wn_) == 0.0 && (we_) == 0.0)) != 0) {                               \
+      int jl_ = jc;                                                                                                    \
+      asm volatile("" : "+v"(jl_));   /* the address is formed here, not carried (and spilled) from the top of the kernel */ \
+      const double tau_ = P.tau[ph.toff + jl_];                                                                        \
+      const EarthAngle e_ = earth_angle((tau_ * (tf - to) / 2 + (tf + to) / 2) * P.ut);                                \
+      aeh.ch = e_.ch; aeh.sh = e_.sh; have_aeh = true;                                                                 \
+    }                                                                                                                  \
+  } while (0)
+      // One gradient entry of every kind of this phase, -(f_p - f_c) / dx / limit (lib/con_aero.py:437-463), from the perturbed
+      // point's air-relative velocity a_ (squared norm nv2_), body axis d_ (1 / |d| = ind_) and density: aero_body's GEL_AERO_EMIT
+      // (gel_kernels.hip), expression for expression.  blk: 0 position, 1 velocity, 2 quaternion; okl_: this lane writes.
+#define GEL_AERO_ENTRY(blk, col, a_, nv2_, d_, ind_, rho_, okl_, a_cc, a_ac, a_qc, a_isc, a_ok)                         \
+  do {                                                                                                                 \
+    double t_ = 0.0, dq_ = 0.0, qp_ = 0.0;                                                                             \
+    const double ac_ = a_ac;                                                                                           \
+    {                                                                                                                  \
+      const double qc_ = a_qc;                                                                                         \
+      qp_ = 0.5 * (rho_) * (nv2_);                                                                                     \
+      dq_ = qp_ - qc_;                                                                                                 \
+      if (a_need_alpha) {                                                                                              \
+        const double cp_ = aero_cos(a_, nv2_, d_, ind_);                                                               \
+        const bool okd_ = aero_dalpha(cp_, nv2_, a_cc, a_isc, a_ok, t_);                                               \
+        if (__builtin_amdgcn_ballot_w64(!okd_) != 0) {                                                                 \
+          const double t2_ = aero_acos(cp_, nv2_) - ac_;                                                               \
+          t_ = okd_ ? t_ : t2_;                                                                                        \
+        }                                                                                                              \
+      }                                                                                                                \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int kind = 0; kind < 3; kind++) {                                                           \
+      if ((blk) == 2 && kind == 1) continue;               /* dynamic pressure has no quaternion block */              \
+      if (!((akinds >> kind) & 1)) continue;               /* wave-uniform */                                          \
+      const double df_ = (kind == 0) ? t_ : ((kind == 1) ? dq_ : qp_ * t_ + dq_ * ac_);                                \
+      const double gv = -(df_ * load_const(&aph->ilx[kind]));                                                          \
+      if (okl_) AEMIT(load_const(&aph->jac[kind][(blk)]) + (col) * load_const(&aph->nk8) + 8 * j0, gv);               \
+    }                                                                                                                  \
+  } while (0)
 #if GEL_CA_CACHE
       Bracket ca_br = no_bracket();   // the node's Mach interval, shared by all of its aerodynamic-force evaluations
 #define GEL_CA_BRACKET (JAC ? &ca_br : (Bracket*)nullptr)   // a residual-only launch looks up once
 #else
 #define GEL_CA_BRACKET nullptr
 #endif
-      struct ParkSink { lds_double* park; GEL_DEV void put(int i, double v) const { park[(PK_FP0 + i) * 64] = v; } };
+      // AERO: p and 1/hypot(z Ra, p Rb) are NOT parked (nor is 1/p, below): the position sweeps form them again from the node
+      // position (geodetic_p_ih: the statements that produced them, 30 operations per sweep), and their three slots hold the aero
+      // rows' centre values cos(alpha), alpha and q instead of ten more registers across the sweeps
+      struct ParkSink { lds_double* park; GEL_DEV void put(int i, double v) const { if (!(AERO && (i == PCS_P || i == PCS_IH))) park[(PK_FP0 + i) * 64] = v; } };
+      constexpr int PK_ACC = PK_FP0 + PCS_P, PK_AAC = PK_FP0 + PCS_IH, PK_AQC = PK_LV2;   // AERO: cos(alpha_c), alpha_c, q_c
       static_assert(PCS_COUNT == 8 && PK_FP7 == PK_FP0 + 7, "PosCentre's early members fill FP0-7");
       {
         PosPart pp;
@@ -1128,6 +1212,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         if (__builtin_amdgcn_ballot_w64(!(pp.wn == 0.0 && pp.we == 0.0)) != 0) {   // tn is still in registers here
           const EarthAngle e0 = earth_angle(tn);
           eh.ch = e0.ch; eh.sh = e0.sh; have_eh = true;
+          // AERO: con_aero's Earth angle is formed where the aero rows begin (below), from the node's time waiting in the slot that
+          // cos(alpha_c) takes over there -- not here, where its pair would occupy four registers across the centre evaluation
+          if (aero_on) PARK_SET(PK_ACC, tn);
         }
         const EarthAngle ea = full_angle(eh);
         wind_eci_or_calm(r, ea, pp.shp, pp.chp, pp.inv_p, pp.wn, pp.we, w);
@@ -1168,7 +1255,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         }
         if (JAC) {   // the half-latitude pair and 1/p wait in the slots of the D.X row for the position sweeps
           asm volatile("" ::: "memory");
-          PARK_SET(PK_LV0, pp.shp); PARK_SET(PK_LV1, pp.chp); PARK_SET(PK_LV2, pp.inv_p);
+          PARK_SET(PK_LV0, pp.shp); PARK_SET(PK_LV1, pp.chp);
+          if (!AERO) PARK_SET(PK_LV2, pp.inv_p);
         }
         if (JAC && lead && !P.fd_recompute) GEL_MASS_CLOSED(tm);   // first: (T d + F) / m dies here
         // velocity sweeps: only the aerodynamic force changes.  Latency form of a WHOLE evaluation (P.split_vel: the optimiser's
@@ -1231,6 +1319,75 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
             EMIT_GROUP(3, ph.s_vt, vt, CG_VT, 0, true, true);
           }
         }
+        if (aero_on) {
+          // ---- aero rows, centre (lib/con_aero.py:39-87,127-139): the air-relative velocity with con_aero's Earth angle, alpha, q;
+          //      then the sweeps whose inputs are at hand here -- quaternion (only the body axis changes) and velocity (only the
+          //      air-relative velocity) -- and the t columns (exact zeros: aero_body, gel_kernels.hip)
+          asm volatile("" ::: "memory");
+          const double ra[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
+          double va[3], wa[3], a0[3];
+#pragma unroll
+          for (int c = 0; c < 3; c++) va[c] = PARK_GET(PK_V0 + c) * P.uv;
+          // the wind in ECI with con_aero's Earth angle (aero_body: wind_eci_or_calm at the centre).  What the rotation needs of the
+          // centre's position part is taken from where it lies by now -- the half-latitude pair from the park, 1/p and the wind
+          // components formed again (geodetic_p_ih, pos_centre_tail: bit-identical) -- instead of five values kept in registers
+          // across the centre evaluation
+          if (have_eh) {   // the centre's wind is not calm in some lane (wave-uniform): the node's time in seconds (lib/con_aero.py:45)
+            const EarthAngle e1 = earth_angle(PARK_GET(PK_ACC) * P.ut);
+            aeh.ch = e1.ch; aeh.sh = e1.sh; have_aeh = true;
+          }
+          if (have_aeh) {
+            PosCentre pcx;
+            double wn_, we_, p_, ip_, ih_;
+            pos_centre_tail(pt, pp.rho, pp.P, tb, pcx, wn_, we_);
+            geodetic_p_ih(ra[0], ra[1], ra[2], p_, ip_, ih_);
+            wind_eci(ra, full_angle(GEL_AEH), PARK_GET(PK_LV0), PARK_GET(PK_LV1), ip_, wn_, we_, wa);
+          } else {
+            wa[0] = 0.0; wa[1] = 0.0; wa[2] = 0.0;
+          }
+          const double nv2 = aero_vair2(ra, va, wa, a0);
+          const double ind = frsqrt(fmax(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2], 1.0e-300));
+          const double cc = a_need_alpha ? aero_cos(a0, nv2, dir, ind) : 0.0;
+          const double alpha_c = a_need_alpha ? aero_acos(cc, nv2) : 0.0;
+          const double qdyn_c = 0.5 * pp.rho * nv2;                       // 0.5 rho |v_air|^2 (wrapper_utils.hpp:163-175)
+          double sc, isc;
+          fsqrt_rsqrt(fmax((1.0 - cc) * (1.0 + cc), 1.0e-300), sc, isc);  // sin(alpha_c) and its reciprocal
+          const bool centre_ok = (cc <= 1.0) && (nv2 >= 1.0e-12) && (sc > 1.0e-6);
+#pragma unroll
+          for (int kind = 0; kind < 3; kind++) {
+            if (!((akinds >> kind) & 1)) continue;   // wave-uniform
+            const double il = load_const(&aph->il[kind]);
+            const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
+            AEMIT(load_const(&aph->con[kind]) + 8 * j0, cv);
+            GEL_CHK(cv);
+#pragma unroll
+            for (int c = 0; c < 2; c++) AEMIT(load_const(&aph->jac[kind][3]) + c * load_const(&aph->nk8) + 8 * j0, 0.0);
+          }
+          if (a_need_alpha && !GEL_X_NOQUAT) {
+            const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              double qp[4], dp[3];
+#pragma unroll
+              for (int d = 0; d < 4; d++) qp[d] = (d == c) ? q[d] + dx : q[d];
+              thrust_dir(qp, dp);
+              const double indp = frsqrt(fmax(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2], 1.0e-300));
+              GEL_AERO_ENTRY(2, c, a0, nv2, dp, indp, pp.rho, true, cc, alpha_c, qdyn_c, isc, centre_ok);
+              __builtin_amdgcn_sched_barrier(0);   // one sweep at a time: interleaved, the seven sweeps of this block cost six spilled registers
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < (GEL_X_NOVEL ? 0 : 3); c++) {
+            double vp[3], a[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) vp[d] = ((d == c) ? PARK_GET(PK_V0 + d) + dx : PARK_GET(PK_V0 + d)) * P.uv;
+            const double nv2p = aero_vair2(ra, vp, wa, a);
+            GEL_AERO_ENTRY(1, c, a, nv2p, dir, ind, pp.rho, true, cc, alpha_c, qdyn_c, isc, centre_ok);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // for the position sweeps: in the slots of p, 1/hypot and 1/p (1/sin(alpha_c) is formed again there)
+          PARK_SET(PK_ACC, cc); PARK_SET(PK_AAC, centre_ok ? alpha_c : -alpha_c); PARK_SET(PK_AQC, qdyn_c);
+        }
         if (JAC) {   // quaternion and D[j][j+1] are no longer needed: their slots take f_c and the thrust direction
           asm volatile("" ::: "memory");
           PARK_SET(PK_Q0, fc[0]); PARK_SET(PK_Q1, fc[1]); PARK_SET(PK_Q2, fc[2]); PARK_SET(PK_Q3, dir[0]); PARK_SET(PK_DJJ, dir[1]);
@@ -1261,15 +1418,37 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     const double vp_[3] = {FDQ((f_)[0], PARK_GET(PK_Q0)), FDQ((f_)[1], PARK_GET(PK_Q1)), FDQ((f_)[2], PARK_GET(PK_Q2))}; \
     EMIT_GROUP(3, kSlotVP + 3 * (kk), vp_, CG_VP, kk, false, okl_);                                           \
   } while (0)
+        // AERO: the aero rows' position entries of sweep kk at the perturbed point (aero_body's GEL_AERO_POS_TAIL): wind into ECI with
+        // con_aero's Earth angle, air-relative velocity, the body axis from the park (1 / |d| formed again: not carried)
+#define GEL_AERO_POS(kk, rp, pq, okl_)                                                                        \
+  do {                                                                                                        \
+    double wq_[3], a_[3];                                                                                     \
+    GEL_AERO_NEED_EA((pq).wn, (pq).we);                                                                       \
+    wind_eci_or_calm(rp, full_angle(GEL_AEH), (pq).shp, (pq).chp, (pq).inv_p, (pq).wn, (pq).we, wq_);             \
+    const double vq_[3] = {PARK_GET(PK_V0) * P.uv, PARK_GET(PK_V1) * P.uv, PARK_GET(PK_V2) * P.uv};           \
+    const double nv2_ = aero_vair2(rp, vq_, wq_, a_);                                                         \
+    const double dd_[3] = {PARK_GET(PK_Q3), PARK_GET(PK_DJJ), dir2};                                          \
+    const double ind_ = frsqrt(fmax(dd_[0] * dd_[0] + dd_[1] * dd_[1] + dd_[2] * dd_[2], 1.0e-300));          \
+    const double cc_ = PARK_GET(PK_ACC);                                                                      \
+    double sc_, isc_;                                                                                         \
+    fsqrt_rsqrt(fmax((1.0 - cc_) * (1.0 + cc_), 1.0e-300), sc_, isc_);                                        \
+    const double acs_ = PARK_GET(PK_AAC);   /* alpha_c, negated where the difference form does not apply at the centre */ \
+    GEL_AERO_ENTRY(0, kk, a_, nv2_, dd_, ind_, (pq).rho, okl_, cc_, fabs(acs_), PARK_GET(PK_AQC), isc_, !__builtin_signbit(acs_)); \
+  } while (0)
         // PosCentre and the centre's position part as far as pos_delta() reads them, from the park
 #define GEL_LOAD_POS_CENTRE(pc, pcv)                                                                                   \
   PosCentre pc;                                                                                                        \
-  pc.p = PARK_GET(PK_FP0 + PCS_P); pc.ih = PARK_GET(PK_FP0 + PCS_IH); pc.ihy = PARK_GET(PK_FP0 + PCS_IHY);             \
+  pc.ihy = PARK_GET(PK_FP0 + PCS_IHY);                                                                                 \
   pc.sl = PARK_GET(PK_FP0 + PCS_SL); pc.cl = PARK_GET(PK_FP0 + PCS_CL); pc.icl = PARK_GET(PK_FP0 + PCS_ICL);           \
   pc.N = PARK_GET(PK_FP0 + PCS_N); pc.G = PARK_GET(PK_FP0 + PCS_G);                                                    \
   PosPart pcv;                                                                                                         \
   pcv.rho = cen_rho; pcv.P = cen_P; pcv.inv_a = cen_inv_a;                                                             \
-  pcv.shp = PARK_GET(PK_LV0); pcv.chp = PARK_GET(PK_LV1); pcv.inv_p = PARK_GET(PK_LV2);                                \
+  pcv.shp = PARK_GET(PK_LV0); pcv.chp = PARK_GET(PK_LV1);                                                              \
+  if (AERO) {                                                                                                          \
+    geodetic_p_ih(fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up), pc.p, pcv.inv_p, pc.ih); \
+  } else {                                                                                                             \
+    pc.p = PARK_GET(PK_FP0 + PCS_P); pc.ih = PARK_GET(PK_FP0 + PCS_IH); pcv.inv_p = PARK_GET(PK_LV2);                  \
+  }                                                                                                                    \
   pos_centre_tail(pt, cen_rho, cen_P, tb, pc, pcv.wn, pcv.we)
         unsigned todo = 0;   // sweeps with a lane the difference form does not cover (wave-uniform)
         unsigned long long coo_okm = 0;   // COO-direct output: the verdict of the difference form, kept for the recomputing pass (the LDS tile
@@ -1301,6 +1480,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
             // form -- a lane's entries do not depend on which other nodes (or, with two vectors per wavefront, which other
             // decision vector) share its wavefront
             GEL_POS_SWEEP_EMIT(k, f, ok);
+            if (aero_on && !GEL_X_NOPOS) GEL_AERO_POS(k, rp, pq, ok);
           }
         }
         if (todo) {
@@ -1328,10 +1508,14 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
             double f[3];
             GEL_POS_SWEEP_F(rp, pq, f);
             GEL_POS_SWEEP_EMIT(k, f, !ok);
+            if (aero_on && !GEL_X_NOPOS) GEL_AERO_POS(k, rp, pq, !ok);
           }
         }
+#undef GEL_AERO_POS
 #undef GEL_LOAD_POS_CENTRE
 #undef GEL_NEED_EARTH_ANGLE
+#undef GEL_AERO_NEED_EA
+#undef GEL_AERO_ENTRY
 #undef GEL_POS_SWEEP_F
 #undef GEL_POS_SWEEP_EMIT
       }
@@ -1342,7 +1526,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         // fetched again (a load behind the stores: it waits for them).
         asm volatile("" ::: "memory");
         const double fcc[3] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2)};
-        const double tau2 = P.tau[ph.toff + jc];
+        int jl2 = jc;
+        if (AERO) asm volatile("" : "+v"(jl2));
+        const double tau2 = P.tau[ph.toff + jl2];
         {
           const double r[3] = {fresh_product(re[0], P.up), fresh_product(re[1], P.up), fresh_product(re[2], P.up)};
           const PosPart p2 = pos_part(r, tb, P.barC20);
@@ -1446,6 +1632,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #undef GEL_CA_BRACKET
 #undef GEL_QUAT_CLOSED
 #undef GEL_MASS_CLOSED
+#undef AEMIT
 #undef EMIT_AT
 #undef RSTORE
 #undef RSTORE_ROWS
@@ -1480,10 +1667,11 @@ __device__ __forceinline__ void signal_done(const ProblemDev& P) {
 // NTS = false: the Jacobian values by ordinary stores instead of non-temporal ones -- launches whose output fits the Infinity Cache
 // and is read again at once (full COO values by update in place at B = 1024: 3.9 -> 6.2 M evals/s; at B = 65536 ordinary stores
 // cost 4.4 %)
-template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, bool LONGP = true, bool NTS = true>
+// AERO = true: the aero path constraints' rows of the aerodynamic phases' nodes ride along (P.aero_ph / aero_out / aero_ld)
+template <bool JAC, bool MFMA, bool SPLIT = false, bool PACK = false, bool LONGP = true, bool NTS = true, bool AERO = false>
 __global__ __launch_bounds__(kBlock, (!JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_RES : ((JAC && PACK) ? GEL_MIN_WAVES_PER_SIMD_PACKJAC : GEL_MIN_WAVES_PER_SIMD)) void eval_kernel(ProblemDev P, int B, const double* __restrict__ x,
                                                       double* __restrict__ res, double* __restrict__ jvar) {
-  eval_body<JAC, MFMA, SPLIT, PACK, 9, LONGP, NTS>(P, B, x, res, jvar, blockIdx.x);
+  eval_body<JAC, MFMA, SPLIT, PACK, 9, LONGP, NTS, AERO>(P, B, x, res, jvar, blockIdx.x);
   if constexpr (SPLIT) signal_done(P);   // latency form only: the throughput forms never signal
 }
 

@@ -150,6 +150,14 @@ struct gel_problem {
   std::vector<gel::AeroRowDev> aero_rows[3];
   std::vector<gel::AeroNodeDev> aero_nodes;                   // the constrained state nodes, shared by the kinds
   gel::AeroNodeDev* d_aero_nodes = nullptr;
+  // gel_eval_batch_aero_device (defect groups + aero rows, one output record per vector): the record's layout, the per-phase
+  // records of the rows the fused kernel's lanes write, and the constrained nodes they do not reach (state node 0 of a phase,
+  // phases without aerodynamics) -- left to aero_wide_kernel
+  int64_t aero_ld = 0, aero_off_con[3] = {0, 0, 0}, aero_off_jac[3] = {0, 0, 0};
+  std::vector<gel::AeroPhaseDev> aero_ph;
+  std::vector<gel::AeroNodeDev> aero_rest;
+  gel::AeroPhaseDev* d_aero_ph = nullptr;
+  gel::AeroNodeDev* d_aero_rest = nullptr;
   double *d_aero_x = nullptr, *d_aero_out = nullptr;          // working set of large host-buffer calls
   size_t d_aero_x_cap = 0, d_aero_out_cap = 0;                // doubles
   // device buffers (static)
@@ -1079,7 +1087,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->cb_res) hipHostFree(p->cb_res);
   for (int i = 0; i < 2; i++) if (p->cb_x[i]) hipHostFree(p->cb_x[i]);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag); hipFree(p->d_unit_base); hipFree(p->d_shard_pos);
-  hipFree(p->d_aero_nodes); hipFree(p->d_aero_x); hipFree(p->d_aero_out);
+  hipFree(p->d_aero_nodes); hipFree(p->d_aero_x); hipFree(p->d_aero_out); hipFree(p->d_aero_ph); hipFree(p->d_aero_rest);
   free_slots(p);
   hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv);
   if (p->h_x) hipHostFree(p->h_x);
@@ -1717,13 +1725,91 @@ int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_
       if (any) nodes.push_back(nd);
     }
   p->aero_nodes = nodes;
+  // ---- the per-vector record of gel_eval_batch_aero_device: [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha]
+  int64_t off = 0;
+  for (int kd = 0; kd < 3; kd++) { p->aero_off_con[kd] = off; off += (int64_t)p->aero_rows[kd].size(); }
+  for (int kd = 0; kd < 3; kd++) { p->aero_off_jac[kd] = off; off += (int64_t)p->aero_rows[kd].size() * ((kd == 1) ? 8 : 12); }
+  p->aero_ld = off;
+  // rows written by the fused kernel's lanes: nodes 1 .. n of an aerodynamic phase with an "all nodes" spec of the kind
+  p->aero_ph.assign(p->ph.size(), gel::AeroPhaseDev{});
+  for (size_t i = 0; i < p->ph.size(); i++) {
+    gel::AeroPhaseDev& a = p->aero_ph[i];
+    a.nk8 = 8 * (p->ph[i].n + 1);
+    for (int kd = 0; kd < 3; kd++) { a.il[kd] = 1.0; a.ilx[kd] = 1.0; }
+    if (!p->ph[i].air) continue;
+    for (int kd = 0; kd < 3; kd++) {
+      const auto& A = p->aero_rows[kd];
+      const int64_t R = (int64_t)A.size();
+      const int nq = (kd == 1) ? 0 : 4;
+      for (size_t r0 = 0; r0 < A.size(); r0 += A[r0].nk) {
+        if (A[r0].phase != (int)i || A[r0].nk != p->ph[i].n + 1) continue;
+        const int64_t row0 = A[r0].row0;
+        const int64_t bo[4] = {0, 3, 6, 6 + nq}, w[4] = {3, 3, 4, 2};
+        a.kinds |= 1 << kd;
+        a.con[kd] = (int32_t)(8 * (p->aero_off_con[kd] + row0 + 1));
+        for (int blk = 0; blk < 4; blk++) a.jac[kd][blk] = (int32_t)(8 * (p->aero_off_jac[kd] + bo[blk] * R + w[blk] * row0 + 1));
+        a.il[kd] = 1.0 / A[r0].limit;            // the kernels' frcp(limit): the correctly rounded quotient
+        a.ilx[kd] = a.il[kd] * p->dev.inv_dx;
+      }
+    }
+  }
+  if (8 * p->aero_ld >= (int64_t)1 << 31) {   // record offsets are 32-bit byte offsets in the fused kernel
+    for (auto& a : p->aero_ph) a.kinds = 0;
+  }
+  p->aero_rest.clear();
+  for (const auto& nd : p->aero_nodes)
+    if (nd.k == 0 || p->aero_ph[nd.phase].kinds == 0) p->aero_rest.push_back(nd);
   if (p->device != GEL_DEVICE_NONE) {
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamSynchronize(p->stream));
-    hipFree(p->d_aero_nodes);
-    p->d_aero_nodes = nullptr;
+    hipFree(p->d_aero_nodes); hipFree(p->d_aero_ph); hipFree(p->d_aero_rest);
+    p->d_aero_nodes = nullptr; p->d_aero_ph = nullptr; p->d_aero_rest = nullptr;
     int rc = upload(&p->d_aero_nodes, p->aero_nodes);
     if (rc) return rc;
+    if ((rc = upload(&p->d_aero_ph, p->aero_ph))) return rc;
+    if (!p->aero_rest.empty() && (rc = upload(&p->d_aero_rest, p->aero_rest))) return rc;
+  }
+  return GEL_OK;
+}
+
+int gel_aero_record_layout(const gel_problem* p, int64_t* width, int64_t* off_con, int64_t* off_jac) {
+  if (!p || !width || !off_con || !off_jac) return fail(GEL_ERR_ARG, "bad argument");
+  *width = p->aero_ld;
+  for (int k = 0; k < 3; k++) { off_con[k] = p->aero_off_con[k]; off_jac[k] = p->aero_off_jac[k]; }
+  return GEL_OK;
+}
+
+// Defect groups AND aero path constraints of a resident batch: d_res [B][11N], d_jvar [B][V] as gel_eval_batch_device writes them,
+// d_aero [B][width] one record per vector (gel_aero_record_layout).  Where the launch takes the cooperative form with one vector
+// per wavefront, the lanes of the aerodynamic phases write the aero rows of their nodes themselves (ONE run of the geodetic ->
+// atmosphere -> wind chain per node and sweep instead of two) and a small second launch adds the nodes no lane has (state node 0
+// of every phase); otherwise the two kernels run one after the other.  Same values bit for bit either way.
+int gel_eval_batch_aero_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar, double* d_aero,
+                               void* stream) {
+  if (!p || !d_x || B < 1 || !d_res || !d_jvar || !d_aero) return fail(GEL_ERR_ARG, "bad argument");
+  NEED_DEVICE(p);
+  if (p->aero_nodes.empty()) return fail(GEL_ERR_ARG, "no aero path constraints configured (gel_aero_configure)");
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  gel::AeroLaunchOut out;
+  for (int k = 0; k < 3; k++) {
+    out.nrows[k] = (int32_t)p->aero_rows[k].size();
+    out.con[k] = out.nrows[k] ? d_aero + p->aero_off_con[k] : nullptr;
+    out.jac[k] = out.nrows[k] ? d_aero + p->aero_off_jac[k] : nullptr;
+  }
+  bool fused = gel::eval_aero_fusable(p->dev, B) && std::getenv("GEL_AERO_UNFUSED") == nullptr;
+  if (fused) {
+    bool any = false;
+    for (const auto& a : p->aero_ph) any = any || a.kinds != 0;
+    fused = any;
+  }
+  if (fused) {
+    gel::ProblemDev dv = p->dev;
+    dv.aero_ph = p->d_aero_ph; dv.aero_out = d_aero; dv.aero_ld = p->aero_ld;
+    HIPCHK(gel::launch_eval_aero(dv, B, d_x, d_res, d_jvar, s));
+    HIPCHK(gel::launch_aero_wide(p->dev, (int)p->aero_rest.size(), p->d_aero_rest, B, d_x, out, p->aero_ld, s));
+  } else {
+    HIPCHK(gel::launch_eval(p->dev, B, d_x, d_res, d_jvar, s));
+    HIPCHK(gel::launch_aero_wide(p->dev, (int)p->aero_nodes.size(), p->d_aero_nodes, B, d_x, out, p->aero_ld, s));
   }
   return GEL_OK;
 }

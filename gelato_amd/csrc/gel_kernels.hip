@@ -19,53 +19,8 @@
 //         consecutive addresses while all lanes share X[i][c] (broadcast).
 #include <hip/hip_runtime.h>
 
-#include "gel_device.h"
-#include "gel_launch.h"
-#include "gel_rhs_parts.h"
+#include "gel_tables.h"
 
-namespace gel {
-
-#ifndef GEL_BLOCK
-#define GEL_BLOCK 256
-#endif
-constexpr int kBlock = GEL_BLOCK;  // threads per workgroup of the fused kernel (a multiple of 64)
-static_assert(kAtmDoubles == kAtmTableDoubles, "atmosphere table size mismatch between host and device");
-
-GEL_DEV Tables table_view(const double* base, int Kw, int Kc) {
-  Tables tb;
-  tb.atm = base;
-  tb.wind = base + kAtmDoubles;
-  tb.ca = tb.wind + 3 * Kw;
-  tb.winds = tb.ca + 2 * Kc;
-  tb.cas = tb.winds + 2 * (Kw - 1);
-  tb.Kw = Kw;
-  tb.Kc = Kc;
-  return tb;
-}
-
-// sync = false: the caller reaches a workgroup barrier of its own before the first table lookup (the cooperative D.X
-// forms do), so the copy shares that barrier -- and its memory latency -- with the caller's own first loads
-// The cooperative forms of the fused kernel split the copy: stage_tables_issue() requests this thread's table entry at the top of
-// the kernel (no wait), stage_tables_commit() writes it to LDS right before the workgroup's first barrier -- behind the state-row
-// loads, so the two memory latencies overlap instead of adding up (the entry-to-descriptor stage of a wavefront was 4-7 k cycles).
-// Tables longer than the workgroup fall back to the loop at the commit.
-GEL_DEV double stage_tables_issue(const ProblemDev& P) {
-  const int ntab = table_doubles(P.Kw, P.Kc);
-  return ((int)threadIdx.x < ntab) ? P.tables[threadIdx.x] : 0.0;
-}
-GEL_DEV void stage_tables_commit(const ProblemDev& P, double* lds, double mine) {
-  const int ntab = table_doubles(P.Kw, P.Kc);
-  if ((int)threadIdx.x < ntab) lds[threadIdx.x] = mine;
-  for (int i = threadIdx.x + blockDim.x; i < ntab; i += blockDim.x) lds[i] = P.tables[i];
-}
-GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds, bool sync = true) {
-  const int ntab = table_doubles(P.Kw, P.Kc);
-  for (int i = threadIdx.x; i < ntab; i += blockDim.x) lds[i] = P.tables[i];
-  if (sync) __syncthreads();
-  return table_view(lds, P.Kw, P.Kc);
-}
-
-}  // namespace gel
 #include "gel_eval_kernel.h"
 namespace gel {
 
@@ -405,6 +360,7 @@ struct AeroOut {
   double* con[3];   // [B][nrows[kind]]
   double* jac[3];   // [B][nrows[kind] * (8 + 4 (kind != 1))]: position | velocity | quaternion | t blocks
   int32_t nrows[3];
+  int64_t ld;       // WIDE form: doubles from one vector's record to the next (con / jac point at the kind's part of record 0)
 };
 
 // One WAVEFRONT = 64 consecutive constrained nodes of one decision vector, every sweep of the node in the same lane (round 2 ran
@@ -428,32 +384,7 @@ struct AeroOut {
                             // directions): 164 VGPRs, -1.5 % launch time at B = 16384 (three alternating runs each)
 #endif
 constexpr int kAeroWaves = 4;
-// air-relative velocity in ECI (wrapper_utils.hpp:93-100) and its SQUARED norm (q needs no root; alpha takes the reciprocal root)
-GEL_DEV double aero_vair2(const double r[3], const double v[3], const double w[3], double a[3]) {
-  a[0] = (v[0] + kOmega * r[1]) - w[0]; a[1] = (v[1] - kOmega * r[0]) - w[1]; a[2] = v[2] - w[2];
-  return a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
-}
-// cosine of the angle of attack (wrapper_utils.hpp:101-106): one dot product times the two reciprocal norms (the reference divides
-// component by component: <= 3 ulp of the cosine apart); d = thrust_dir(q), ind = 1/|d|
-GEL_DEV double aero_cos(const double a[3], double nv2, const double d[3], double ind) {
-  return ((a[0] * d[0] + a[1] * d[1] + a[2] * d[2]) * frsqrt(fmax(nv2, 1.0e-300))) * ind;
-}
-// the reference's clamps (wrapper_utils.hpp:107-111): cos > 1 -> 0, |v_air| < 1e-6 -> 0
-GEL_DEV double aero_acos(double c, double nv2) { return (c > 1.0) ? 0.0 : ((nv2 < 1.0e-12) ? 0.0 : acos(c)); }
-// Exact-difference form of alpha: with c = cos(alpha_c), s = sin(alpha_c) and the perturbed cosine c_p,
-//   c_p - c = c (cos t - 1) - s sin t   =>   t = -(c_p - c)/s - (c / 2s) t^2 + t^3/6 - ...        (t = alpha_p - alpha_c)
-// solved by two substitutions.  With x = (c / 2s) t0 the fixed point is t0 (1 - x + 2x^2 - 5x^3 + ...) and two substitutions
-// give t0 (1 - x + 2x^2 - x^3): 4 |x|^3 of t short, i.e. <= 4e-12 of t under the guard |x| < 1e-4 below (t ~ 1e-8 .. 1e-5, so
-// the guard refuses only angles of attack below a few degrees at the largest steps) -- four orders below what a second acos
-// would carry.  One reciprocal root and a dozen operations instead of that acos.  false: a lane where the form does not
-// apply (a clamp of the reference is active at either point, sin(alpha) < 1e-6, or the step is not small against sin(alpha)).
-GEL_DEV bool aero_dalpha(double c_p, double nv2_p, double c_c, double inv_s, bool centre_ok, double& t) {
-  const double t0 = (c_c - c_p) * inv_s, k = (0.5 * c_c) * inv_s;
-  const double t1 = t0 - (k * t0) * t0;
-  t = (t0 - (k * t1) * t1) + (t1 * t1) * (t1 * (1.0 / 6.0));
-  return centre_ok && (c_p <= 1.0) && (nv2_p >= 1.0e-12) && (fabs(k * t0) < 1.0e-4);
-}
-
+// aero_vair2(), aero_cos(), aero_acos(), aero_dalpha(): gel_rhs_parts.h (shared with the fused kernel's aero rows)
 // park slots of one wavefront (doubles; the last six hold up to 12 ints per lane)
 enum { AP_ILIM = 0, AP_AC = 3, AP_QC, AP_CC, AP_IS, AP_IND, AP_W = 8, AP_A0 = 11, AP_DIR = 14, AP_RHO = 17, AP_NV2 = 18, AP_INTS = 19,
        kAeroParkSlots = 25 };
@@ -462,7 +393,11 @@ typedef __attribute__((address_space(3))) double lds_f64;
 // ROLES (the B = 1 callback launch, where the length of one wavefront's chain is what counts): the four wavefronts of a
 // workgroup share ONE tile -- wavefront 0 the centre values and the light sweeps, wavefronts 1..3 the centre and one position
 // sweep each.  Same operations on the same operands per entry: bit-identical to the one-wavefront form.
-template <bool ROLES>
+// WIDE (the rows the fused kernel's lanes do not reach -- state node 0 of every phase, phases without aerodynamics -- of a launch
+// whose outputs are the per-vector records of gel_eval_batch_aero_device): any number of vectors per wavefront (entry f of the
+// (vector, node) sequence -> vector f / nnodes), outputs at 64-bit addresses b * ld + ... by plain global stores.  Same
+// expressions per entry, same bits.
+template <bool ROLES, bool WIDE = false>
 __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes, int tiles, int B,
                                           const double* __restrict__ x, const AeroOut O, const unsigned vblk) {
   extern __shared__ double lds[];
@@ -473,10 +408,17 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   // FLAT (batch launches, tiles == 0) [r5]: a wavefront takes 64 consecutive entries of the (vector, node) sequence of the whole batch,
   // whichever vectors they belong to -- 325 constrained nodes per vector are 5.08 wavefronts' worth, not six tiles with the last one
   // 59 / 64 empty.  A wavefront then straddles at most two vectors (nnodes >= 64), so the vector is a per-lane value.
-  const bool flat = !ROLES && tiles == 0;
+  const bool flat = !ROLES && !WIDE && tiles == 0;
   int b, ni_raw;
   bool live;
-  if (flat) {
+  if (WIDE) {
+    const long long total = (long long)B * nnodes, f = wid * 64 + lane;
+    if (wid * 64 >= total) return;                      // after the tables' barrier
+    live = f < total;
+    const long long fc = live ? f : total - 1;
+    b = (int)(fc / nnodes);
+    ni_raw = live ? (int)(fc - (long long)b * nnodes) : nnodes;
+  } else if (flat) {
     const long long total = (long long)B * nnodes, f0 = wid * 64;
     if (f0 >= total) return;                           // after the tables' barrier
     const int b0 = (int)(f0 / nnodes), r0 = (int)(f0 - (long long)b0 * nnodes);
@@ -577,6 +519,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
       const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
       if (ROLES) __builtin_nontemporal_store(cv, O.con[kind] + (size_t)b * O.nrows[kind] + row);
+      else if (WIDE) O.con[kind][(size_t)b * O.ld + row] = cv;
       else O.con[kind][(size_t)b * O.nrows[kind] + row] = cv;
       chk += cv;
     }
@@ -620,7 +563,8 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       const double gv = (zero) ? 0.0 : -(df_ * AP_GET(AP_ILIM + kind));                                           \
       gel_au2 gd_;                                                                                                \
       __builtin_memcpy(&gd_, &gv, 8);                                                                             \
-      __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], ((col) == 0) ? a8_ : a8_ + (col) * ipark[kind * 64], 8 * bo * O.nrows[kind], ROLES ? 2 : 0); /* ROLES = the one-vector callback: streamed to pinned host memory */ \
+      if (WIDE) O.jac[kind][(size_t)b * O.ld + (size_t)bo * O.nrows[kind] + ((a8_ + (col) * ipark[kind * 64]) >> 3)] = gv;                     \
+      else __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], ((col) == 0) ? a8_ : a8_ + (col) * ipark[kind * 64], 8 * bo * O.nrows[kind], ROLES ? 2 : 0); /* ROLES = the one-vector callback: streamed to pinned host memory */ \
       chk += gv;                                                                                                  \
     }                                                                                                             \
   } while (0)
@@ -629,7 +573,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   __amdgpu_buffer_rsrc_t jrs[3];
 #pragma unroll
   for (int kind = 0; kind < 3; kind++)
-    jrs[kind] = __builtin_amdgcn_make_buffer_rsrc(O.jac[kind] ? (void*)(O.jac[kind] + (flat ? (size_t)0 : (size_t)__builtin_amdgcn_readfirstlane(b) * O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)))) : (void*)nullptr,
+    jrs[kind] = __builtin_amdgcn_make_buffer_rsrc((O.jac[kind] && !WIDE) ? (void*)(O.jac[kind] + (flat ? (size_t)0 : (size_t)__builtin_amdgcn_readfirstlane(b) * O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)))) : (void*)nullptr,
                                                   0, -1, 0x00020000);
   if (want_jac) {
     // ---- t0 / tf columns
@@ -752,12 +696,30 @@ __global__ __launch_bounds__(64 * kAeroWaves, GEL_AERO_MIN_WAVES) void aero_kern
                                                                 int tiles, int B, const double* __restrict__ x, AeroOut O) {
   aero_body<false>(P, nnodes, nodes, tiles, B, x, O, blockIdx.x);
 }
+__global__ __launch_bounds__(64 * kAeroWaves, 2) void aero_wide_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
+                                                                int B, const double* __restrict__ x, AeroOut O) {
+  aero_body<false, true>(P, nnodes, nodes, 0, B, x, O, blockIdx.x);
+}
+
+// the listed nodes' rows into per-vector records: out.con / out.jac point at each kind's part of record 0, ld doubles per record
+hipError_t launch_aero_wide(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
+                            const AeroLaunchOut& out, long long ld, hipStream_t s) {
+  if (B <= 0 || nnodes <= 0) return hipSuccess;
+  AeroOut O;
+  for (int k = 0; k < 3; k++) { O.con[k] = out.con[k]; O.jac[k] = out.jac[k]; O.nrows[k] = out.nrows[k]; }
+  O.ld = ld;
+  const size_t lds = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + (size_t)kAeroWaves * kAeroParkSlots * 64);
+  const long long waves = ((long long)B * nnodes + 63) / 64;
+  hipLaunchKernelGGL(aero_wide_kernel, dim3((unsigned)((waves + kAeroWaves - 1) / kAeroWaves)), dim3(64 * kAeroWaves), lds, s, P, nnodes, nodes, B, d_x, O);
+  return hipGetLastError();
+}
 
 hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
                        const AeroLaunchOut& out, hipStream_t s) {
   if (B <= 0 || nnodes <= 0) return hipSuccess;
   AeroOut O;
   for (int k = 0; k < 3; k++) { O.con[k] = out.con[k]; O.jac[k] = out.jac[k]; O.nrows[k] = out.nrows[k]; }
+  O.ld = 0;
   int tiles = (nnodes + 63) / 64;
   const size_t lds = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + (size_t)kAeroWaves * kAeroParkSlots * 64);
   long long waves = (long long)B * tiles;
@@ -1015,6 +977,7 @@ hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_
   A.nb_eval = (P.nunits + 3) / 4;                  // four wavefronts = four units per workgroup
   if (aero && nnodes > 0) {
     for (int k = 0; k < 3; k++) { A.O.con[k] = aero->con[k]; A.O.jac[k] = aero->jac[k]; A.O.nrows[k] = aero->nrows[k]; }
+    A.O.ld = 0;
     A.nnodes = nnodes; A.nodes = nodes; A.tiles = (nnodes + 63) / 64; A.nb_aero = A.tiles;   // ROLES form: one workgroup per tile
   }
   int rows_blocks = 0;

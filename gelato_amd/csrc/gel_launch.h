@@ -13,6 +13,9 @@ namespace gel {
 struct EvalForm { bool jac, mfma, split, pack; long long waves; };
 EvalForm eval_form(const ProblemDev& P, int B, bool want_res, bool want_jac);
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s);
+// defect groups + the aero rows of the aerodynamic phases' nodes 1 .. n in ONE launch (gel_eval_kernel.h, AERO instantiation)
+bool eval_aero_fusable(const ProblemDev& P, int B);
+hipError_t launch_eval_aero(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s);
 hipError_t launch_expand(long long nnz, long long V, int B, const double* cval, const int32_t* src,
                          const double* d_jvar, double* d_full, hipStream_t s);
 // x-dependent entries only, into a full COO buffer that holds the constants (launch_fill_full lays them down)
@@ -38,6 +41,9 @@ hipError_t launch_point(int kind, int n, const double* in, const double* aux, in
 struct AeroLaunchOut { double* con[3]; double* jac[3]; int32_t nrows[3]; };
 hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
                        const AeroLaunchOut& out, hipStream_t s);
+
+hipError_t launch_aero_wide(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
+                            const AeroLaunchOut& out, long long ld, hipStream_t s);
 
 // one callback = one launch: defect groups (split form) + aero kinds + row table as workgroup ranges of one grid; aero / d_con
 // may be null (that part is left out)

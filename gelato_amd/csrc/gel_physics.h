@@ -338,6 +338,17 @@ GEL_DEV void geodetic_lat_p(double x, double y, double z, double& lat, double& p
 // pair, so its rounding had to correlate with the reference's; the sweeps now take the exact-difference form (pos_delta) and
 // no longer see how the centre pair was rounded.  pp == 0 (the polar axis, where the reference gets cos(pi/2) = 6.1e-17 and
 // an altitude of -N) returns the reference's pair.  ih_out / ihy_out: 1/hypot(z Ra, p Rb) and 1/hypot(zz, pp) for pos_delta().
+// the head of geodetic_sincos_p() on its own: p, 1/p and 1/hypot(z Ra, p Rb) -- the same statements, hence the same bits.  The
+// AERO instantiation of the fused kernel forms them again in every position sweep instead of parking them (their three park slots
+// hold the aero rows' centre values there).
+GEL_DEV void geodetic_p_ih(double x, double y, double z, double& p, double& inv_p, double& ih) {
+  const double p2 = x * x + y * y;
+  fsqrt_rsqrt(fmax(p2, 1.0e-300), p, inv_p);
+  if (!(p2 > 0.0)) { p = 0.0; inv_p = 0.0; }
+  const double a = z * kRa, b = p * kRb;
+  const double h2 = a * a + b * b;
+  ih = frsqrt(fmax(h2, 1.0e-300));
+}
 GEL_DEV void geodetic_sincos_p(double x, double y, double z, double& sl, double& cl, double& p, double& inv_p,
                                double* ih_out = nullptr, double* ihy_out = nullptr) {
   const double p2 = x * x + y * y;

@@ -353,4 +353,35 @@ GEL_DEV void quat_rate(const double q[4], double u0, double u1, double unit_u, d
   dq[3] = 0.5 * (q[0] * oz + q[1] * oy);
 }
 
+// ---------------------------------------------------------------------------
+// Aero path constraints (lib/con_aero.py, src/wrapper_utils.hpp:89-206): the pieces aero_kernel (gel_kernels.hip) and the
+// aero rows of the fused kernel (gel_eval_kernel.h, AERO instantiation) share -- the same expressions, hence the same bits.
+// ---------------------------------------------------------------------------
+// air-relative velocity in ECI (wrapper_utils.hpp:93-100) and its SQUARED norm (q needs no root; alpha takes the reciprocal root)
+GEL_DEV double aero_vair2(const double r[3], const double v[3], const double w[3], double a[3]) {
+  a[0] = (v[0] + kOmega * r[1]) - w[0]; a[1] = (v[1] - kOmega * r[0]) - w[1]; a[2] = v[2] - w[2];
+  return a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+}
+// cosine of the angle of attack (wrapper_utils.hpp:101-106): one dot product times the two reciprocal norms (the reference divides
+// component by component: <= 3 ulp of the cosine apart); d = thrust_dir(q), ind = 1/|d|
+GEL_DEV double aero_cos(const double a[3], double nv2, const double d[3], double ind) {
+  return ((a[0] * d[0] + a[1] * d[1] + a[2] * d[2]) * frsqrt(fmax(nv2, 1.0e-300))) * ind;
+}
+// the reference's clamps (wrapper_utils.hpp:107-111): cos > 1 -> 0, |v_air| < 1e-6 -> 0
+GEL_DEV double aero_acos(double c, double nv2) { return (c > 1.0) ? 0.0 : ((nv2 < 1.0e-12) ? 0.0 : acos(c)); }
+// Exact-difference form of alpha: with c = cos(alpha_c), s = sin(alpha_c) and the perturbed cosine c_p,
+//   c_p - c = c (cos t - 1) - s sin t   =>   t = -(c_p - c)/s - (c / 2s) t^2 + t^3/6 - ...        (t = alpha_p - alpha_c)
+// solved by two substitutions.  With x = (c / 2s) t0 the fixed point is t0 (1 - x + 2x^2 - 5x^3 + ...) and two substitutions
+// give t0 (1 - x + 2x^2 - x^3): 4 |x|^3 of t short, i.e. <= 4e-12 of t under the guard |x| < 1e-4 below (t ~ 1e-8 .. 1e-5, so
+// the guard refuses only angles of attack below a few degrees at the largest steps) -- four orders below what a second acos
+// would carry.  One reciprocal root and a dozen operations instead of that acos.  false: a lane where the form does not
+// apply (a clamp of the reference is active at either point, sin(alpha) < 1e-6, or the step is not small against sin(alpha)).
+GEL_DEV bool aero_dalpha(double c_p, double nv2_p, double c_c, double inv_s, bool centre_ok, double& t) {
+  const double t0 = (c_c - c_p) * inv_s, k = (0.5 * c_c) * inv_s;
+  const double t1 = t0 - (k * t0) * t0;
+  t = (t0 - (k * t1) * t1) + (t1 * t1) * (t1 * (1.0 / 6.0));
+  return centre_ok && (c_p <= 1.0) && (nv2_p >= 1.0e-12) && (fabs(k * t0) < 1.0e-4);
+}
+
+
 }  // namespace gel

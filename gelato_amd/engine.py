@@ -450,6 +450,23 @@ class Engine:
         jp = (C.c_void_p * 3)(*[p or None for p in d_jac]) if d_jac is not None else None
         check(lib().gel_eval_aero_all_device(self._h, B, d_x, cp, jp, stream or None))
 
+    def aero_record_layout(self):
+        """-> (width, {kind: (con offset, rows)}, {kind: (jac offset, values)}): the per-vector record of eval_batch_aero_device"""
+        w = C.c_int64()
+        oc, oj = (C.c_int64 * 3)(), (C.c_int64 * 3)()
+        check(lib().gel_aero_record_layout(self._h, C.byref(w), oc, oj))
+        con, jac = {}, {}
+        for i, kind in enumerate(self.AERO_KINDS):
+            nrow, nnz = self.aero_dims(kind)
+            con[kind] = (int(oc[i]), nrow)
+            jac[kind] = (int(oj[i]), sum(nnz))
+        return int(w.value), con, jac
+
+    def eval_batch_aero_device(self, B, d_x, d_res, d_jvar, d_aero, stream=0):
+        """defect groups + aero path constraints of a resident batch (device pointers as ints): res [B, nres], jvar [B, V] as
+        eval_batch_device, aero [B, width] one record per vector (aero_record_layout)"""
+        check(lib().gel_eval_batch_aero_device(self._h, B, d_x, d_res, d_jvar, d_aero, stream or None))
+
     def eval_callback(self, x, want_jac, xptr=None):
         """ONE device round trip for one decision vector: the four defect groups, the row table (if configured) and the aero
         kinds (if configured), values only or values + derivatives.  -> dict of the engine's own output arrays (overwritten

@@ -261,6 +261,20 @@ int gel_eval_aero(gel_problem* p, int32_t kind, int32_t B, const double* x, doub
 int gel_eval_aero_all(gel_problem* p, int32_t B, const double* x, double* const* con /* [3] */, double* const* jac /* [3] or NULL */);
 int gel_eval_aero_all_device(gel_problem* p, int32_t B, const double* d_x, double* const* d_con /* [3] */,
                              double* const* d_jac /* [3] or NULL */, void* stream);
+/* Defect groups AND aero path constraints of a resident batch in one call [r6] -- the hot-path share of objfunc + sens with the aero
+ * rows riding on it (lib/con_dynamics.py:216-496 and lib/con_aero.py:89-248,311-371 evaluate the same geodetic -> atmosphere -> wind
+ * chain at the same nodes; src/pybind_dynamics.cpp:42-59 / src/wrapper_utils.hpp:89-206).  d_res [B][11 N] and d_jvar [B][V] as
+ * gel_eval_batch_device writes them; d_aero [B][width]: ONE record per decision vector,
+ *   [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha]      (gel_aero_record_layout: width and the six offsets),
+ * each part laid out exactly like the corresponding array of gel_eval_aero_all (a kind without rows has an empty part).
+ * Where the launch takes the throughput form with one decision vector per wavefront, the lanes of an aerodynamic phase write the
+ * aero rows of their state nodes 1 .. n themselves, from the centre evaluation and the position sweeps they run anyway, and one
+ * small launch adds the rows no lane has (state node 0 of a phase, phases without aerodynamics); otherwise (a handful of vectors,
+ * meshes of phases of at most 32 nodes, GEL_FLAG_FD_RECOMPUTE) the two kernels run one after the other.  Every value is the same
+ * bit for bit as gel_eval_batch_device's and gel_eval_aero_all_device's.  Asynchronous on `stream`; status through gel_sync. */
+int gel_aero_record_layout(const gel_problem* p, int64_t* width, int64_t* off_con /* [3] */, int64_t* off_jac /* [3] */);
+int gel_eval_batch_aero_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar, double* d_aero,
+                               void* stream);
 
 /* ---- knot / terminal / user rows.
  *  Linear rows: value = (coef0 * x[idx0] + coef1 * x[idx1]) + c0 (idx1 < 0: one term) over the packed decision vector --

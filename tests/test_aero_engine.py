@@ -333,3 +333,132 @@ def test_flat_batch_mapping_equals_the_one_vector_calls(name, B):
     assert E.sync(s) == 0
     for i, kind in enumerate(KINDS):
         assert np.array_equal(dcon[i].cpu().numpy(), con[kind]) and np.array_equal(djac[i].cpu().numpy(), jac[kind])
+
+
+def _fused_case(name, B, specs, seed=41, flags=0):
+    """gel_eval_batch_aero_device against the two separate launches on the same resident batch -> (engine, what the one call wrote,
+    what the separate launches wrote)"""
+    import torch
+    from gelato_amd import Engine, con_dynamics, pack_x, problem
+    pdict, unitdict, _c, xdict = problem.make_problem(name)
+    E = Engine(con_dynamics.problem_arrays(pdict, unitdict), flags=flags)
+    for kind, spec in specs(pdict).items():
+        E.aero_configure(kind, spec)
+    X = problem.synthetic_batch(pack_x(xdict), E.M, min(B, 64), seed=seed)
+    X = np.tile(X, (B // len(X) + 1, 1))[:B]
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    dX = torch.from_numpy(X).to(dev)
+    width, ocon, ojac = E.aero_record_layout()
+    nan = float("nan")
+    r1 = torch.full((B, E.nres), nan, dtype=torch.float64, device=dev)
+    j1 = torch.full((B, E.V), nan, dtype=torch.float64, device=dev)
+    a1 = torch.full((B, width), nan, dtype=torch.float64, device=dev)
+    E.eval_batch_aero_device(B, dX.data_ptr(), r1.data_ptr(), j1.data_ptr(), a1.data_ptr(), s)
+    assert E.sync(s) == 0
+    r0 = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    j0 = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    E.eval_batch_device(B, dX.data_ptr(), r0.data_ptr(), j0.data_ptr(), s)
+    dims = [E.aero_dims(k) for k in KINDS]
+    dcon = [torch.empty((B, max(d[0], 1)), dtype=torch.float64, device=dev) for d in dims]
+    djac = [torch.empty((B, max(sum(d[1]), 1)), dtype=torch.float64, device=dev) for d in dims]
+    E.eval_aero_all_device(B, dX.data_ptr(), [t.data_ptr() if d[0] else 0 for t, d in zip(dcon, dims)],
+                           [t.data_ptr() if d[0] else 0 for t, d in zip(djac, dims)], s)
+    assert E.sync(s) == 0
+    one = {"res": r1.cpu().numpy(), "jvar": j1.cpu().numpy(), "aero": a1.cpu().numpy()}
+    two = {"res": r0.cpu().numpy(), "jvar": j0.cpu().numpy(),
+           "con": {k: dcon[i].cpu().numpy() for i, k in enumerate(KINDS)}, "jac": {k: djac[i].cpu().numpy() for i, k in enumerate(KINDS)}}
+    return E, one, two, (width, ocon, ojac)
+
+
+def _all_air(lims=(0.2, 4.0e4, 5.0e3)):
+    def specs(pdict):
+        S = pdict["num_sections"]
+        return {k: [(i, 1, lim) for i in range(S - 1)] for k, lim in zip(KINDS, lims)}
+    return specs
+
+
+def _ragged(pdict):
+    """kinds with different phase sets, an "initial"-only spec (one row: the fused lanes have none of it) and the phase without
+    aerodynamics constrained too (all of its rows are left to the second launch)"""
+    S = pdict["num_sections"]
+    return {"alpha": [(i, 1, 0.15) for i in range(0, S - 1, 2)],
+            "q": [(i, (i % 3 != 1), 3.5e4 + 100.0 * i) for i in range(S - 1)],
+            "qalpha": [(i, 1, 4.0e3) for i in range(1, S - 1)]}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,specs", [("mixed-6x64", 70, _all_air()), ("mixed-6x64", 67, _ragged), ("dense-6x64", 65, _all_air()),
+                                          ("stress-12x128", 66, _all_air()), ("example", 300, _ragged), ("3x32", 70, _all_air()),
+                                          ("mixed-6x64", 3, _all_air())])
+def test_defect_groups_and_aero_rows_in_one_launch_equal_the_two_kernels(name, B, specs):
+    """gel_eval_batch_aero_device [r6]: residual rows, compact Jacobian values and every aero constraint value / gradient value of
+    every vector are THE BITS of gel_eval_batch_device and gel_eval_aero_all_device -- where the aero rows ride in the fused
+    kernel's lanes (cooperative form, one vector per wavefront: mixed / dense / 12 x 128 / the shipped example at B >= 65; the
+    rows of state node 0 and of phases without aerodynamics by the second launch) and where the call falls back to the two
+    kernels (a handful of vectors; 3 x 32: two vectors per wavefront).  Nothing outside the record's parts is written, nothing
+    inside is left unwritten."""
+    E, one, two, (width, ocon, ojac) = _fused_case(name, B, specs)
+    assert np.array_equal(one["res"], two["res"]) and np.array_equal(one["jvar"], two["jvar"])
+    covered = np.zeros(width, dtype=bool)
+    for kind in KINDS:
+        (oc, nr), (oj, nj) = ocon[kind], ojac[kind]
+        covered[oc:oc + nr] = True
+        covered[oj:oj + nj] = True
+        if nr == 0:
+            continue
+        assert np.array_equal(one["aero"][:, oc:oc + nr], two["con"][kind]), (kind, "values")
+        d = one["aero"][:, oj:oj + nj] != two["jac"][kind]
+        assert not d.any(), (kind, "gradient values", int(d.sum()), np.argwhere(d)[:5])
+    assert covered.all() and not np.isnan(one["aero"]).any()
+
+
+@pytest.mark.gpu
+def test_fused_aero_rows_take_the_recomputing_fallback_like_the_aero_kernel():
+    """Nodes whose perturbed point leaves the centre's atmosphere layer / wind-table piece (the difference form does not cover them)
+    and nodes next to the polar axis: the fused lanes take the same per-lane fallbacks as aero_kernel -- same bits."""
+    import torch
+    from gelato_amd import Engine, con_dynamics, pack_x, problem
+    pdict, unitdict, _c, xdict = problem.make_problem("mixed-6x64")
+    E = Engine(con_dynamics.problem_arrays(pdict, unitdict))
+    S = pdict["num_sections"]
+    for kind, lim in zip(KINDS, (0.2, 4.0e4, 5.0e3)):
+        E.aero_configure(kind, [(i, 1, lim) for i in range(S - 1)])
+    x0 = pack_x(xdict)
+    X = problem.synthetic_batch(x0, E.M, 8, seed=5)
+    X = np.tile(X, (9, 1))[:68]
+    # positions moved onto layer / table boundaries and towards the pole, vector by vector
+    M = E.M
+    rng = np.random.default_rng(12)
+    pos = X[:, M:4 * M].reshape(len(X), M, 3)
+    up = float(unitdict["position"])
+    for b in range(len(X)):
+        r = pos[b] * up
+        nr = np.linalg.norm(r, axis=1)
+        if b % 4 == 1:      # geometric altitudes right at US-1976 layer bases / wind-table knots (within the FD step)
+            targets = np.array([1000.0, 11019.1, 20063.1, 23000.0, 32161.9, 47350.1, 5000.0, 2000.0])
+            alt = targets[rng.integers(0, len(targets), M)] + rng.uniform(-0.02, 0.02, M)
+            r = r / nr[:, None] * (6371000.0 + alt)[:, None]     # spherical stand-in: lands within metres of the knot; the jitter does the rest
+        elif b % 4 == 2:    # next to the polar axis
+            r = np.stack([rng.uniform(-5.0, 5.0, M), rng.uniform(-5.0, 5.0, M), nr], axis=1)
+        pos[b] = r / up
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    B = len(X)
+    dX = torch.from_numpy(X).to(dev)
+    width, ocon, ojac = E.aero_record_layout()
+    r1 = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    j1 = torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    a1 = torch.full((B, width), float("nan"), dtype=torch.float64, device=dev)
+    E.eval_batch_aero_device(B, dX.data_ptr(), r1.data_ptr(), j1.data_ptr(), a1.data_ptr(), s)
+    E.sync(s)
+    r0, j0 = torch.empty_like(r1), torch.empty_like(j1)
+    E.eval_batch_device(B, dX.data_ptr(), r0.data_ptr(), j0.data_ptr(), s)
+    E.sync(s)
+    assert torch.equal(r0.view(torch.int64), r1.view(torch.int64)) and torch.equal(j0.view(torch.int64), j1.view(torch.int64))
+    con, jac, _rc = E.eval_aero_all(X)
+    a = a1.cpu().numpy()
+    for kind in KINDS:
+        (oc, nr_), (oj, nj) = ocon[kind], ojac[kind]
+        assert np.array_equal(a[:, oc:oc + nr_], con[kind], equal_nan=True), kind
+        assert np.array_equal(a[:, oj:oj + nj], jac[kind], equal_nan=True), kind
