@@ -66,6 +66,18 @@ def launch_ranks(n_gpus, argv, dry=False):
     return 0
 
 
+def cpu_model():
+    """model name of the host's CPU (/proc/cpuinfo), for the cpu_baseline leg"""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(prob, D, tau, X, gpu_first=None, budget_s=12.0, residual_only=False):
     """The oracle (scalar C port of the reference algorithm) timed on this box's host cores, 1 thread,
     on a bounded sample of the same workload.  This leg is the only place bench.py touches oracle/: besides
@@ -97,7 +109,8 @@ def cpu_baseline(prob, D, tau, X, gpu_first=None, budget_s=12.0, residual_only=F
     run(X[:n])
     dt = time.perf_counter() - t0
     what = "4 residuals" if residual_only else "4 residuals + 4 COO Jacobians each, every COO value computed"
-    out = {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+    out = {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+           "host_cores_visible": len(os.sched_getaffinity(0)),
            "sample": "%d evals (%s) of the same workload, oracle/libgelato_oracle.so, 1 thread, %.1f s; "
                      "per-eval distribution over %d single-eval calls" % (n, what, dt, nd),
            "ms_per_eval": 1e3 * dt / n,
@@ -144,7 +157,10 @@ def cpu_baseline(prob, D, tau, X, gpu_first=None, budget_s=12.0, residual_only=F
                 wall = time.perf_counter() - t0
                 for pr in procs:
                     pr.wait(timeout=30)
-            out["all_cores"] = {"value": W * per_w / wall, "cores": W,
+            out["all_cores"] = {"value": W * per_w / wall, "cores": W, "kind": "port, %d single-thread worker processes" % W,
+                                # SURVEY 8(d) names OpenMP over phases x sweeps: threads of one process do not run concurrently in this
+                                # pool's sandbox (measured, round 3), so the many-core leg is W independent processes over slices
+                                "form": "%d processes x 1 thread (not OpenMP threads of one process)" % W,
                                 "sample": "%d worker processes x %d evals, 1 thread each, %.1f s" % (W, per_w, wall)}
     except Exception as ex:  # noqa: BLE001
         out["all_cores"] = {"error": str(ex)[:200]}
@@ -237,23 +253,13 @@ def main():
     X = problem.synthetic_batch(x0, E.M, B, seed=20260313 + (0 if shard else rank * B))
     stream = torch.cuda.current_stream().cuda_stream  # the engine launches on torch's current stream
     dX = torch.from_numpy(X).to(dev)
+    # [r6] `value` is timed on the buffers as the allocator places them, W warm-up steps after an idle GPU -- the contract's number.
+    # The placed figure (gelato_amd/placement.py: candidate allocations measured, the fastest kept) follows AFTER both timed regions
+    # and is informational (`buffer_placement.value_placed`): rounds 4-5 placed first, which made `value` a best-of-13 pick that had
+    # also seen ~300 launches of warm-up.
     placement = None
-    if a.placement_tries > 1 and not shard:
-        # Where the three resident arrays lie against one another on the HBM channels moves the launch by up to 7 % (same kernel, same
-        # data, one process: gelato_amd/placement.py).  Like a consumer that keeps its batch buffers, the bench places them once,
-        # before anything is timed: a few candidate allocations, a handful of launches on each, the fastest kept.
-        from gelato_amd.placement import place_batch_buffers
-        try:
-            dX, dres, djv, placement = place_batch_buffers(E, dX, want_jac=not a.residual_only, tries=a.placement_tries, stream=stream,
-                                                          seed=rank)
-        except Exception as ex:  # noqa: BLE001  (e.g. not enough free memory for a second set of buffers): what the allocator gives
-            torch.cuda.empty_cache()
-            placement = {"error": str(ex)[:200]}
-            dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
-            djv = None if a.residual_only else torch.empty((B, E.V), dtype=torch.float64, device=dev)
-    else:
-        dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
-        djv = None if a.residual_only else torch.empty((B, E.V), dtype=torch.float64, device=dev)
+    dres = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
+    djv = None if a.residual_only else torch.empty((B, E.V), dtype=torch.float64, device=dev)
     djv_ptr = 0 if djv is None else djv.data_ptr()
 
     if shard:
@@ -277,7 +283,7 @@ def main():
                 evaluate(dout, rank)
     else:
         def step():
-            E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), djv_ptr, stream)
+            E.eval_batch_device(B, dX.data_ptr(), dres.data_ptr(), 0 if djv is None else djv.data_ptr(), stream)
         kernel_only = step
 
     def barrier():
@@ -306,7 +312,7 @@ def main():
     WARM_MS = 40.0
     # every launch of this run is under HIP events, group by group: their mean is what a kernel trace of the whole run averages
     # (`roofline.kernel_ms_mean_of_all_launches`, beside the timed region's `kernel_ms`)
-    all_ms, all_n = (placement["all_launches_ms"], placement["all_launches"]) if placement and "all_launches" in placement else (0.0, 0)
+    all_ms, all_n = 0.0, 0
 
     def untimed(n):
         nonlocal all_ms, all_n
@@ -349,11 +355,50 @@ def main():
     all_ms += kern_ms_settled * K
     all_n += K
     status = E.sync(stream)
+    # [r6] buffer placement, after the contract's timed regions: the same K steps on the fastest of `--placement-tries` candidate
+    # placements of jvar and of (x, res), W warm-up steps in front (informational; every rank does the same)
+    elapsed_placed, kern_ms_placed = float("nan"), float("nan")
+    do_place = a.placement_tries > 1 and not shard
+    if do_place:
+        # free memory first: a rank that cannot hold a second set of buffers beside the first makes EVERY rank skip
+        # the placement, so that the barriers of the timed region behind it stay matched
+        free_b, _tot = torch.cuda.mem_get_info(dev)
+        need = 2 * 8 * B * (E.nvars + E.nres + (0 if a.residual_only else E.V)) + (5 << 30)   # two more sets (kept + candidate) and the pads
+        ok_t = torch.tensor([1 if free_b >= need else 0], dtype=torch.int64, device=dev)
+        if use_dist:
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if int(ok_t.item()) == 0:
+            do_place = False
+            placement = {"error": "placement skipped: %.1f GB free on rank %d, %.1f GB wanted for the candidate buffers" % (free_b / 1e9, rank, need / 1e9)}
+    if do_place:
+        from gelato_amd.placement import place_batch_buffers
+        placed_ok = 1
+        try:
+            dX, dres, djv, placement = place_batch_buffers(E, dX, want_jac=not a.residual_only, tries=a.placement_tries, stream=stream,
+                                                          seed=rank)
+            all_ms += placement["all_launches_ms"]
+            all_n += placement["all_launches"]
+        except Exception as ex:  # noqa: BLE001: what the allocator gave stays
+            torch.cuda.empty_cache()
+            placement = {"error": str(ex)[:200]}
+            placed_ok = 0
+        if use_dist:   # every rank times the placed steps, or none does (the timed region holds barriers)
+            ok_t = torch.tensor([placed_ok], dtype=torch.int64, device=dev)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+            placed_ok = int(ok_t.item())
+        if placed_ok:
+            untimed(W)
+            elapsed_placed, kern_ms_placed = timed(K)
+            all_ms += kern_ms_placed * K
+            all_n += K
+        elif placement is not None and "error" not in placement:
+            placement["error"] = "another rank could not place its buffers: the placed steps were not timed"
+    djv_ptr = 0 if djv is None else djv.data_ptr()
 
-    tmax = torch.tensor([elapsed, elapsed_settled], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed, elapsed_settled, elapsed_placed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    T, T_settled = float(tmax[0].item()), float(tmax[1].item())
+    T, T_settled, T_placed = float(tmax[0].item()), float(tmax[1].item()), float(tmax[2].item())
 
     if rank != 0:
         if use_dist:
@@ -419,10 +464,17 @@ def main():
                    "output": ("4 defect residuals, in HBM" if a.residual_only else
                               "4 defect residuals + all x-dependent COO Jacobian values (compact), in HBM")},
         "status": int(status),
-        # before anything was timed: candidate placements of the resident x / res / jvar buffers (a few launches each), the fastest
-        # kept (gelato_amd/placement.py; --placement-tries 1 takes what the allocator gives).  null: not used in this mode
+        # AFTER the timed regions of `value` / `value_settled` [r6]: candidate placements of the resident x / res / jvar buffers (a
+        # few launches each), the fastest kept (gelato_amd/placement.py), then W warm-up steps and the same K steps on them:
+        # `value_placed`.  Informational -- `value` is on the allocator's own placement.  null: --placement-tries 1 / phase-shard mode
         "buffer_placement": placement,
     }
+    if placement is not None and "error" not in placement:
+        placement["value_placed"] = evals / T_placed
+        placement["ms_per_step_placed"] = 1e3 * T_placed / K
+        placement["kernel_ms_placed"] = kern_ms_placed
+        placement["launches_before_value_placed"] = placement.get("all_launches", 0) + W
+        placement["value_placed_over_value"] = T / T_placed
     out["build"] = build
     if not shard:
         # one launch = B evals on this rank; HIP events on the launch stream over the K timed launches
@@ -459,6 +511,9 @@ def main():
                            # regions and the settling launches between them): what `rocprofv3 --kernel-trace --stats` of the run averages
                            "kernel_ms_mean_of_all_launches": all_ms / max(all_n, 1), "launches_so_far": all_n,
                            "frac_settled": abytes / (kern_ms_settled * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_settled": kern_ms_settled,
+                           # informational: on the placed buffers (buffer_placement); frac / kernel_ms are on the allocator's placement
+                           "frac_placed": (abytes / (kern_ms_placed * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms_placed == kern_ms_placed else None,
+                           "kernel_ms_placed": kern_ms_placed if kern_ms_placed == kern_ms_placed else None,
                            "algorithmic_bytes_per_eval": a_min, "algorithmic_bytes_per_launch": abytes,
                            # what one eval actually writes (residual + the DISTINCT x-dependent values; the gather map
                            # restores negated / shared / structurally constant entries) -- `achieved` uses SURVEY 8(d)'s
@@ -547,9 +602,12 @@ def main():
                                       "update_in_place": {"x_dependent_entries": nvar_entries, "update_kernel_ms": ms_upd,
                                                           "fused_plus_update_ms": ms_both,
                                                           "algorithmic_bytes_per_launch": 8 * (E.V + nvar_entries) * Bf},
-                                      "evals_per_s_fused_plus_expand": Bf / (ms_both * 1e-3),
-                                      "evals_per_s_fused_plus_expand_mode": "update in place (gel_fill_full_device once, gel_eval_full_device per step: fused "
-                                                                           "launch + update of the x-dependent entries); the full rewrite is evals_per_s_fused_plus_full_rewrite"}
+                                      # key names as in rounds 1-4: ..._fused_plus_expand = fused launch + FULL rewrite of every COO
+                                      # value (expand_kernel); the update-in-place mode of round 5 has its own key
+                                      "evals_per_s_fused_plus_expand": Bf / ((ms_fused + ms) * 1e-3),
+                                      "evals_per_s_fused_plus_update_in_place": Bf / (ms_both * 1e-3),
+                                      "update_in_place_mode": "gel_fill_full_device once, gel_eval_full_device per step: fused launch + update of "
+                                                              "the x-dependent entries (every COO value valid in HBM after each step)"}
             del dfull
         except Exception as ex:  # noqa: BLE001
             out["full_coo_expand"] = {"error": str(ex)}
@@ -571,13 +629,15 @@ def main():
             return 1e3 * float(np.median(ts)), 1e3 * float(ts.mean()), 1e3 * float(np.percentile(ts, 90))
 
         med, mean, p90 = b1_stats(lambda: E.eval(x0, out=pvals, res_out=pres), 300)
-        out["b1_host_callback_ms"], out["b1_host_callback_ms_mean"], out["b1_host_callback_ms_p90"] = med, mean, p90
+        out["b1_pinned_buffers_ms_median"], out["b1_pinned_buffers_ms_mean"], out["b1_pinned_buffers_ms_p90"] = med, mean, p90
         vals = E.eval(x0)[1]
-        med, mean, p90 = b1_stats(lambda: E.eval(x0, out=vals), 100)
-        out["b1_host_callback_ms_caller_arrays"] = med
+        med_c, mean_c, p90_c = b1_stats(lambda: E.eval(x0, out=vals), 50)
+        # key as in rounds 1-4: the MEAN of 50 calls into the caller's numpy arrays
+        out["b1_host_callback_ms"] = mean_c
+        out["b1_host_callback_ms_caller_arrays_median"] = med_c
         out["b1_note"] = ("one residual + full-COO Jacobian evaluation of one decision vector through Engine.eval (ctypes included): "
-                          "b1_host_callback_ms = median per call into the handle's pinned buffers (zero-copy; mean and p90 beside it), ..._caller_arrays "
-                          "= median into numpy arrays of the caller")
+                          "b1_host_callback_ms = mean of 50 calls into numpy arrays of the caller (the key's meaning since round 1); "
+                          "b1_pinned_buffers_ms_* = 300 calls into the handle's pinned buffers (zero-copy, COO-direct), median / mean / p90")
         # informational: the batched host-buffer entry point (pageable caller buffers -> pinned staging -> H2D,
         # launch, D2H of residuals + compact Jacobian values): PCIe inclusive, never `value`
         Bh = min(B, 512)
@@ -681,9 +741,10 @@ def main():
                     cand.append(e0.elapsed_time(e1) / 10)
                     del dcon, djac
                     torch.cuda.empty_cache()
-                msl = min(cand)
+                msl = cand[0]      # the allocator's own placement; the fastest of the candidates beside it (informational)
                 out["aero_constraints"]["large_batch"] = {"batch": Bl_, "device_kernel_ms": msl, "device_resident_vectors_per_s": Bl_ / (msl * 1e-3),
                                                           "hbm_frac": 8 * (E.nvars + rows + grads) * Bl_ / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                          "hbm_frac_best_placement": 8 * (E.nvars + rows + grads) * Bl_ / (min(cand) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                           "buffer_placement_ms": [round(c, 4) for c in cand]}
         except Exception as ex:  # noqa: BLE001
             out["aero_constraints"] = {"error": str(ex)}
@@ -762,33 +823,38 @@ def main():
                 El = Engine(prob_l, D=D_l, tau=tau_l, device=local, flags=fl)
                 Xl = problem.synthetic_batch(pack_x(xd_l), El.M, LEG_DISTINCT)
                 dXl = torch.from_numpy(Xl).to(dev).repeat(Bl // LEG_DISTINCT, 1).contiguous()
-                place_l = None
-                if a.placement_tries > 1:      # as for the headline: the leg's buffers placed once, before its warm-up
+                # [r6] as for the headline: `value` / `frac` on the allocator's placement; then the leg's buffers placed (the fastest of
+                # four candidates) -> `value_placed` / `frac_placed`, informational
+                dresl = torch.empty((Bl, El.nres), dtype=torch.float64, device=dev)
+                djvl = None if resonly else torch.empty((Bl, El.V), dtype=torch.float64, device=dev)
+
+                def measure_leg():
+                    jp_ = 0 if djvl is None else djvl.data_ptr()
+
+                    def leg_step():
+                        El.eval_batch_device(Bl, dXl.data_ptr(), dresl.data_ptr(), jp_, stream)
+                    leg_step()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    leg_step()
+                    torch.cuda.synchronize()
+                    one_ms = 1e3 * (time.perf_counter() - t0)
+                    for _ in range(max(2, min(2000, int(WARM_MS / max(one_ms, 1e-3))))):
+                        leg_step()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(LEG_K):
+                        leg_step()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / LEG_K
+                ms = measure_leg()
+                place_l, ms_placed = None, None
+                if a.placement_tries > 1:
                     from gelato_amd.placement import place_batch_buffers
                     dXl, dresl, djvl, place_l = place_batch_buffers(El, dXl, want_jac=not resonly, tries=min(a.placement_tries, 4),
                                                                     launches=8, warm=4, stream=stream, seed=1)
-                else:
-                    dresl = torch.empty((Bl, El.nres), dtype=torch.float64, device=dev)
-                    djvl = None if resonly else torch.empty((Bl, El.V), dtype=torch.float64, device=dev)
-                jp = 0 if djvl is None else djvl.data_ptr()
-
-                def leg_step():
-                    El.eval_batch_device(Bl, dXl.data_ptr(), dresl.data_ptr(), jp, stream)
-                leg_step()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                leg_step()
-                torch.cuda.synchronize()
-                one_ms = 1e3 * (time.perf_counter() - t0)
-                for _ in range(max(2, min(2000, int(WARM_MS / max(one_ms, 1e-3))))):
-                    leg_step()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(LEG_K):
-                    leg_step()
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / LEG_K
+                    ms_placed = measure_leg()
                 st_l = El.sync(stream)
                 amin_l = 8 * (El.nvars + El.nres) if resonly else El.algorithmic_bytes
                 tag_l = wl + ("_resonly" if resonly else "") + ("_flags%d" % fl if fl else "")
@@ -801,13 +867,16 @@ def main():
                            "frac_of_bytes_moved": None if moved is None else moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "kernel": "gel::eval_kernel<%s, %s, %s, %s>" % tuple("true" if v else "false" for v in (inf_l[0], inf_l[1], inf_l[2], inf_l[4])),
                            "status": int(st_l),
+                           "value_placed": None if ms_placed is None else Bl / (ms_placed * 1e-3),
+                           "frac_placed": None if ms_placed is None else amin_l * Bl / (ms_placed * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "buffer_placement_ms": None if place_l is None else [round(c["ms_per_launch"], 4) for c in place_l["candidates"]]}
                 El.close()
                 del dXl, dresl, djvl, El
             except Exception as ex:  # noqa: BLE001
                 oc[key] = {"error": str(ex)[:300]}
         oc["note"] = ("%d distinct synthetic vectors tiled to the batch on the device; >= 40 ms of untimed launches, then %d launches under "
-                      "HIP events; after the headline's timed region; %.1f s in all" % (LEG_DISTINCT, LEG_K, time.perf_counter() - t_legs))
+                      "HIP events -> value / frac on the allocator's placement, value_placed / frac_placed on the fastest of four candidate "
+                      "placements; after the headline's timed region; %.1f s in all" % (LEG_DISTINCT, LEG_K, time.perf_counter() - t_legs))
         out["other_configs"] = oc
 
     if not a.no_cpu_baseline:   # rank 0, at every N

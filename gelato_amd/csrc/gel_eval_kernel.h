@@ -102,6 +102,12 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #define GEL_STORE_AUX 2  // cache policy of the Jacobian stores: 2 = nt (A/B: 0 plain, 1 sc0, 16 sc1, 18 sc1+nt)
 #endif
 
+#ifndef GEL_AERO_STORE_AUX
+#define GEL_AERO_STORE_AUX 0  // cache policy of the fused kernel's aero-row stores.  A spec's rows are n + 1 doubles long and the lanes write nodes
+                              // 1 .. n: every 512-byte store starts 8 bytes into a 64-byte line and ends 8 bytes into another, and the
+                              // neighbouring column fills the rest later -- ordinary stores let the partial lines meet in L2
+#endif
+
 // JAC: also the FD Jacobian.  MFMA: D.X on the matrix pipe (v_mfma_f64_16x16x4_f64) instead of VALU FMAs.
 // SPLIT (latency form for a handful of decision vectors, e.g. the optimiser's B = 1 callback): every work item
 // becomes four wavefronts -- part 0 does everything except the three position sweeps, parts 1..3 do the
@@ -318,7 +324,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     const double _v = (val);                                                            \
     gel_u2 _d;                                                                          \
     __builtin_memcpy(&_d, &_v, 8);                                                      \
-    __builtin_amdgcn_raw_buffer_store_b64(_d, ars, jvo, (byteoff), GEL_STORE_AUX);      \
+    __builtin_amdgcn_raw_buffer_store_b64(_d, ars, jvo, (byteoff), GEL_AERO_STORE_AUX); \
   } while (0)
 // (latency form: the rows go to pinned host memory -- streamed, so that they cross PCIe while the wavefront computes on instead of
 // waiting in L2 for the end of the kernel; throughput form: the strided rows' partial lines want to meet in L2 first)

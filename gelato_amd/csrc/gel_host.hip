@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <chrono>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -205,6 +206,7 @@ struct gel_problem {
   int32_t* d_done = nullptr;                                  // self-signalling one-vector launches (ProblemDev::done_flag): device counter,
   volatile int32_t* h_done = nullptr;                         // pinned host word, sequence number of the last armed launch
   int32_t done_seq = 0;
+  long long done_ema_us = 100;                                // running estimate of a self-signalling launch's wait (sets the spin budget)
   int jfd_status = GEL_OK;
   // knot / terminal / user rows (gel_rows_configure)
   std::vector<gel::LinRowDev> lin_rows;
@@ -434,15 +436,33 @@ static void arm_done(gel_problem* p, gel::ProblemDev& dv) {
   dv.done_seq = ++p->done_seq;
 }
 static hipError_t spin_wait(hipStream_t s);
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::this_thread::yield();
+#endif
+}
 static hipError_t wait_done(gel_problem* p, const gel::ProblemDev& dv) {
   if (dv.done_flag) {
+    // Spin budget: a few times what this handle's launches have taken so far (floor 200 us, ceiling 5 ms) -- with several resident
+    // processes taking turns on the GPU, or a preempted queue, a fixed 5 ms burnt a core per call before the runtime's wait was
+    // taken anyway.  A launch that never signals (it should not happen) falls back to that wait as well.
     const auto t0 = std::chrono::steady_clock::now();
+    const auto budget = std::chrono::microseconds(std::min<long long>(5000, std::max<long long>(200, 8 * p->done_ema_us)));
     for (unsigned it = 1;; it++) {
-      if (*p->h_done == dv.done_seq) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
-      __builtin_ia32_pause();
-      // a launch that never signals (it should not happen) falls back to the runtime's wait after 5 ms
-      if ((it & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+      if (*p->h_done == dv.done_seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        p->done_ema_us = (3 * p->done_ema_us + us + 3) / 4;
+        return hipSuccess;
+      }
+      cpu_relax();
+      if ((it & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > budget) break;
     }
+    p->done_ema_us = std::min<long long>(5000, 2 * p->done_ema_us + 50);   // the wait outlasted the budget: a longer one next time
   }
   return spin_wait(p->stream);
 }
@@ -1796,7 +1816,12 @@ int gel_eval_batch_aero_device(gel_problem* p, int32_t B, const double* d_x, dou
     out.con[k] = out.nrows[k] ? d_aero + p->aero_off_con[k] : nullptr;
     out.jac[k] = out.nrows[k] ? d_aero + p->aero_off_jac[k] : nullptr;
   }
-  bool fused = gel::eval_aero_fusable(p->dev, B) && std::getenv("GEL_AERO_UNFUSED") == nullptr;
+  // Measured (MI355X, mixed-6x64, B = 65536, profiles/r06/aero_fused_*): the fused launch 5.47 ms + the node-0 launch 0.48 ms against
+  // 3.30 + 2.05 ms for the two kernels -- the aero rows' own algebra (32 gradient entries per node: cosine, alpha difference, q,
+  // scaling) is 1,480 vector instructions per wavefront on top of the fused kernel's 1,966, against aero_kernel's 1,984 with the
+  // chain: sharing the chain saves a quarter of the instructions and runs the rest at four waves per SIMD beside 60 stores per
+  // lane.  So the two kernels are the default; GEL_AERO_FUSED=1 selects the fused launch (same bits, tests/test_aero_engine.py).
+  bool fused = gel::eval_aero_fusable(p->dev, B) && std::getenv("GEL_AERO_FUSED") != nullptr && std::getenv("GEL_AERO_FUSED")[0] == '1';
   if (fused) {
     bool any = false;
     for (const auto& a : p->aero_ph) any = any || a.kinds != 0;
@@ -1809,7 +1834,7 @@ int gel_eval_batch_aero_device(gel_problem* p, int32_t B, const double* d_x, dou
     HIPCHK(gel::launch_aero_wide(p->dev, (int)p->aero_rest.size(), p->d_aero_rest, B, d_x, out, p->aero_ld, s));
   } else {
     HIPCHK(gel::launch_eval(p->dev, B, d_x, d_res, d_jvar, s));
-    HIPCHK(gel::launch_aero_wide(p->dev, (int)p->aero_nodes.size(), p->d_aero_nodes, B, d_x, out, p->aero_ld, s));
+    HIPCHK(gel::launch_aero(p->dev, (int)p->aero_nodes.size(), p->d_aero_nodes, B, d_x, out, s, p->aero_ld));
   }
   return GEL_OK;
 }

@@ -360,7 +360,8 @@ struct AeroOut {
   double* con[3];   // [B][nrows[kind]]
   double* jac[3];   // [B][nrows[kind] * (8 + 4 (kind != 1))]: position | velocity | quaternion | t blocks
   int32_t nrows[3];
-  int64_t ld;       // WIDE form: doubles from one vector's record to the next (con / jac point at the kind's part of record 0)
+  int64_t ld;       // != 0: the outputs are per-vector RECORDS of ld doubles (gel_eval_batch_aero_device): con / jac point at the
+                    // kind's part of record 0, a vector's part lies b * ld doubles on; 0: dense [B][...] arrays per kind
 };
 
 // One WAVEFRONT = 64 consecutive constrained nodes of one decision vector, every sweep of the node in the same lane (round 2 ran
@@ -510,7 +511,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
         const bool has = live && O.jac[kind] && row >= 0;
         // FLAT: the vector's gradient values start b R (8 + nq) doubles into the kind's buffer (unsigned 32-bit byte offsets: the
         // launcher keeps to the per-vector mapping where a batch's gradients exceed 4 GB); -1 = no entry
-        const unsigned vb = flat ? (unsigned)b * (unsigned)(O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)) * 8) : 0u;
+        const unsigned vb = flat ? (unsigned)b * (unsigned)(O.ld ? (int)O.ld * 8 : O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)) * 8) : 0u;
         ipark[kind * 64] = 8 * Nd.nk[kind];
         ipark[AP_AIDX(kind, 3) * 64] = has ? (int)(vb + 8u * (unsigned)(3 * Nd.row0[kind] + Nd.k)) : -1;
         ipark[AP_AIDX(kind, 2) * 64] = has ? (int)(vb + 8u * (unsigned)(2 * Nd.row0[kind] + Nd.k)) : -1;
@@ -520,7 +521,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
       if (ROLES) __builtin_nontemporal_store(cv, O.con[kind] + (size_t)b * O.nrows[kind] + row);
       else if (WIDE) O.con[kind][(size_t)b * O.ld + row] = cv;
-      else O.con[kind][(size_t)b * O.nrows[kind] + row] = cv;
+      else O.con[kind][(size_t)b * (O.ld ? (size_t)O.ld : (size_t)O.nrows[kind]) + row] = cv;
       chk += cv;
     }
     ipark[11 * 64] = centre_ok ? 1 : 0;
@@ -573,7 +574,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
   __amdgpu_buffer_rsrc_t jrs[3];
 #pragma unroll
   for (int kind = 0; kind < 3; kind++)
-    jrs[kind] = __builtin_amdgcn_make_buffer_rsrc((O.jac[kind] && !WIDE) ? (void*)(O.jac[kind] + (flat ? (size_t)0 : (size_t)__builtin_amdgcn_readfirstlane(b) * O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)))) : (void*)nullptr,
+    jrs[kind] = __builtin_amdgcn_make_buffer_rsrc((O.jac[kind] && !WIDE) ? (void*)(O.jac[kind] + (flat ? (size_t)0 : (size_t)__builtin_amdgcn_readfirstlane(b) * (O.ld ? (size_t)O.ld : (size_t)O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4))))) : (void*)nullptr,
                                                   0, -1, 0x00020000);
   if (want_jac) {
     // ---- t0 / tf columns
@@ -714,19 +715,33 @@ hipError_t launch_aero_wide(const ProblemDev& P, int nnodes, const AeroNodeDev* 
   return hipGetLastError();
 }
 
+// ld != 0: per-vector records (see AeroOut).  The flat mapping addresses a batch's gradient values with 32-bit byte offsets: a
+// batch whose records span more is launched in runs of vectors that do not.
 hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
-                       const AeroLaunchOut& out, hipStream_t s) {
+                       const AeroLaunchOut& out, hipStream_t s, long long ld) {
   if (B <= 0 || nnodes <= 0) return hipSuccess;
+  if (ld > 0 && B > 1 && nnodes >= 64 && (nnodes & 63) != 0) {
+    const long long run = ((1LL << 32) - (1LL << 25)) / (ld * 8);
+    if (run >= 1 && run < B) {
+      for (long long b0 = 0; b0 < B; b0 += run) {
+        AeroLaunchOut o = out;
+        for (int k = 0; k < 3; k++) { if (o.con[k]) o.con[k] += b0 * ld; if (o.jac[k]) o.jac[k] += b0 * ld; }
+        const hipError_t e = launch_aero(P, nnodes, nodes, (int)std::min<long long>(run, B - b0), d_x + b0 * P.nvars, o, s, ld);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    }
+  }
   AeroOut O;
   for (int k = 0; k < 3; k++) { O.con[k] = out.con[k]; O.jac[k] = out.jac[k]; O.nrows[k] = out.nrows[k]; }
-  O.ld = 0;
+  O.ld = ld;
   int tiles = (nnodes + 63) / 64;
   const size_t lds = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + (size_t)kAeroWaves * kAeroParkSlots * 64);
   long long waves = (long long)B * tiles;
   // flat (vector, node) mapping (tiles = 0 tells the kernel): no mostly-empty last tile per vector; needs every wavefront inside two
   // vectors and the batch's gradient values of a kind inside 32-bit byte offsets
   long long maxbytes = 0;
-  for (int k = 0; k < 3; k++) maxbytes = std::max(maxbytes, (long long)B * O.nrows[k] * (8 + ((k == 1) ? 0 : 4)) * 8);
+  for (int k = 0; k < 3; k++) maxbytes = std::max(maxbytes, (long long)B * (ld ? ld : (long long)O.nrows[k] * (8 + ((k == 1) ? 0 : 4))) * 8);
   if (B > 1 && nnodes >= 64 && (nnodes & 63) != 0 && maxbytes < (1LL << 32) - (1LL << 24)) {
     waves = ((long long)B * nnodes + 63) / 64;
     tiles = 0;

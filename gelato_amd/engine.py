@@ -37,6 +37,10 @@ def pack_x(xdict, out=None):
     return np.concatenate([np.asarray(xdict[k], dtype=np.float64).ravel() for k in XKEYS], out=out)
 
 
+class _PinnedView(np.ndarray):
+    """numpy view of the handle's pinned host memory that keeps its Engine alive (attribute _engine on the base view)"""
+
+
 class Engine:
     """prob: dict with num_nodes, thrust, massflow, reference_area, nozzle_area, engine_on,
     attitude_hold, units (mass, position, velocity, u, t), dx, wind_table [K,3], ca_table [K,2];
@@ -107,6 +111,7 @@ class Engine:
         self._src = None
         self._nlin = self._nfn = 0
         self._cfg_gen = 0       # bumped by every (re)configuration of the row table or of an aero kind
+        self.shard_plan_key = None   # (ranks, width, unit ranges) of the plan the handle holds (shard_plan)
 
     # ------------------------------------------------------------------
     def close(self):
@@ -177,8 +182,16 @@ class Engine:
         x = _f64(x)
         assert x.size == self.nvars
         res = np.empty(self.nres)
+        self._direct_call()
         rc = check(lib().gel_eval_residual(self._h, _d(x), _d(res)))
         return res, rc
+
+    def _direct_call(self):
+        """A one-vector call outside eval_callback rewrites the handle's pinned value array (the COO-direct path writes through
+        it even when the caller names its own output) and residual vector -- the memory eval_callback hands out as its frame's
+        `vals` / `res`.  A frame cached by the reference-named functions (con_dynamics._State.frame) is only valid for the
+        generation it was evaluated in: bump it, so that the next mirror call evaluates again."""
+        self._cfg_gen = getattr(self, "_cfg_gen", 0) + 1
 
     def eval_jacobian(self, x, out=None):
         """-> (vals_full [total_nnz], status).  `out` (from a previous call) is updated in place:
@@ -189,6 +202,7 @@ class Engine:
         if out is None:
             out = np.empty(self.total_nnz)
             fill = 1
+        self._direct_call()
         rc = check(lib().gel_eval_jacobian(self._h, _d(x), _d(out), fill))
         return out, rc
 
@@ -202,9 +216,15 @@ class Engine:
             r, v, x0, x1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
             check(lib().gel_pinned_buffers(self._h, C.byref(r), C.byref(v), C.byref(x0), C.byref(x1)))
             dp = C.POINTER(C.c_double)
-            res = np.ctypeslib.as_array(C.cast(r, dp), shape=(self.nres,))
-            vals = np.ctypeslib.as_array(C.cast(v, dp), shape=(max(self.total_nnz, 1),))[:self.total_nnz]
-            xb = [np.ctypeslib.as_array(C.cast(q, dp), shape=(self.nvars,)) for q in (x0, x1)]
+            # the views hold a reference to this engine (every slice of them reaches it through .base): the pinned memory is
+            # freed by close(), and a garbage-collected engine closes itself -- not while one of these arrays is alive
+            def view(ptr, n):
+                a = np.ctypeslib.as_array(C.cast(ptr, dp), shape=(n,)).view(_PinnedView)
+                a._engine = self
+                return a
+            res = view(r, self.nres)
+            vals = view(v, max(self.total_nnz, 1))[:self.total_nnz]
+            xb = [view(q, self.nvars) for q in (x0, x1)]
             pb = self._pinned = (res, vals, _d(res), _d(vals), xb, [_d(b) for b in xb])
         return pb[0], pb[1]
 
@@ -228,6 +248,7 @@ class Engine:
             out = np.empty(self.total_nnz)
             fill = 1
         vp = pb[3] if (pb is not None and out is pb[1]) else _d(out)
+        self._direct_call()
         rc = check(lib().gel_eval(self._h, _d(x), rp if rp is not None else _d(res), vp, fill))
         return res, out, rc
 
@@ -327,11 +348,15 @@ class Engine:
         """rank `rank`'s units of all B vectors straight into its slice of the exchange buffer d_out [nranks][B][width].
         plan = (nranks, width) the buffer was sized for (default: the handle's current plan); the call fails if the handle
         holds another plan by now."""
+        if plan is None and self.shard_plan_key is None:
+            raise _lib.GelatoAmdError("no shard plan on this handle: call shard_plan(unit_begin) first (or pass plan=(ranks, width))")
         nr, w = plan if plan is not None else self.shard_plan_key[:2]
         check(lib().gel_eval_shard_packed_device(self._h, B, d_x, d_out, int(rank), int(nr), int(w), stream or None))
 
     def shard_unpack_device(self, B, d_out, d_res, d_jvar, stream=0, plan=None):
         """exchange buffer -> the ordinary res [B][11N] / jvar [B][V] layouts (one gather launch; either may be 0)"""
+        if plan is None and self.shard_plan_key is None:
+            raise _lib.GelatoAmdError("no shard plan on this handle: call shard_plan(unit_begin) first (or pass plan=(ranks, width))")
         nr, w = plan if plan is not None else self.shard_plan_key[:2]
         check(lib().gel_shard_unpack_device(self._h, B, d_out, d_res or None, d_jvar or None, int(nr), int(w), stream or None))
 

@@ -86,7 +86,13 @@ class UnitShards:
             self.ranges = [(int(self.unit_begin[r]), int(self.unit_begin[r + 1] - self.unit_begin[r])) for r in range(self.world)]
         self.engine = engine
         import os
-        self.inplace = os.environ.get("GELATO_AMD_ALLGATHER_COPY", "0") in ("", "0")
+        # [r6] default: the NON-aliased send buffer (a copy of this rank's slice: one device copy of width * B doubles per step).  The
+        # in-place form (send = a view of the receive buffer at the rank's offset: documented for NCCL / RCCL all-gather, a memcpy
+        # with src == dst on gloo) has never run on RCCL with more than one rank from this repository -- gpurun boxes have one GPU,
+        # the driver's multi-GPU records were skipped in every round -- so it is opt-in until it has: GELATO_AMD_ALLGATHER_INPLACE=1
+        # (GELATO_AMD_ALLGATHER_COPY=1, the older switch, still forces the copy)
+        self.inplace = (os.environ.get("GELATO_AMD_ALLGATHER_INPLACE", "0") not in ("", "0")
+                        and os.environ.get("GELATO_AMD_ALLGATHER_COPY", "0") in ("", "0"))
         self.width, self.res_pos, self.jv_pos = engine.shard_plan(self.unit_begin)
         self.plan_key = engine.shard_plan_key
         self.nres, self.V = engine.nres, engine.V

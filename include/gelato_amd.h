@@ -267,11 +267,13 @@ int gel_eval_aero_all_device(gel_problem* p, int32_t B, const double* d_x, doubl
  * gel_eval_batch_device writes them; d_aero [B][width]: ONE record per decision vector,
  *   [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha]      (gel_aero_record_layout: width and the six offsets),
  * each part laid out exactly like the corresponding array of gel_eval_aero_all (a kind without rows has an empty part).
- * Where the launch takes the throughput form with one decision vector per wavefront, the lanes of an aerodynamic phase write the
- * aero rows of their state nodes 1 .. n themselves, from the centre evaluation and the position sweeps they run anyway, and one
- * small launch adds the rows no lane has (state node 0 of a phase, phases without aerodynamics); otherwise (a handful of vectors,
- * meshes of phases of at most 32 nodes, GEL_FLAG_FD_RECOMPUTE) the two kernels run one after the other.  Every value is the same
- * bit for bit as gel_eval_batch_device's and gel_eval_aero_all_device's.  Asynchronous on `stream`; status through gel_sync. */
+ * Default: the defect kernel and the aero kernel one after the other on `stream`.  Environment GEL_AERO_FUSED=1: where the launch
+ * takes the throughput form with one decision vector per wavefront, the lanes of an aerodynamic phase write the aero rows of their
+ * state nodes 1 .. n themselves, from the centre evaluation and the position sweeps they run anyway, and one small launch adds the
+ * rows no lane has (state node 0 of a phase, phases without aerodynamics) -- built and measured in round 6: the rows' own algebra
+ * outweighs the shared chain (83-91 against 78-81 ns per vector at mixed-6x64), so it is not the default.  Every
+ * value is the same bit for bit as gel_eval_batch_device's and gel_eval_aero_all_device's either way.  Asynchronous on `stream`;
+ * status through gel_sync. */
 int gel_aero_record_layout(const gel_problem* p, int64_t* width, int64_t* off_con /* [3] */, int64_t* off_jac /* [3] */);
 int gel_eval_batch_aero_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar, double* d_aero,
                                void* stream);

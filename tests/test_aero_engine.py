@@ -38,6 +38,11 @@ def test_aero_pattern_host_only(cname):
 EXPECTED_UNBOUNDED = {"example": 0, "synthetic": 20}    # entries whose derived bound is not finite, per block: five q-alpha rows of the synthetic set (x 3, 3, 4, 2 columns)
 MIN_CAUGHT = {"example": 10, "synthetic": 3}            # entries a first-order truncation of the alpha difference must push out of tolerance
 BENIGN_LAT_DEG, BENIGN_ALPHA_DEG = 55.0, 1.0   # the region the margins table reports separately (moderate latitude, an angle of attack above a degree)
+# SURVEY 8(c)'s FLAT tolerance (1e-5 + 1e-6 |ref|) is NOT met on q-alpha rows even in that benign region: a q-alpha entry is the
+# angle's entry times q / limit, so its forward-difference noise floor is the angle's times that factor.  Recorded in round 5
+# (profiles/r05/parity_margins.json): worst excess over the flat tolerance there +4.70e-5 (g9_example) / +3.93e-5 (g9_synthetic) on
+# q-alpha rows, none (< 0) on alpha and q rows.  The ceilings below keep those figures from drifting [r6, VERDICT r5 item 8].
+FLAT_EXCESS_BENIGN_CEILING = {"alpha": 0.0, "q": 0.0, "qalpha": 6.0e-5}
 
 
 def aero_margins(cname, flags=0):
@@ -143,6 +148,10 @@ def test_aero_values_and_gradients_gpu(cname, flags):
         # (2) the FLAT tolerance of SURVEY 8(c) where it holds: every dynamic-pressure entry; angle-of-attack entries below
         #     55 deg of latitude above 1 deg of angle of attack; q-alpha entries there with the flat term times (1 + q / limit)
         assert row["worst_flat_domain_excess"] is None or row["worst_flat_domain_excess"] <= 0.0, (what, row["worst_flat_domain_excess"])
+        # (2b) how far the flat tolerance is missed where the stated one is needed -- q-alpha rows of the benign region -- stays
+        #      below its recorded ceiling; alpha and q rows meet the flat tolerance there
+        assert row["worst_flat_excess_benign"] is None or row["worst_flat_excess_benign"] <= FLAT_EXCESS_BENIGN_CEILING[row["kind"]], \
+            (what, row["worst_flat_excess_benign"])
         # entries without a finite bound (the air-relative speed may vanish: lift-off inside the wind table) are counted, not hidden
         assert row["entries_without_finite_bound"] <= EXPECTED_UNBOUNDED[cname], (what, row["entries_without_finite_bound"])
     # (3) the tolerance has teeth: with the alpha-difference series cut after its first term the same assertion (1) fails
@@ -388,16 +397,18 @@ def _ragged(pdict):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("name,B,specs", [("mixed-6x64", 70, _all_air()), ("mixed-6x64", 67, _ragged), ("dense-6x64", 65, _all_air()),
                                           ("stress-12x128", 66, _all_air()), ("example", 300, _ragged), ("3x32", 70, _all_air()),
                                           ("mixed-6x64", 3, _all_air())])
-def test_defect_groups_and_aero_rows_in_one_launch_equal_the_two_kernels(name, B, specs):
+def test_defect_groups_and_aero_rows_in_one_call_equal_the_two_kernels(name, B, specs, fused, monkeypatch):
     """gel_eval_batch_aero_device [r6]: residual rows, compact Jacobian values and every aero constraint value / gradient value of
-    every vector are THE BITS of gel_eval_batch_device and gel_eval_aero_all_device -- where the aero rows ride in the fused
-    kernel's lanes (cooperative form, one vector per wavefront: mixed / dense / 12 x 128 / the shipped example at B >= 65; the
-    rows of state node 0 and of phases without aerodynamics by the second launch) and where the call falls back to the two
-    kernels (a handful of vectors; 3 x 32: two vectors per wavefront).  Nothing outside the record's parts is written, nothing
-    inside is left unwritten."""
+    every vector are THE BITS of gel_eval_batch_device and gel_eval_aero_all_device -- with GEL_AERO_FUSED=1 where the aero rows
+    ride in the fused kernel's lanes (cooperative form, one vector per wavefront: mixed / dense / 12 x 128 at B >= 65; the rows of
+    state node 0 and of phases without aerodynamics by the second launch) and where that call falls back to the two kernels (a
+    handful of vectors; example / 3 x 32: two vectors per wavefront), and in the default form (the two kernels writing the
+    per-vector records).  Nothing outside the record's parts is written, nothing inside is left unwritten."""
+    monkeypatch.setenv("GEL_AERO_FUSED", fused)
     E, one, two, (width, ocon, ojac) = _fused_case(name, B, specs)
     assert np.array_equal(one["res"], two["res"]) and np.array_equal(one["jvar"], two["jvar"])
     covered = np.zeros(width, dtype=bool)
@@ -414,7 +425,7 @@ def test_defect_groups_and_aero_rows_in_one_launch_equal_the_two_kernels(name, B
 
 
 @pytest.mark.gpu
-def test_fused_aero_rows_take_the_recomputing_fallback_like_the_aero_kernel():
+def test_fused_aero_rows_take_the_recomputing_fallback_like_the_aero_kernel(monkeypatch):
     """Nodes whose perturbed point leaves the centre's atmosphere layer / wind-table piece (the difference form does not cover them)
     and nodes next to the polar axis: the fused lanes take the same per-lane fallbacks as aero_kernel -- same bits."""
     import torch
@@ -446,6 +457,7 @@ def test_fused_aero_rows_take_the_recomputing_fallback_like_the_aero_kernel():
     s = torch.cuda.current_stream().cuda_stream
     B = len(X)
     dX = torch.from_numpy(X).to(dev)
+    monkeypatch.setenv("GEL_AERO_FUSED", "1")
     width, ocon, ojac = E.aero_record_layout()
     r1 = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
     j1 = torch.empty((B, E.V), dtype=torch.float64, device=dev)

@@ -197,6 +197,7 @@ for it in range(2):                       # twice: the exchange buffer is reused
     assert np.array_equal(res.numpy(), ores), "residual after the all-gather"
     assert np.array_equal(jv.numpy(), full_jv), "jacobian after the all-gather"
 assert calls == ([rank] * 2 if sh.ranges[rank][1] > 0 else [])
+assert sh.inplace == (os.environ.get("GELATO_AMD_ALLGATHER_INPLACE", "0") == "1")
 # one collective per step, delivering (world-1)/world of the outputs up to padding to the largest share
 if {empty_rank} < 0:
     assert sh.bytes_received_per_vector() <= 8 * (E.nres + E.V) * (world - 1) / world * 1.6
@@ -218,7 +219,7 @@ print("WORKER_OK", rank)
 """
 
 
-def run_gloo_world(tmp_path, world, empty_rank=-1):
+def run_gloo_world(tmp_path, world, empty_rank=-1, inplace=False):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.replace("{empty_rank}", str(empty_rank)).replace("{root!r}", repr(ROOT)))
     s = socket.socket()
@@ -228,7 +229,7 @@ def run_gloo_world(tmp_path, world, empty_rank=-1):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1")
+                   OMP_NUM_THREADS="1", GELATO_AMD_ALLGATHER_INPLACE="1" if inplace else "0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -243,8 +244,11 @@ def run_gloo_world(tmp_path, world, empty_rank=-1):
         assert p.returncode == 0 and "WORKER_OK %d" % r in out, out[-3000:]
 
 
-def test_world_size_2_gloo(tmp_path):
-    run_gloo_world(tmp_path, 2)
+@pytest.mark.parametrize("inplace", [False, True])
+def test_world_size_2_gloo(tmp_path, inplace):
+    """inplace = False: the default since round 6 (the send buffer is a copy of the rank's slice); True: the aliased form
+    (GELATO_AMD_ALLGATHER_INPLACE=1), opt-in until it has run on RCCL with more than one rank"""
+    run_gloo_world(tmp_path, 2, inplace=inplace)
 
 
 def test_world_size_4_gloo_with_a_rank_without_units(tmp_path):

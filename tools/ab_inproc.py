@@ -3,7 +3,7 @@
 handles launch on the SAME device buffers, turns of AB_TURN_MS (default 1000) alternate in shuffled order.  Where the driver places
 a process's 14 GB of buffers moves a launch by up to 7 % (tools/ab_variants.py: processes of ONE build 3.06 .. 3.29 ms on one box);
 here the placement is common to both builds.  AB_PROCS (default 3) fresh processes = that many placements; pooled at the end.
-GPU box:  python3 tools/ab_inproc.py <workload> <batch> <rounds> <libA.so> <libB.so>   [env AB_RES_ONLY=1 | AB_AERO=1]"""
+GPU box:  python3 tools/ab_inproc.py <workload> <batch> <rounds> <libA.so> <libB.so>   [env AB_RES_ONLY=1 | AB_AERO=1 | AB_FUSED=1]"""
 import json, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,10 +42,19 @@ if aero:
     dcon = [torch.empty((B, d[0]), dtype=torch.float64, device="cuda") for d in dims]
     djac = [torch.empty((B, sum(d[1])), dtype=torch.float64, device="cuda") for d in dims]
     cp, jpp = [t.data_ptr() for t in dcon], [t.data_ptr() for t in djac]
+fused = os.environ.get("AB_FUSED", "0") == "1"         # defect groups + aero rows in one call (gel_eval_batch_aero_device)
+if fused:
+    S = pd["num_sections"]
+    for e in E:
+        for kind, lim in (("alpha", 0.2), ("q", 4.0e4), ("qalpha", 5.0e3)):
+            e.aero_configure(kind, [(i, 1, lim) for i in range(S - 1)])
+    da = torch.empty((B, E[0].aero_record_layout()[0]), dtype=torch.float64, device="cuda")
 def burst(e, n):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    if aero:
+    if fused:
+        for _ in range(n): e.eval_batch_aero_device(B, dX.data_ptr(), r.data_ptr(), j.data_ptr(), da.data_ptr(), s)
+    elif aero:
         for _ in range(n): e.eval_aero_all_device(B, dX.data_ptr(), cp, jpp, s)
     else:
         for _ in range(n): e.eval_batch_device(B, dX.data_ptr(), r.data_ptr(), jp, s)

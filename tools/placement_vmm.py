@@ -65,8 +65,22 @@ def way_vmm(chunk, align=0, shuffle=0, offset=0):
     return f
 
 
+def way_torch_pad1mb(i):
+    """as gelato_amd/placement.py: a pad of a random multiple of 1 MB in front"""
+    import random
+    rng = random.Random(i)
+    torch.cuda.empty_cache()
+    pad = torch.empty(rng.randrange(64, 4096) * (1 << 17), dtype=torch.float64, device="cuda") if i else None
+    j = torch.empty((B, E.V), dtype=torch.float64, device="cuda")
+    del pad
+    ms = measure(j.data_ptr())
+    ptr = j.data_ptr()
+    del j
+    return ms + [hex(ptr)]
+
+
 GB, MB = 1 << 30, 1 << 20
-ways = [("torch_hipMalloc", way_torch), ("vmm_one_handle", way_vmm(0)), ("vmm_2MB", way_vmm(2 * MB)), ("vmm_64MB", way_vmm(64 * MB)),
+ways = [("torch_pad1MB", way_torch_pad1mb)] + [("vmm_off%dMB" % o, way_vmm(0, GB, 0, o * MB)) for o in (0, 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31)] + [("torch_hipMalloc", way_torch), ("vmm_one_handle", way_vmm(0)), ("vmm_2MB", way_vmm(2 * MB)), ("vmm_64MB", way_vmm(64 * MB)),
         ("vmm_1GB", way_vmm(GB, GB)), ("vmm_2MB_shuffled", way_vmm(2 * MB, 0, 1)), ("vmm_1GB_shuffled", way_vmm(GB, GB, 1)),
         ("vmm_one_handle_off4K", way_vmm(0, 0, 0, 4096)), ("vmm_one_handle_off1M", way_vmm(0, 0, 0, MB))]
 if len(sys.argv) > 4:
