@@ -107,6 +107,7 @@ SIGNATURES = {
     "gel_eval_aero_all_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.c_void_p]),
     "gel_aero_record_layout": (C.c_int, [C.c_void_p, _lp, _lp, _lp]),
+    "gel_aero_record_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _lp]),
     "gel_eval_batch_aero_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gel_rows_configure": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GelLinearRow), C.c_int32, C.POINTER(GelNodefnRow)]),
     "gel_rows_dims": (C.c_int, [C.c_void_p, _ip, _ip]),

@@ -56,19 +56,24 @@ struct AeroRowDev {
 struct AeroNodeDev {
   int32_t phase, k;
   int32_t row[3], nk[3], row0[3];
+  int32_t ko;        // the node's place inside its spec's rows in the OUTPUT (k, or k - 1 in the lanes' part of a record: AeroPhaseDev)
   double limit[3];
 };
 
 // Aero rows written by the FUSED kernel (gel_eval_kernel.h, AERO instantiation; gel_eval_batch_aero_device): one record per phase.
 // The lanes of an aerodynamic phase's wavefront are its state nodes 1 .. n; where the phase has an "all nodes" spec of a kind they
 // also write that kind's constraint value and gradient entries of their node, from the centre evaluation and the position /
-// velocity / quaternion sweeps they run anyway.  Outputs: ONE record of aero_ld doubles per decision vector,
-// [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha], each part laid out like gel_eval_aero_all's arrays
-// (jac of a kind: position | velocity | quaternion | t blocks of R rows, a spec's entries [column][node]).  Byte offsets are
-// relative to the vector's record and name node 1 (lane 0 of the phase's first chunk), column 0.
+// velocity / quaternion sweeps they run anyway.  Outputs: ONE record of aero_ld doubles per decision vector in two parts, each
+// [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha] laid out like gel_eval_aero_all's arrays for ITS rows (jac
+// of a kind: position | velocity | quaternion | t blocks of R rows, a spec's entries [column][node]): part A = the rows the
+// lanes write (nodes 1 .. n of these phases: a spec's row of a column is n doubles, 512 bytes at n = 64, every part on a
+// 64-byte boundary -- whole lines per store), part B = every other row (state node 0 of a phase, phases without aerodynamics,
+// "initial" specs), written by aero_wide_kernel.  gel_aero_record_map gives the record index of every entry of the
+// reference's layout.  Byte offsets are relative to the vector's record and name node 1 (lane 0 of the phase's first chunk),
+// column 0.
 struct AeroPhaseDev {
   int32_t kinds;       // bit k: nodes 1 .. n of this phase have a row of kind k AND the phase runs the aerodynamic chain
-  int32_t nk8;         // 8 (n + 1): bytes between two columns of a spec's gradient block
+  int32_t nk8;         // 8 n: bytes between two columns of a spec's gradient block in part A
   int32_t con[3];      // kind k: the constraint value
   int32_t jac[3][4];   // kind k, block (0 position, 1 velocity, 2 quaternion, 3 t): the gradient entry
   double il[3];        // 1 / limit (limit = units[3] of con_aero.py), divided on the host (the same IEEE quotient the kernels' frcp forms)

@@ -154,11 +154,13 @@ struct gel_problem {
   // gel_eval_batch_aero_device (defect groups + aero rows, one output record per vector): the record's layout, the per-phase
   // records of the rows the fused kernel's lanes write, and the constrained nodes they do not reach (state node 0 of a phase,
   // phases without aerodynamics) -- left to aero_wide_kernel
-  int64_t aero_ld = 0, aero_off_con[3] = {0, 0, 0}, aero_off_jac[3] = {0, 0, 0};
+  int64_t aero_ld = 0, aero_off_con[2][3] = {{0, 0, 0}, {0, 0, 0}}, aero_off_jac[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  std::vector<gel::AeroRowDev> aero_part_rows[2][3];          // the rows of part A (the lanes') and part B (the rest), per kind
+  std::vector<int32_t> aero_part_of[3];                       // per row of a kind: part | (row inside the part) << 1
+  std::vector<gel::AeroNodeDev> aero_part_nodes[2];
   std::vector<gel::AeroPhaseDev> aero_ph;
-  std::vector<gel::AeroNodeDev> aero_rest;
   gel::AeroPhaseDev* d_aero_ph = nullptr;
-  gel::AeroNodeDev* d_aero_rest = nullptr;
+  gel::AeroNodeDev* d_aero_part_nodes[2] = {nullptr, nullptr};
   double *d_aero_x = nullptr, *d_aero_out = nullptr;          // working set of large host-buffer calls
   size_t d_aero_x_cap = 0, d_aero_out_cap = 0;                // doubles
   // device buffers (static)
@@ -1107,7 +1109,7 @@ int gel_problem_destroy(gel_problem* p) {
   if (p->cb_res) hipHostFree(p->cb_res);
   for (int i = 0; i < 2; i++) if (p->cb_x[i]) hipHostFree(p->cb_x[i]);
   hipFree(p->d_cval); hipFree(p->d_src); hipFree(p->d_flag); hipFree(p->d_unit_base); hipFree(p->d_shard_pos);
-  hipFree(p->d_aero_nodes); hipFree(p->d_aero_x); hipFree(p->d_aero_out); hipFree(p->d_aero_ph); hipFree(p->d_aero_rest);
+  hipFree(p->d_aero_nodes); hipFree(p->d_aero_x); hipFree(p->d_aero_out); hipFree(p->d_aero_ph); hipFree(p->d_aero_part_nodes[0]); hipFree(p->d_aero_part_nodes[1]);
   free_slots(p);
   hipFree(p->d_x); hipFree(p->d_res); hipFree(p->d_jv);
   if (p->h_x) hipHostFree(p->h_x);
@@ -1732,7 +1734,7 @@ int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_
   std::vector<gel::AeroNodeDev> nodes;
   for (int i = 0; i + 1 < (int)p->ph.size(); i++)
     for (int k = 0; k <= p->ph[i].n; k++) {
-      gel::AeroNodeDev nd{i, k, {-1, -1, -1}, {0, 0, 0}, {0, 0, 0}, {1.0, 1.0, 1.0}};
+      gel::AeroNodeDev nd{i, k, {-1, -1, -1}, {0, 0, 0}, {0, 0, 0}, k, {1.0, 1.0, 1.0}};
       bool any = false;
       for (int kd = 0; kd < 3; kd++) {
         const auto& A = p->aero_rows[kd];
@@ -1745,49 +1747,94 @@ int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_
       if (any) nodes.push_back(nd);
     }
   p->aero_nodes = nodes;
-  // ---- the per-vector record of gel_eval_batch_aero_device: [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha]
+  // ---- the per-vector record of gel_eval_batch_aero_device: two parts, each in gel_eval_aero_all's layout for ITS rows.
+  //      Part A: nodes 1 .. n of the aerodynamic phases' "all nodes" specs -- what the fused kernel's lanes can write, a spec's row of
+  //      a column n doubles long.  Part B: every other row.  Every section starts on a multiple of eight doubles.
+  auto fusable = [&](const gel::AeroRowDev& r) { return p->ph[r.phase].air && r.nk == p->ph[r.phase].n + 1 && r.k >= 1; };
+  for (int part = 0; part < 2; part++)
+    for (int kd = 0; kd < 3; kd++) {
+      p->aero_part_rows[part][kd].clear();
+      p->aero_part_of[kd].assign(p->aero_rows[kd].size(), 0);
+    }
+  for (int kd = 0; kd < 3; kd++) {
+    const auto& A = p->aero_rows[kd];
+    for (size_t r0 = 0; r0 < A.size(); r0 += A[r0].nk) {
+      // the spec's rows of part A and of part B, each a spec of its own there
+      int rowA0 = (int)p->aero_part_rows[0][kd].size(), rowB0 = (int)p->aero_part_rows[1][kd].size(), nA = 0, nB = 0;
+      for (int k = 0; k < A[r0].nk; k++) (fusable(A[r0 + k]) ? nA : nB)++;
+      int iA = 0, iB = 0;
+      for (int k = 0; k < A[r0].nk; k++) {
+        const bool fa = fusable(A[r0 + k]);
+        gel::AeroRowDev q = A[r0 + k];
+        q.nk = fa ? nA : nB; q.row0 = fa ? rowA0 : rowB0;
+        p->aero_part_of[kd][r0 + k] = (fa ? 0 : 1) | ((fa ? rowA0 + iA : rowB0 + iB) << 1);   // part, row inside the part
+        p->aero_part_rows[fa ? 0 : 1][kd].push_back(q);
+        (fa ? iA : iB)++;
+      }
+    }
+  }
   int64_t off = 0;
-  for (int kd = 0; kd < 3; kd++) { p->aero_off_con[kd] = off; off += (int64_t)p->aero_rows[kd].size(); }
-  for (int kd = 0; kd < 3; kd++) { p->aero_off_jac[kd] = off; off += (int64_t)p->aero_rows[kd].size() * ((kd == 1) ? 8 : 12); }
+  auto pad8 = [](int64_t v) { return (v + 7) / 8 * 8; };
+  for (int part = 0; part < 2; part++) {
+    for (int kd = 0; kd < 3; kd++) { p->aero_off_con[part][kd] = off; off = pad8(off + (int64_t)p->aero_part_rows[part][kd].size()); }
+    for (int kd = 0; kd < 3; kd++) { p->aero_off_jac[part][kd] = off; off = pad8(off + (int64_t)p->aero_part_rows[part][kd].size() * ((kd == 1) ? 8 : 12)); }
+  }
   p->aero_ld = off;
-  // rows written by the fused kernel's lanes: nodes 1 .. n of an aerodynamic phase with an "all nodes" spec of the kind
+  // node tables of the two parts (a node of part A: output place k - 1 inside its spec's n rows)
+  for (int part = 0; part < 2; part++) {
+    auto& nodes_p = p->aero_part_nodes[part];
+    nodes_p.clear();
+    for (const auto& nd0 : p->aero_nodes) {
+      gel::AeroNodeDev nd = nd0;
+      bool any = false;
+      for (int kd = 0; kd < 3; kd++) {
+        nd.row[kd] = -1;
+        if (nd0.row[kd] < 0) continue;
+        const int32_t po = p->aero_part_of[kd][nd0.row[kd]];
+        if ((po & 1) != part) continue;
+        const auto& q = p->aero_part_rows[part][kd][po >> 1];
+        nd.row[kd] = po >> 1; nd.nk[kd] = q.nk; nd.row0[kd] = q.row0;
+        nd.ko = (po >> 1) - q.row0;
+        any = true;
+      }
+      if (any) nodes_p.push_back(nd);
+    }
+  }
+  // per-phase records of part A for the fused kernel's lanes
   p->aero_ph.assign(p->ph.size(), gel::AeroPhaseDev{});
   for (size_t i = 0; i < p->ph.size(); i++) {
     gel::AeroPhaseDev& a = p->aero_ph[i];
-    a.nk8 = 8 * (p->ph[i].n + 1);
+    a.nk8 = 8 * p->ph[i].n;
     for (int kd = 0; kd < 3; kd++) { a.il[kd] = 1.0; a.ilx[kd] = 1.0; }
-    if (!p->ph[i].air) continue;
     for (int kd = 0; kd < 3; kd++) {
-      const auto& A = p->aero_rows[kd];
+      const auto& A = p->aero_part_rows[0][kd];
       const int64_t R = (int64_t)A.size();
       const int nq = (kd == 1) ? 0 : 4;
       for (size_t r0 = 0; r0 < A.size(); r0 += A[r0].nk) {
-        if (A[r0].phase != (int)i || A[r0].nk != p->ph[i].n + 1) continue;
+        if (A[r0].phase != (int)i) continue;
         const int64_t row0 = A[r0].row0;
         const int64_t bo[4] = {0, 3, 6, 6 + nq}, w[4] = {3, 3, 4, 2};
         a.kinds |= 1 << kd;
-        a.con[kd] = (int32_t)(8 * (p->aero_off_con[kd] + row0 + 1));
-        for (int blk = 0; blk < 4; blk++) a.jac[kd][blk] = (int32_t)(8 * (p->aero_off_jac[kd] + bo[blk] * R + w[blk] * row0 + 1));
+        a.con[kd] = (int32_t)(8 * (p->aero_off_con[0][kd] + row0));
+        for (int blk = 0; blk < 4; blk++) a.jac[kd][blk] = (int32_t)(8 * (p->aero_off_jac[0][kd] + bo[blk] * R + w[blk] * row0));
         a.il[kd] = 1.0 / A[r0].limit;            // the kernels' frcp(limit): the correctly rounded quotient
         a.ilx[kd] = a.il[kd] * p->dev.inv_dx;
       }
     }
   }
-  if (8 * p->aero_ld >= (int64_t)1 << 31) {   // record offsets are 32-bit byte offsets in the fused kernel
-    for (auto& a : p->aero_ph) a.kinds = 0;
-  }
-  p->aero_rest.clear();
-  for (const auto& nd : p->aero_nodes)
-    if (nd.k == 0 || p->aero_ph[nd.phase].kinds == 0) p->aero_rest.push_back(nd);
+  if (8 * p->aero_ld >= (int64_t)1 << 31) return fail(GEL_ERR_ARG, "aero record too long for 32-bit byte offsets");
   if (p->device != GEL_DEVICE_NONE) {
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamSynchronize(p->stream));
-    hipFree(p->d_aero_nodes); hipFree(p->d_aero_ph); hipFree(p->d_aero_rest);
-    p->d_aero_nodes = nullptr; p->d_aero_ph = nullptr; p->d_aero_rest = nullptr;
+    hipFree(p->d_aero_nodes); hipFree(p->d_aero_ph);
+    p->d_aero_nodes = nullptr; p->d_aero_ph = nullptr;
+    hipFree(p->d_aero_part_nodes[0]); hipFree(p->d_aero_part_nodes[1]);
+    p->d_aero_part_nodes[0] = p->d_aero_part_nodes[1] = nullptr;
     int rc = upload(&p->d_aero_nodes, p->aero_nodes);
     if (rc) return rc;
     if ((rc = upload(&p->d_aero_ph, p->aero_ph))) return rc;
-    if (!p->aero_rest.empty() && (rc = upload(&p->d_aero_rest, p->aero_rest))) return rc;
+    for (int part = 0; part < 2; part++)
+      if (!p->aero_part_nodes[part].empty() && (rc = upload(&p->d_aero_part_nodes[part], p->aero_part_nodes[part]))) return rc;
   }
   return GEL_OK;
 }
@@ -1795,47 +1842,67 @@ int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_
 int gel_aero_record_layout(const gel_problem* p, int64_t* width, int64_t* off_con, int64_t* off_jac) {
   if (!p || !width || !off_con || !off_jac) return fail(GEL_ERR_ARG, "bad argument");
   *width = p->aero_ld;
-  for (int k = 0; k < 3; k++) { off_con[k] = p->aero_off_con[k]; off_jac[k] = p->aero_off_jac[k]; }
+  for (int part = 0; part < 2; part++)
+    for (int k = 0; k < 3; k++) { off_con[3 * part + k] = p->aero_off_con[part][k]; off_jac[3 * part + k] = p->aero_off_jac[part][k]; }
+  return GEL_OK;
+}
+
+// record index of every entry of gel_eval_aero_all's arrays: var = -1 the constraint vector [nrows], var 0..3 the position /
+// velocity / quaternion / t block of the gradient values (in the order of gel_aero_pattern)
+int gel_aero_record_map(const gel_problem* p, int32_t kind, int32_t var, int64_t* idx) {
+  if (!p || kind < 0 || kind > 2 || var < -1 || var > 3 || !idx) return fail(GEL_ERR_ARG, "bad argument");
+  const auto& A = p->aero_rows[kind];
+  const int nq = (kind == 1) ? 0 : 4;
+  int64_t o = 0;
+  if (var == -1) {
+    for (size_t r = 0; r < A.size(); r++) {
+      const int32_t po = p->aero_part_of[kind][r];
+      idx[o++] = p->aero_off_con[po & 1][kind] + (po >> 1);
+    }
+    return GEL_OK;
+  }
+  if (var == 2 && kind == 1) return GEL_OK;   // dynamic pressure has no quaternion block
+  const int64_t w = (var == 2) ? 4 : ((var == 3) ? 2 : 3);
+  const int64_t bo = (var == 0) ? 0 : ((var == 1) ? 3 : ((var == 2) ? 6 : 6 + nq));
+  for (size_t r0 = 0; r0 < A.size(); r0 += A[r0].nk)
+    for (int64_t j = 0; j < w; j++)
+      for (int k = 0; k < A[r0].nk; k++) {     // the reference's emission order: spec, column, node (gel_aero_pattern)
+        const int32_t po = p->aero_part_of[kind][r0 + k];
+        const int part = po & 1;
+        const auto& q = p->aero_part_rows[part][kind][po >> 1];
+        const int64_t R = (int64_t)p->aero_part_rows[part][kind].size();
+        idx[o++] = p->aero_off_jac[part][kind] + bo * R + w * q.row0 + j * q.nk + ((po >> 1) - q.row0);
+      }
   return GEL_OK;
 }
 
 // Defect groups AND aero path constraints of a resident batch: d_res [B][11N], d_jvar [B][V] as gel_eval_batch_device writes them,
-// d_aero [B][width] one record per vector (gel_aero_record_layout).  Where the launch takes the cooperative form with one vector
-// per wavefront, the lanes of the aerodynamic phases write the aero rows of their nodes themselves (ONE run of the geodetic ->
-// atmosphere -> wind chain per node and sweep instead of two) and a small second launch adds the nodes no lane has (state node 0
-// of every phase); otherwise the two kernels run one after the other.  Same values bit for bit either way.
+// d_aero [B][width] one record per vector (gel_aero_record_layout / gel_aero_record_map).
 int gel_eval_batch_aero_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar, double* d_aero,
                                void* stream) {
   if (!p || !d_x || B < 1 || !d_res || !d_jvar || !d_aero) return fail(GEL_ERR_ARG, "bad argument");
   NEED_DEVICE(p);
   if (p->aero_nodes.empty()) return fail(GEL_ERR_ARG, "no aero path constraints configured (gel_aero_configure)");
   hipStream_t s = stream ? (hipStream_t)stream : p->stream;
-  gel::AeroLaunchOut out;
-  for (int k = 0; k < 3; k++) {
-    out.nrows[k] = (int32_t)p->aero_rows[k].size();
-    out.con[k] = out.nrows[k] ? d_aero + p->aero_off_con[k] : nullptr;
-    out.jac[k] = out.nrows[k] ? d_aero + p->aero_off_jac[k] : nullptr;
-  }
-  // Measured (MI355X, mixed-6x64, B = 65536, profiles/r06/aero_fused_*): the fused launch 5.47 ms + the node-0 launch 0.48 ms against
-  // 3.30 + 2.05 ms for the two kernels -- the aero rows' own algebra (32 gradient entries per node: cosine, alpha difference, q,
-  // scaling) is 1,480 vector instructions per wavefront on top of the fused kernel's 1,966, against aero_kernel's 1,984 with the
-  // chain: sharing the chain saves a quarter of the instructions and runs the rest at four waves per SIMD beside 60 stores per
-  // lane.  So the two kernels are the default; GEL_AERO_FUSED=1 selects the fused launch (same bits, tests/test_aero_engine.py).
-  bool fused = gel::eval_aero_fusable(p->dev, B) && std::getenv("GEL_AERO_FUSED") != nullptr && std::getenv("GEL_AERO_FUSED")[0] == '1';
-  if (fused) {
-    bool any = false;
-    for (const auto& a : p->aero_ph) any = any || a.kinds != 0;
-    fused = any;
-  }
+  gel::AeroLaunchOut out[2];
+  for (int part = 0; part < 2; part++)
+    for (int k = 0; k < 3; k++) {
+      out[part].nrows[k] = (int32_t)p->aero_part_rows[part][k].size();
+      out[part].con[k] = out[part].nrows[k] ? d_aero + p->aero_off_con[part][k] : nullptr;
+      out[part].jac[k] = out[part].nrows[k] ? d_aero + p->aero_off_jac[part][k] : nullptr;
+    }
+  // GEL_AERO_FUSED=0: the two kernels one after the other (same record, same bits)
+  const char* e = std::getenv("GEL_AERO_FUSED");
+  const bool fused = gel::eval_aero_fusable(p->dev, B) && !p->aero_part_nodes[0].empty() && !(e && e[0] == '0');
   if (fused) {
     gel::ProblemDev dv = p->dev;
     dv.aero_ph = p->d_aero_ph; dv.aero_out = d_aero; dv.aero_ld = p->aero_ld;
     HIPCHK(gel::launch_eval_aero(dv, B, d_x, d_res, d_jvar, s));
-    HIPCHK(gel::launch_aero_wide(p->dev, (int)p->aero_rest.size(), p->d_aero_rest, B, d_x, out, p->aero_ld, s));
   } else {
     HIPCHK(gel::launch_eval(p->dev, B, d_x, d_res, d_jvar, s));
-    HIPCHK(gel::launch_aero(p->dev, (int)p->aero_nodes.size(), p->d_aero_nodes, B, d_x, out, s, p->aero_ld));
+    HIPCHK(gel::launch_aero(p->dev, (int)p->aero_part_nodes[0].size(), p->d_aero_part_nodes[0], B, d_x, out[0], s, p->aero_ld));
   }
+  HIPCHK(gel::launch_aero_wide(p->dev, (int)p->aero_part_nodes[1].size(), p->d_aero_part_nodes[1], B, d_x, out[1], p->aero_ld, s));
   return GEL_OK;
 }
 

@@ -513,9 +513,9 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
         // launcher keeps to the per-vector mapping where a batch's gradients exceed 4 GB); -1 = no entry
         const unsigned vb = flat ? (unsigned)b * (unsigned)(O.ld ? (int)O.ld * 8 : O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)) * 8) : 0u;
         ipark[kind * 64] = 8 * Nd.nk[kind];
-        ipark[AP_AIDX(kind, 3) * 64] = has ? (int)(vb + 8u * (unsigned)(3 * Nd.row0[kind] + Nd.k)) : -1;
-        ipark[AP_AIDX(kind, 2) * 64] = has ? (int)(vb + 8u * (unsigned)(2 * Nd.row0[kind] + Nd.k)) : -1;
-        if (kind != 1) ipark[AP_AIDX(kind, 4) * 64] = has ? (int)(vb + 8u * (unsigned)(4 * Nd.row0[kind] + Nd.k)) : -1;
+        ipark[AP_AIDX(kind, 3) * 64] = has ? (int)(vb + 8u * (unsigned)(3 * Nd.row0[kind] + Nd.ko)) : -1;
+        ipark[AP_AIDX(kind, 2) * 64] = has ? (int)(vb + 8u * (unsigned)(2 * Nd.row0[kind] + Nd.ko)) : -1;
+        if (kind != 1) ipark[AP_AIDX(kind, 4) * 64] = has ? (int)(vb + 8u * (unsigned)(4 * Nd.row0[kind] + Nd.ko)) : -1;
       }
       if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
       const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;

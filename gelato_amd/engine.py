@@ -476,15 +476,25 @@ class Engine:
         check(lib().gel_eval_aero_all_device(self._h, B, d_x, cp, jp, stream or None))
 
     def aero_record_layout(self):
-        """-> (width, {kind: (con offset, rows)}, {kind: (jac offset, values)}): the per-vector record of eval_batch_aero_device"""
+        """-> (width, {kind: con index [nrows]}, {kind: jac index [sum nnz]}): the per-vector record of eval_batch_aero_device and
+        the gather that restores eval_aero_all's arrays from it -- con[kind] = record[..., con_idx[kind]], jac likewise (the four
+        blocks position | velocity | quaternion | t concatenated, as eval_aero_all returns them)"""
         w = C.c_int64()
-        oc, oj = (C.c_int64 * 3)(), (C.c_int64 * 3)()
+        oc, oj = (C.c_int64 * 6)(), (C.c_int64 * 6)()
         check(lib().gel_aero_record_layout(self._h, C.byref(w), oc, oj))
         con, jac = {}, {}
         for i, kind in enumerate(self.AERO_KINDS):
             nrow, nnz = self.aero_dims(kind)
-            con[kind] = (int(oc[i]), nrow)
-            jac[kind] = (int(oj[i]), sum(nnz))
+            ci = np.zeros(nrow, dtype=np.int64)
+            if nrow:
+                check(lib().gel_aero_record_map(self._h, i, -1, ci.ctypes.data_as(_lp)))
+            parts = []
+            for v in range(4):
+                ji = np.zeros(nnz[v], dtype=np.int64)
+                if nnz[v]:
+                    check(lib().gel_aero_record_map(self._h, i, v, ji.ctypes.data_as(_lp)))
+                parts.append(ji)
+            con[kind], jac[kind] = ci, np.concatenate(parts)
         return int(w.value), con, jac
 
     def eval_batch_aero_device(self, B, d_x, d_res, d_jvar, d_aero, stream=0):

@@ -264,17 +264,22 @@ int gel_eval_aero_all_device(gel_problem* p, int32_t B, const double* d_x, doubl
 /* Defect groups AND aero path constraints of a resident batch in one call [r6] -- the hot-path share of objfunc + sens with the aero
  * rows riding on it (lib/con_dynamics.py:216-496 and lib/con_aero.py:89-248,311-371 evaluate the same geodetic -> atmosphere -> wind
  * chain at the same nodes; src/pybind_dynamics.cpp:42-59 / src/wrapper_utils.hpp:89-206).  d_res [B][11 N] and d_jvar [B][V] as
- * gel_eval_batch_device writes them; d_aero [B][width]: ONE record per decision vector,
- *   [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha]      (gel_aero_record_layout: width and the six offsets),
- * each part laid out exactly like the corresponding array of gel_eval_aero_all (a kind without rows has an empty part).
- * Default: the defect kernel and the aero kernel one after the other on `stream`.  Environment GEL_AERO_FUSED=1: where the launch
- * takes the throughput form with one decision vector per wavefront, the lanes of an aerodynamic phase write the aero rows of their
- * state nodes 1 .. n themselves, from the centre evaluation and the position sweeps they run anyway, and one small launch adds the
- * rows no lane has (state node 0 of a phase, phases without aerodynamics) -- built and measured in round 6: the rows' own algebra
- * outweighs the shared chain (83-91 against 78-81 ns per vector at mixed-6x64), so it is not the default.  Every
- * value is the same bit for bit as gel_eval_batch_device's and gel_eval_aero_all_device's either way.  Asynchronous on `stream`;
- * status through gel_sync. */
-int gel_aero_record_layout(const gel_problem* p, int64_t* width, int64_t* off_con /* [3] */, int64_t* off_jac /* [3] */);
+ * gel_eval_batch_device writes them; d_aero [B][width]: ONE record per decision vector in two parts, each
+ *   [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha]
+ * laid out like gel_eval_aero_all's arrays for ITS rows: part A = state nodes 1 .. n of the aerodynamic phases' "all nodes"
+ * specs (the rows a lane of the fused kernel has: a spec's row of a column is n doubles -- whole 64-byte lines per store), part
+ * B = every other row (state node 0 of a phase, phases without aerodynamics, "initial" specs).  gel_aero_record_layout: width and
+ * the twelve section offsets (off_con / off_jac [2][3]: part, kind; every section on a multiple of eight doubles);
+ * gel_aero_record_map: the record index of every entry of gel_eval_aero_all's arrays (var = -1: the constraint vector; 0..3: the
+ * position / velocity / quaternion / t block in gel_aero_pattern's order) -- the gather a consumer applies, like gel_full_source
+ * for the compact Jacobian values.
+ * Where the launch takes the throughput form with one decision vector per wavefront (not: a handful of vectors, meshes of phases
+ * of at most 32 nodes, GEL_FLAG_FD_RECOMPUTE), the lanes of an aerodynamic phase write part A themselves, from the centre
+ * evaluation and the position sweeps they run anyway; otherwise -- and with GEL_AERO_FUSED=0 in the environment -- aero_kernel
+ * writes it in a launch of its own.  Part B is always a small second launch.  Every value is the same bit for bit as
+ * gel_eval_batch_device's and gel_eval_aero_all_device's either way.  Asynchronous on `stream`; status through gel_sync. */
+int gel_aero_record_layout(const gel_problem* p, int64_t* width, int64_t* off_con /* [2][3] */, int64_t* off_jac /* [2][3] */);
+int gel_aero_record_map(const gel_problem* p, int32_t kind, int32_t var, int64_t* idx);
 int gel_eval_batch_aero_device(gel_problem* p, int32_t B, const double* d_x, double* d_res, double* d_jvar, double* d_aero,
                                void* stream);
 

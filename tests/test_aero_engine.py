@@ -406,22 +406,27 @@ def test_defect_groups_and_aero_rows_in_one_call_equal_the_two_kernels(name, B, 
     every vector are THE BITS of gel_eval_batch_device and gel_eval_aero_all_device -- with GEL_AERO_FUSED=1 where the aero rows
     ride in the fused kernel's lanes (cooperative form, one vector per wavefront: mixed / dense / 12 x 128 at B >= 65; the rows of
     state node 0 and of phases without aerodynamics by the second launch) and where that call falls back to the two kernels (a
-    handful of vectors; example / 3 x 32: two vectors per wavefront), and in the default form (the two kernels writing the
-    per-vector records).  Nothing outside the record's parts is written, nothing inside is left unwritten."""
+    handful of vectors; example / 3 x 32: two vectors per wavefront), and with GEL_AERO_FUSED=0 (aero_kernel writing part A of
+    the per-vector records).  The record is read through gel_aero_record_map.  Nothing outside the record's sections is
+    written, nothing inside is left unwritten."""
     monkeypatch.setenv("GEL_AERO_FUSED", fused)
     E, one, two, (width, ocon, ojac) = _fused_case(name, B, specs)
     assert np.array_equal(one["res"], two["res"]) and np.array_equal(one["jvar"], two["jvar"])
     covered = np.zeros(width, dtype=bool)
     for kind in KINDS:
-        (oc, nr), (oj, nj) = ocon[kind], ojac[kind]
-        covered[oc:oc + nr] = True
-        covered[oj:oj + nj] = True
-        if nr == 0:
+        ci, ji = ocon[kind], ojac[kind]
+        assert not covered[ci].any() and not covered[ji].any() and len(np.unique(ci)) == len(ci) and len(np.unique(ji)) == len(ji)
+        covered[ci] = True
+        covered[ji] = True
+        if len(ci) == 0:
             continue
-        assert np.array_equal(one["aero"][:, oc:oc + nr], two["con"][kind]), (kind, "values")
-        d = one["aero"][:, oj:oj + nj] != two["jac"][kind]
+        assert np.array_equal(one["aero"][:, ci], two["con"][kind]), (kind, "values")
+        d = one["aero"][:, ji] != two["jac"][kind]
         assert not d.any(), (kind, "gradient values", int(d.sum()), np.argwhere(d)[:5])
-    assert covered.all() and not np.isnan(one["aero"]).any()
+    # every entry of the reference's arrays has its own place in the record; what the map does not name is padding (sections
+    # start on multiples of eight doubles) and is never written
+    assert np.isnan(one["aero"][:, ~covered]).all() and not np.isnan(one["aero"][:, covered]).any()
+    assert (~covered).sum() < 8 * 12
 
 
 @pytest.mark.gpu
@@ -471,6 +476,5 @@ def test_fused_aero_rows_take_the_recomputing_fallback_like_the_aero_kernel(monk
     con, jac, _rc = E.eval_aero_all(X)
     a = a1.cpu().numpy()
     for kind in KINDS:
-        (oc, nr_), (oj, nj) = ocon[kind], ojac[kind]
-        assert np.array_equal(a[:, oc:oc + nr_], con[kind], equal_nan=True), kind
-        assert np.array_equal(a[:, oj:oj + nj], jac[kind], equal_nan=True), kind
+        assert np.array_equal(a[:, ocon[kind]], con[kind], equal_nan=True), kind
+        assert np.array_equal(a[:, ojac[kind]], jac[kind], equal_nan=True), kind

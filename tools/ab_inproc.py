@@ -23,9 +23,15 @@ for i, lib in enumerate(libs):
     importlib.import_module(name + ".problem"); importlib.import_module(name + ".con_dynamics")
     pk.append(m)
 E = []
-for m in pk:
+for i, m in enumerate(pk):
+    # AB_ENVA / AB_ENVB = "K=V,K=V": environment switches read at handle creation, per side (the same library may be given twice)
+    for kv in filter(None, os.environ.get("AB_ENV" + "AB"[i], "").split(",")):
+        k, v = kv.split("=", 1)
+        os.environ[k] = v
     pd, ud, c, xd = m.problem.make_problem(wl)
     E.append(m.Engine(m.con_dynamics.problem_arrays(pd, ud)))
+    for kv in filter(None, os.environ.get("AB_ENV" + "AB"[i], "").split(",")):
+        os.environ.pop(kv.split("=", 1)[0], None)
 m = pk[0]
 X = np.tile(m.problem.synthetic_batch(m.pack_x(xd), E[0].M, 64), (B // 64 + 1, 1))[:B]
 dX = torch.from_numpy(X).cuda()
