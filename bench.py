@@ -803,9 +803,10 @@ def main():
                 "algorithmic_bytes_per_vector": a_bytes,
                 "frac": a_bytes * B / (min(ms_one, ms_one2) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "gel_eval_batch_aero_device: ONE fused launch (defect groups + the aero rows of the aerodynamic phases' nodes 1..n from "
-                        "the same chain) + a small launch for state node 0 of every phase, against gel_eval_batch_device followed by "
-                        "gel_eval_aero_all_device; 12 warm-up + 12 timed calls each, twice, alternating; HIP events; same values bit for bit "
-                        "(tests/test_aero_engine.py)"}
+                        "the same chain, written as whole 64-byte lines into part A of a per-vector record) + a small launch for every other "
+                        "row (state node 0 of every phase), against gel_eval_batch_device followed by gel_eval_aero_all_device (dense per-kind "
+                        "arrays); 12 warm-up + 12 timed calls each, twice, alternating; HIP events; same values bit for bit "
+                        "(tests/test_aero_engine.py); GEL_AERO_FUSED=0 in the environment: aero_kernel writes part A in a launch of its own"}
             del daero, dcon, djac
         except Exception as ex:  # noqa: BLE001
             out["defect_plus_aero"] = {"error": str(ex)[:300]}

@@ -103,9 +103,11 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #endif
 
 #ifndef GEL_AERO_STORE_AUX
-#define GEL_AERO_STORE_AUX 0  // cache policy of the fused kernel's aero-row stores.  A spec's rows are n + 1 doubles long and the lanes write nodes
-                              // 1 .. n: every 512-byte store starts 8 bytes into a 64-byte line and ends 8 bytes into another, and the
-                              // neighbouring column fills the rest later -- ordinary stores let the partial lines meet in L2
+#define GEL_AERO_STORE_AUX 2  // cache policy of the fused kernel's aero-row stores: streamed (nt) like the Jacobian values.  In part A of the
+                              // record a spec's row of a column is the phase's n nodes -- at n = 64 one store is eight whole 64-byte
+                              // lines (in gel_eval_aero_all's layout the rows are n + 1 doubles long and every store of nodes 1 .. n
+                              // began 8 bytes into a line and ended 8 bytes into another: the fused launch took 4.95 ms instead of
+                              // 4.46).  In-process A/B at mixed-6x64: nt -0.8 % against ordinary stores.
 #endif
 
 // JAC: also the FD Jacobian.  MFMA: D.X on the matrix pipe (v_mfma_f64_16x16x4_f64) instead of VALU FMAs.
