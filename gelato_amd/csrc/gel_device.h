@@ -63,22 +63,23 @@ struct AeroNodeDev {
 // Aero rows written by the FUSED kernel (gel_eval_kernel.h, AERO instantiation; gel_eval_batch_aero_device): one record per phase.
 // The lanes of an aerodynamic phase's wavefront are its state nodes 1 .. n; where the phase has an "all nodes" spec of a kind they
 // also write that kind's constraint value and gradient entries of their node, from the centre evaluation and the position /
-// velocity / quaternion sweeps they run anyway.  Outputs: ONE record of aero_ld doubles per decision vector in two parts, each
-// [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha] laid out like gel_eval_aero_all's arrays for ITS rows (jac
-// of a kind: position | velocity | quaternion | t blocks of R rows, a spec's entries [column][node]): part A = the rows the
-// lanes write (nodes 1 .. n of these phases: a spec's row of a column is n doubles, 512 bytes at n = 64, every part on a
-// 64-byte boundary -- whole lines per store), part B = every other row (state node 0 of a phase, phases without aerodynamics,
-// "initial" specs), written by aero_wide_kernel.  gel_aero_record_map gives the record index of every entry of the
-// reference's layout.  Byte offsets are relative to the vector's record and name node 1 (lane 0 of the phase's first chunk),
-// column 0.
+// velocity / quaternion sweeps they run anyway.  Outputs: ONE record of aero_ld doubles per decision vector in two parts.
+// Part A = the rows the lanes write, SPEC-MAJOR: every (kind, phase) spec is one block of 13 n doubles,
+//   [con n | position 3 n | velocity 3 n | quaternion 4 n | t 2 n]      (columns [column][node]; the dynamic pressure leaves its
+// quaternion columns unwritten), so that a lane's store address is base[kind] + ((first column of the block + column) n + node) 8
+// -- ONE scalar per kind and phase instead of a table of block offsets -- and a column's row is the phase's n nodes: whole 64-byte
+// lines at n = 64.  Part B = every other row (state node 0 of a phase, phases without aerodynamics, "initial" specs) in
+// gel_eval_aero_all's per-kind block layout, written by aero_wide_kernel.  gel_aero_record_map gives the record index of every entry
+// of the reference's layout.
 struct AeroPhaseDev {
   int32_t kinds;       // bit k: nodes 1 .. n of this phase have a row of kind k AND the phase runs the aerodynamic chain
-  int32_t nk8;         // 8 n: bytes between two columns of a spec's gradient block in part A
-  int32_t con[3];      // kind k: the constraint value
-  int32_t jac[3][4];   // kind k, block (0 position, 1 velocity, 2 quaternion, 3 t): the gradient entry
+  int32_t base[3];     // kind k: BYTE offset of the spec's block inside the vector's record; a kind the phase does not have: the record's
+                       // dump area (13 n doubles nobody reads), with il = ilx = 0 -- the lanes store unconditionally
   double il[3];        // 1 / limit (limit = units[3] of con_aero.py), divided on the host (the same IEEE quotient the kernels' frcp forms)
   double ilx[3];       // (1 / limit) * (1 / dx): what every gradient entry of the kind is scaled by
 };
+// first column (in units of n doubles) of a block inside a spec-major block: con 0, position 1, velocity 4, quaternion 7, t 11
+constexpr int kAeroSpecCols = 13;
 
 // knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py): see gel_kernels.hip rows_kernel
 struct LinRowDev { int32_t idx0, idx1; double coef0, coef1, c0; };  // (coef0 x[idx0] + coef1 x[idx1]) + c0; idx1 < 0: one term

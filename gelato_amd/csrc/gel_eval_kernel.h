@@ -1174,6 +1174,15 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
       // One gradient entry of every kind of this phase, -(f_p - f_c) / dx / limit (lib/con_aero.py:437-463), from the perturbed
       // point's air-relative velocity a_ (squared norm nv2_), body axis d_ (1 / |d| = ind_) and density: aero_body's GEL_AERO_EMIT
       // (gel_kernels.hip), expression for expression.  blk: 0 position, 1 velocity, 2 quaternion; okl_: this lane writes.
+      // A kind this phase does not have (akinds) is not branched around: its block base points at the record's dump area and its
+      // scale factors are zero (gel_host.hip) -- three scalar tests and branches less per entry, nothing written where it counts.
+      // the phase's aero record, fetched ONCE per group of entries (scalar loads, one round trip -- fetched where each store needs
+      // them they were 35 round trips per wavefront, each waited for on the spot): block bases, scale factors; n8_ = bytes of a
+      // column's row, j08_ = this chunk's first node in it
+#define GEL_AERO_FETCH()                                                                                               \
+  const int ab_[3] = {load_const(&aph->base[0]), load_const(&aph->base[1]), load_const(&aph->base[2])};                \
+  const double ax_[3] = {load_const(&aph->ilx[0]), load_const(&aph->ilx[1]), load_const(&aph->ilx[2])};                \
+  const int n8_ = 8 * n, j08_ = 8 * j0
 #define GEL_AERO_ENTRY(blk, col, a_, nv2_, d_, ind_, rho_, okl_, a_cc, a_ac, a_qc, a_isc, a_ok)                         \
   do {                                                                                                                 \
     double t_ = 0.0, dq_ = 0.0, qp_ = 0.0;                                                                             \
@@ -1193,10 +1202,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     }                                                                                                                  \
     _Pragma("unroll") for (int kind = 0; kind < 3; kind++) {                                                           \
       if ((blk) == 2 && kind == 1) continue;               /* dynamic pressure has no quaternion block */              \
-      if (!((akinds >> kind) & 1)) continue;               /* wave-uniform */                                          \
       const double df_ = (kind == 0) ? t_ : ((kind == 1) ? dq_ : qp_ * t_ + dq_ * ac_);                                \
-      const double gv = -(df_ * load_const(&aph->ilx[kind]));                                                          \
-      if (okl_) AEMIT(load_const(&aph->jac[kind][(blk)]) + (col) * load_const(&aph->nk8) + 8 * j0, gv);               \
+      const double gv = -(df_ * ax_[kind]);                                                                            \
+      if (okl_) AEMIT(ab_[kind] + (((blk) == 0 ? 1 : ((blk) == 1 ? 4 : 7)) + (col)) * n8_ + j08_, gv);                 \
     }                                                                                                                  \
   } while (0)
 #if GEL_CA_CACHE
@@ -1361,15 +1369,16 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
           double sc, isc;
           fsqrt_rsqrt(fmax((1.0 - cc) * (1.0 + cc), 1.0e-300), sc, isc);  // sin(alpha_c) and its reciprocal
           const bool centre_ok = (cc <= 1.0) && (nv2 >= 1.0e-12) && (sc > 1.0e-6);
+          GEL_AERO_FETCH();
+          const double ail_[3] = {load_const(&aph->il[0]), load_const(&aph->il[1]), load_const(&aph->il[2])};
 #pragma unroll
           for (int kind = 0; kind < 3; kind++) {
-            if (!((akinds >> kind) & 1)) continue;   // wave-uniform
-            const double il = load_const(&aph->il[kind]);
+            const double il = ail_[kind];
             const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
-            AEMIT(load_const(&aph->con[kind]) + 8 * j0, cv);
+            AEMIT(ab_[kind] + j08_, cv);
             GEL_CHK(cv);
 #pragma unroll
-            for (int c = 0; c < 2; c++) AEMIT(load_const(&aph->jac[kind][3]) + c * load_const(&aph->nk8) + 8 * j0, 0.0);
+            for (int c = 0; c < 2; c++) AEMIT(ab_[kind] + (11 + c) * n8_ + j08_, 0.0);
           }
           if (a_need_alpha && !GEL_X_NOQUAT) {
             const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};
@@ -1441,6 +1450,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     double sc_, isc_;                                                                                         \
     fsqrt_rsqrt(fmax((1.0 - cc_) * (1.0 + cc_), 1.0e-300), sc_, isc_);                                        \
     const double acs_ = PARK_GET(PK_AAC);   /* alpha_c, negated where the difference form does not apply at the centre */ \
+    GEL_AERO_FETCH();                                                                                         \
     GEL_AERO_ENTRY(0, kk, a_, nv2_, dd_, ind_, (pq).rho, okl_, cc_, fabs(acs_), PARK_GET(PK_AQC), isc_, !__builtin_signbit(acs_)); \
   } while (0)
         // PosCentre and the centre's position part as far as pos_delta() reads them, from the park
@@ -1524,6 +1534,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #undef GEL_NEED_EARTH_ANGLE
 #undef GEL_AERO_NEED_EA
 #undef GEL_AERO_ENTRY
+#undef GEL_AERO_FETCH
 #undef GEL_POS_SWEEP_F
 #undef GEL_POS_SWEEP_EMIT
       }

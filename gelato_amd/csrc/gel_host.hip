@@ -157,6 +157,9 @@ struct gel_problem {
   int64_t aero_ld = 0, aero_off_con[2][3] = {{0, 0, 0}, {0, 0, 0}}, aero_off_jac[2][3] = {{0, 0, 0}, {0, 0, 0}};
   std::vector<gel::AeroRowDev> aero_part_rows[2][3];          // the rows of part A (the lanes') and part B (the rest), per kind
   std::vector<int32_t> aero_part_of[3];                       // per row of a kind: part | (row inside the part) << 1
+  std::vector<int64_t> aero_partA_base[3];                    // per row of part A: first double of its spec's block in the record
+  int64_t aero_partA_len = 0;                                 // doubles of part A (part B's sections follow)
+  int64_t aero_dump = 0;                                      // first double of the dump area at the end of part A
   std::vector<gel::AeroNodeDev> aero_part_nodes[2];
   std::vector<gel::AeroPhaseDev> aero_ph;
   gel::AeroPhaseDev* d_aero_ph = nullptr;
@@ -1775,12 +1778,29 @@ int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_
   }
   int64_t off = 0;
   auto pad8 = [](int64_t v) { return (v + 7) / 8 * 8; };
-  for (int part = 0; part < 2; part++) {
-    for (int kd = 0; kd < 3; kd++) { p->aero_off_con[part][kd] = off; off = pad8(off + (int64_t)p->aero_part_rows[part][kd].size()); }
-    for (int kd = 0; kd < 3; kd++) { p->aero_off_jac[part][kd] = off; off = pad8(off + (int64_t)p->aero_part_rows[part][kd].size() * ((kd == 1) ? 8 : 12)); }
+  // part A, spec-major (gel_device.h AeroPhaseDev): one block of 13 n doubles per (kind, phase) spec
+  for (int kd = 0; kd < 3; kd++) {
+    const auto& A = p->aero_part_rows[0][kd];
+    p->aero_partA_base[kd].assign(A.size(), 0);
+    for (size_t r0 = 0; r0 < A.size(); r0 += A[r0].nk) {
+      for (int k = 0; k < A[r0].nk; k++) p->aero_partA_base[kd][r0 + k] = off;
+      off = pad8(off + (int64_t)gel::kAeroSpecCols * A[r0].nk);
+    }
   }
+  {   // the dump area: where the lanes' stores of a kind their phase does not have go (AeroPhaseDev::base)
+    int nmax = 0;
+    for (const auto& h : p->ph) nmax = std::max(nmax, h.n);
+    p->aero_dump = off;
+    off = pad8(off + (int64_t)gel::kAeroSpecCols * nmax);
+  }
+  p->aero_partA_len = off;
+  // part B: gel_eval_aero_all's layout for its rows
+  for (int kd = 0; kd < 3; kd++) { p->aero_off_con[1][kd] = off; off = pad8(off + (int64_t)p->aero_part_rows[1][kd].size()); }
+  for (int kd = 0; kd < 3; kd++) { p->aero_off_jac[1][kd] = off; off = pad8(off + (int64_t)p->aero_part_rows[1][kd].size() * ((kd == 1) ? 8 : 12)); }
+  for (int kd = 0; kd < 3; kd++) { p->aero_off_con[0][kd] = 0; p->aero_off_jac[0][kd] = 0; }
   p->aero_ld = off;
-  // node tables of the two parts (a node of part A: output place k - 1 inside its spec's n rows)
+  // node tables of the two parts.  Part A: row0 = first double of the spec's block in the record, row = the constraint value's place
+  // (block + node), ko = the node's place in a column's row; part B: the ordinary tables of its own rows
   for (int part = 0; part < 2; part++) {
     auto& nodes_p = p->aero_part_nodes[part];
     nodes_p.clear();
@@ -1793,8 +1813,14 @@ int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_
         const int32_t po = p->aero_part_of[kd][nd0.row[kd]];
         if ((po & 1) != part) continue;
         const auto& q = p->aero_part_rows[part][kd][po >> 1];
-        nd.row[kd] = po >> 1; nd.nk[kd] = q.nk; nd.row0[kd] = q.row0;
         nd.ko = (po >> 1) - q.row0;
+        nd.nk[kd] = q.nk;
+        if (part == 0) {
+          nd.row0[kd] = (int32_t)p->aero_partA_base[kd][po >> 1];
+          nd.row[kd] = nd.row0[kd] + nd.ko;
+        } else {
+          nd.row[kd] = po >> 1; nd.row0[kd] = q.row0;
+        }
         any = true;
       }
       if (any) nodes_p.push_back(nd);
@@ -1804,19 +1830,13 @@ int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_
   p->aero_ph.assign(p->ph.size(), gel::AeroPhaseDev{});
   for (size_t i = 0; i < p->ph.size(); i++) {
     gel::AeroPhaseDev& a = p->aero_ph[i];
-    a.nk8 = 8 * p->ph[i].n;
-    for (int kd = 0; kd < 3; kd++) { a.il[kd] = 1.0; a.ilx[kd] = 1.0; }
+    for (int kd = 0; kd < 3; kd++) { a.il[kd] = 0.0; a.ilx[kd] = 0.0; a.base[kd] = (int32_t)(8 * p->aero_dump); }
     for (int kd = 0; kd < 3; kd++) {
       const auto& A = p->aero_part_rows[0][kd];
-      const int64_t R = (int64_t)A.size();
-      const int nq = (kd == 1) ? 0 : 4;
       for (size_t r0 = 0; r0 < A.size(); r0 += A[r0].nk) {
         if (A[r0].phase != (int)i) continue;
-        const int64_t row0 = A[r0].row0;
-        const int64_t bo[4] = {0, 3, 6, 6 + nq}, w[4] = {3, 3, 4, 2};
         a.kinds |= 1 << kd;
-        a.con[kd] = (int32_t)(8 * (p->aero_off_con[0][kd] + row0));
-        for (int blk = 0; blk < 4; blk++) a.jac[kd][blk] = (int32_t)(8 * (p->aero_off_jac[0][kd] + bo[blk] * R + w[blk] * row0));
+        a.base[kd] = (int32_t)(8 * p->aero_partA_base[kd][r0]);
         a.il[kd] = 1.0 / A[r0].limit;            // the kernels' frcp(limit): the correctly rounded quotient
         a.ilx[kd] = a.il[kd] * p->dev.inv_dx;
       }
@@ -1857,7 +1877,8 @@ int gel_aero_record_map(const gel_problem* p, int32_t kind, int32_t var, int64_t
   if (var == -1) {
     for (size_t r = 0; r < A.size(); r++) {
       const int32_t po = p->aero_part_of[kind][r];
-      idx[o++] = p->aero_off_con[po & 1][kind] + (po >> 1);
+      if (po & 1) idx[o++] = p->aero_off_con[1][kind] + (po >> 1);
+      else idx[o++] = p->aero_partA_base[kind][po >> 1] + ((po >> 1) - p->aero_part_rows[0][kind][po >> 1].row0);
     }
     return GEL_OK;
   }
@@ -1871,7 +1892,9 @@ int gel_aero_record_map(const gel_problem* p, int32_t kind, int32_t var, int64_t
         const int part = po & 1;
         const auto& q = p->aero_part_rows[part][kind][po >> 1];
         const int64_t R = (int64_t)p->aero_part_rows[part][kind].size();
-        idx[o++] = p->aero_off_jac[part][kind] + bo * R + w * q.row0 + j * q.nk + ((po >> 1) - q.row0);
+        const int64_t ko = (po >> 1) - q.row0;
+        if (part == 1) idx[o++] = p->aero_off_jac[1][kind] + bo * R + w * q.row0 + j * q.nk + ko;
+        else idx[o++] = p->aero_partA_base[kind][po >> 1] + (((var == 0) ? 1 : ((var == 1) ? 4 : ((var == 2) ? 7 : 11))) + j) * q.nk + ko;
       }
   return GEL_OK;
 }
@@ -1886,7 +1909,7 @@ int gel_eval_batch_aero_device(gel_problem* p, int32_t B, const double* d_x, dou
   hipStream_t s = stream ? (hipStream_t)stream : p->stream;
   gel::AeroLaunchOut out[2];
   for (int part = 0; part < 2; part++)
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 3; k++) {   // part A (spec-major): every pointer is the record itself
       out[part].nrows[k] = (int32_t)p->aero_part_rows[part][k].size();
       out[part].con[k] = out[part].nrows[k] ? d_aero + p->aero_off_con[part][k] : nullptr;
       out[part].jac[k] = out[part].nrows[k] ? d_aero + p->aero_off_jac[part][k] : nullptr;
@@ -1900,7 +1923,7 @@ int gel_eval_batch_aero_device(gel_problem* p, int32_t B, const double* d_x, dou
     HIPCHK(gel::launch_eval_aero(dv, B, d_x, d_res, d_jvar, s));
   } else {
     HIPCHK(gel::launch_eval(p->dev, B, d_x, d_res, d_jvar, s));
-    HIPCHK(gel::launch_aero(p->dev, (int)p->aero_part_nodes[0].size(), p->d_aero_part_nodes[0], B, d_x, out[0], s, p->aero_ld));
+    HIPCHK(gel::launch_aero(p->dev, (int)p->aero_part_nodes[0].size(), p->d_aero_part_nodes[0], B, d_x, out[0], s, p->aero_ld, true));
   }
   HIPCHK(gel::launch_aero_wide(p->dev, (int)p->aero_part_nodes[1].size(), p->d_aero_part_nodes[1], B, d_x, out[1], p->aero_ld, s));
   return GEL_OK;

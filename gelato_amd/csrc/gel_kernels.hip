@@ -362,6 +362,8 @@ struct AeroOut {
   int32_t nrows[3];
   int64_t ld;       // != 0: the outputs are per-vector RECORDS of ld doubles (gel_eval_batch_aero_device): con / jac point at the
                     // kind's part of record 0, a vector's part lies b * ld doubles on; 0: dense [B][...] arrays per kind
+  int32_t sm;       // != 0 (records only): SPEC-MAJOR part A (gel_device.h AeroPhaseDev) -- a node's row0[kind] is the first double of
+                    // its spec's block in the record, row[kind] its constraint value's place; con / jac all point at the record
 };
 
 // One WAVEFRONT = 64 consecutive constrained nodes of one decision vector, every sweep of the node in the same lane (round 2 ran
@@ -513,9 +515,9 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
         // launcher keeps to the per-vector mapping where a batch's gradients exceed 4 GB); -1 = no entry
         const unsigned vb = flat ? (unsigned)b * (unsigned)(O.ld ? (int)O.ld * 8 : O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)) * 8) : 0u;
         ipark[kind * 64] = 8 * Nd.nk[kind];
-        ipark[AP_AIDX(kind, 3) * 64] = has ? (int)(vb + 8u * (unsigned)(3 * Nd.row0[kind] + Nd.ko)) : -1;
-        ipark[AP_AIDX(kind, 2) * 64] = has ? (int)(vb + 8u * (unsigned)(2 * Nd.row0[kind] + Nd.ko)) : -1;
-        if (kind != 1) ipark[AP_AIDX(kind, 4) * 64] = has ? (int)(vb + 8u * (unsigned)(4 * Nd.row0[kind] + Nd.ko)) : -1;
+        ipark[AP_AIDX(kind, 3) * 64] = has ? (int)(vb + 8u * (unsigned)((O.sm ? 1 : 3) * Nd.row0[kind] + Nd.ko)) : -1;
+        ipark[AP_AIDX(kind, 2) * 64] = has ? (int)(vb + 8u * (unsigned)((O.sm ? 1 : 2) * Nd.row0[kind] + Nd.ko)) : -1;
+        if (kind != 1) ipark[AP_AIDX(kind, 4) * 64] = has ? (int)(vb + 8u * (unsigned)((O.sm ? 1 : 4) * Nd.row0[kind] + Nd.ko)) : -1;
       }
       if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
       const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
@@ -565,6 +567,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       gel_au2 gd_;                                                                                                \
       __builtin_memcpy(&gd_, &gv, 8);                                                                             \
       if (WIDE) O.jac[kind][(size_t)b * O.ld + (size_t)bo * O.nrows[kind] + ((a8_ + (col) * ipark[kind * 64]) >> 3)] = gv;                     \
+      else if (O.sm) __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], a8_ + ((((boff) < 0) ? 11 : ((boff) == 0 ? 1 : ((boff) == 3 ? 4 : 7))) + (col)) * ipark[kind * 64], 0, 0); \
       else __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], ((col) == 0) ? a8_ : a8_ + (col) * ipark[kind * 64], 8 * bo * O.nrows[kind], ROLES ? 2 : 0); /* ROLES = the one-vector callback: streamed to pinned host memory */ \
       chk += gv;                                                                                                  \
     }                                                                                                             \
@@ -708,7 +711,7 @@ hipError_t launch_aero_wide(const ProblemDev& P, int nnodes, const AeroNodeDev* 
   if (B <= 0 || nnodes <= 0) return hipSuccess;
   AeroOut O;
   for (int k = 0; k < 3; k++) { O.con[k] = out.con[k]; O.jac[k] = out.jac[k]; O.nrows[k] = out.nrows[k]; }
-  O.ld = ld;
+  O.ld = ld; O.sm = 0;
   const size_t lds = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + (size_t)kAeroWaves * kAeroParkSlots * 64);
   const long long waves = ((long long)B * nnodes + 63) / 64;
   hipLaunchKernelGGL(aero_wide_kernel, dim3((unsigned)((waves + kAeroWaves - 1) / kAeroWaves)), dim3(64 * kAeroWaves), lds, s, P, nnodes, nodes, B, d_x, O);
@@ -718,7 +721,7 @@ hipError_t launch_aero_wide(const ProblemDev& P, int nnodes, const AeroNodeDev* 
 // ld != 0: per-vector records (see AeroOut).  The flat mapping addresses a batch's gradient values with 32-bit byte offsets: a
 // batch whose records span more is launched in runs of vectors that do not.
 hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
-                       const AeroLaunchOut& out, hipStream_t s, long long ld) {
+                       const AeroLaunchOut& out, hipStream_t s, long long ld, bool spec_major) {
   if (B <= 0 || nnodes <= 0) return hipSuccess;
   if (ld > 0 && B > 1 && nnodes >= 64 && (nnodes & 63) != 0) {
     const long long run = ((1LL << 32) - (1LL << 25)) / (ld * 8);
@@ -726,7 +729,7 @@ hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes
       for (long long b0 = 0; b0 < B; b0 += run) {
         AeroLaunchOut o = out;
         for (int k = 0; k < 3; k++) { if (o.con[k]) o.con[k] += b0 * ld; if (o.jac[k]) o.jac[k] += b0 * ld; }
-        const hipError_t e = launch_aero(P, nnodes, nodes, (int)std::min<long long>(run, B - b0), d_x + b0 * P.nvars, o, s, ld);
+        const hipError_t e = launch_aero(P, nnodes, nodes, (int)std::min<long long>(run, B - b0), d_x + b0 * P.nvars, o, s, ld, spec_major);
         if (e != hipSuccess) return e;
       }
       return hipSuccess;
@@ -734,7 +737,7 @@ hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes
   }
   AeroOut O;
   for (int k = 0; k < 3; k++) { O.con[k] = out.con[k]; O.jac[k] = out.jac[k]; O.nrows[k] = out.nrows[k]; }
-  O.ld = ld;
+  O.ld = ld; O.sm = (ld > 0 && spec_major) ? 1 : 0;
   int tiles = (nnodes + 63) / 64;
   const size_t lds = sizeof(double) * (((staged_table_doubles(P.Kw, P.Kc) + 1) & ~(size_t)1) + (size_t)kAeroWaves * kAeroParkSlots * 64);
   long long waves = (long long)B * tiles;
@@ -992,7 +995,7 @@ hipError_t launch_callback(const ProblemDev& P0, bool want_jac, const double* d_
   A.nb_eval = (P.nunits + 3) / 4;                  // four wavefronts = four units per workgroup
   if (aero && nnodes > 0) {
     for (int k = 0; k < 3; k++) { A.O.con[k] = aero->con[k]; A.O.jac[k] = aero->jac[k]; A.O.nrows[k] = aero->nrows[k]; }
-    A.O.ld = 0;
+    A.O.ld = 0; A.O.sm = 0;
     A.nnodes = nnodes; A.nodes = nodes; A.tiles = (nnodes + 63) / 64; A.nb_aero = A.tiles;   // ROLES form: one workgroup per tile
   }
   int rows_blocks = 0;

@@ -40,7 +40,7 @@ hipError_t launch_point(int kind, int n, const double* in, const double* aux, in
 // outputs of one aero launch: per kind (0 alpha, 1 q, 2 q-alpha) the constraint vector and the COO values, or null
 struct AeroLaunchOut { double* con[3]; double* jac[3]; int32_t nrows[3]; };
 hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
-                       const AeroLaunchOut& out, hipStream_t s, long long ld = 0);
+                       const AeroLaunchOut& out, hipStream_t s, long long ld = 0, bool spec_major = false);
 
 hipError_t launch_aero_wide(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes, int B, const double* d_x,
                             const AeroLaunchOut& out, long long ld, hipStream_t s);

@@ -425,8 +425,13 @@ def test_defect_groups_and_aero_rows_in_one_call_equal_the_two_kernels(name, B, 
         assert not d.any(), (kind, "gradient values", int(d.sum()), np.argwhere(d)[:5])
     # every entry of the reference's arrays has its own place in the record; what the map does not name is padding (sections
     # start on multiples of eight doubles) and is never written
-    assert np.isnan(one["aero"][:, ~covered]).all() and not np.isnan(one["aero"][:, covered]).any()
-    assert (~covered).sum() < 8 * 12
+    # (unnamed cells: the padding of sections to multiples of eight doubles, and the quaternion columns the dynamic pressure does
+    # not have inside its spec-major blocks of part A)
+    # (and, with the fused launch, the dump area: a lane whose phase lacks a kind stores that kind's zeros there instead of
+    # branching around the store)
+    assert not np.isnan(one["aero"][:, covered]).any()
+    unnamed = one["aero"][:, ~covered]
+    assert np.all(np.isnan(unnamed) | (unnamed == 0.0) | (unnamed == 1.0))
 
 
 @pytest.mark.gpu

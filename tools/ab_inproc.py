@@ -54,7 +54,7 @@ if fused:
     for e in E:
         for kind, lim in (("alpha", 0.2), ("q", 4.0e4), ("qalpha", 5.0e3)):
             e.aero_configure(kind, [(i, 1, lim) for i in range(S - 1)])
-    da = torch.empty((B, E[0].aero_record_layout()[0]), dtype=torch.float64, device="cuda")
+    da = torch.empty((B, max(e.aero_record_layout()[0] for e in E)), dtype=torch.float64, device="cuda")   # the builds' records may differ in width
 def burst(e, n):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
