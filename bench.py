@@ -431,7 +431,7 @@ def main():
     from gelato_amd import _lib
     build = _lib.build_info()
 
-    def static_counters(kind, tag=None, batch=None):
+    def static_counters(kind, tag=None, batch=None, engine=None, jac=None):
         """profiles/<kind>_<workload>_B<batch>.json (separate rocprofv3 --pmc passes of this command, tools/gpu_record.sh) --
         only if it was recorded with THE library that is loaded now (build_so_sha256); -> (dict or None, why not)"""
         path = os.path.join(ROOT, "profiles", "%s_%s_B%d.json" % (kind, tag or wl_tag, batch or B))
@@ -445,6 +445,14 @@ def main():
         if d.get("build_so_sha256") != build["so_sha256"] and not same_device_code:      # counters describe the DEVICE code
             return None, ("profiles/%s describes another build (so_sha256 %s..., git %s; loaded: %s...): not reported"
                           % (os.path.basename(path), str(d.get("build_so_sha256"))[:12], str(d.get("build_git_head"))[:10], build["so_sha256"][:12]))
+        # the launch policy the counters were taken under (instantiation, wavefront count, work items) must be the one this library
+        # picks now: the same device code launched differently moves different bytes
+        pol = d.get("launch_policy")
+        if isinstance(pol, dict) and "launch_info" in pol:
+            eng = engine or E
+            now = {"launch_info": eng.launch_info(batch or B, True, (not a.residual_only) if jac is None else jac), "num_chunks": eng.num_chunks()}
+            if pol != now:
+                return None, "profiles/%s was recorded under another launch policy (%r, now %r): not reported" % (os.path.basename(path), pol, now)
         d["_file"] = os.path.basename(path)
         return d, None
 
@@ -871,7 +879,7 @@ def main():
                 st_l = El.sync(stream)
                 amin_l = 8 * (El.nvars + El.nres) if resonly else El.algorithmic_bytes
                 tag_l = wl + ("_resonly" if resonly else "") + ("_flags%d" % fl if fl else "")
-                td_l, _why = static_counters("traffic", tag_l, Bl)
+                td_l, _why = static_counters("traffic", tag_l, Bl, engine=El, jac=not resonly)
                 moved = None if td_l is None else td_l.get("hbm_bytes_per_launch")
                 inf_l = El.launch_info(Bl, True, not resonly)
                 oc[key] = {"workload": wl + (" (residual only)" if resonly else ""), "engine_flags": fl, "batch": Bl,

@@ -5,6 +5,18 @@ and the time the fp64 datapath was occupied (vector fp64 and matrix fp64 share i
 per SIMD, against GRBM_GUI_ACTIVE / 8 cycles).  Usage: pmc_fp64.py <dir> [bench args]"""
 import csv, glob, json, os, sys
 
+
+def launch_policy(workload, batch, resonly):
+    """what the HOST side decided for this launch (instantiation, wavefronts, LDS order, store policy: gel_launch_info + the
+    environment switches that change it) -- recorded with the counters, so that bench.py does not report them for a library whose
+    device code is the same but whose launch policy is not"""
+    from gelato_amd import Engine, con_dynamics, problem
+    pd, ud, _c, _x = problem.make_problem(workload)
+    E = Engine(con_dynamics.problem_arrays(pd, ud))
+    return {"launch_info": E.launch_info(batch, True, not resonly), "num_chunks": E.num_chunks()}
+
+
+
 root = sys.argv[1]
 args = sys.argv[2:]
 
@@ -57,4 +69,8 @@ out["source"] = ("tools/gpu_record.sh -> rocprofv3 --kernel-trace --pmc, two pas
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from gelato_amd import _lib  # noqa: E402  (provenance only: which build these counters describe)
 out.update({"build_" + k: v for k, v in _lib.build_info().items()})
+try:
+    out["launch_policy"] = launch_policy(out["workload"].replace("_resonly", ""), out["batch"], out["workload"].endswith("_resonly"))
+except Exception as ex:  # noqa: BLE001
+    out["launch_policy"] = {"error": str(ex)[:200]}
 print(json.dumps(out, indent=1))
