@@ -400,7 +400,9 @@ typedef __attribute__((address_space(3))) double lds_f64;
 // whose outputs are the per-vector records of gel_eval_batch_aero_device): any number of vectors per wavefront (entry f of the
 // (vector, node) sequence -> vector f / nnodes), outputs at 64-bit addresses b * ld + ... by plain global stores.  Same
 // expressions per entry, same bits.
-template <bool ROLES, bool WIDE = false>
+// SM (records only): SPEC-MAJOR part A (AeroOut::sm) -- an instantiation of its own, so that the ordinary launches carry neither
+// its selects nor a third form of every store (as a run-time switch it cost aero_kernel 8 %)
+template <bool ROLES, bool WIDE = false, bool SM = false>
 __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes, int tiles, int B,
                                           const double* __restrict__ x, const AeroOut O, const unsigned vblk) {
   extern __shared__ double lds[];
@@ -515,9 +517,9 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
         // launcher keeps to the per-vector mapping where a batch's gradients exceed 4 GB); -1 = no entry
         const unsigned vb = flat ? (unsigned)b * (unsigned)(O.ld ? (int)O.ld * 8 : O.nrows[kind] * (8 + ((kind == 1) ? 0 : 4)) * 8) : 0u;
         ipark[kind * 64] = 8 * Nd.nk[kind];
-        ipark[AP_AIDX(kind, 3) * 64] = has ? (int)(vb + 8u * (unsigned)((O.sm ? 1 : 3) * Nd.row0[kind] + Nd.ko)) : -1;
-        ipark[AP_AIDX(kind, 2) * 64] = has ? (int)(vb + 8u * (unsigned)((O.sm ? 1 : 2) * Nd.row0[kind] + Nd.ko)) : -1;
-        if (kind != 1) ipark[AP_AIDX(kind, 4) * 64] = has ? (int)(vb + 8u * (unsigned)((O.sm ? 1 : 4) * Nd.row0[kind] + Nd.ko)) : -1;
+        ipark[AP_AIDX(kind, 3) * 64] = has ? (int)(vb + 8u * (unsigned)((SM ? 1 : 3) * Nd.row0[kind] + Nd.ko)) : -1;
+        ipark[AP_AIDX(kind, 2) * 64] = has ? (int)(vb + 8u * (unsigned)((SM ? 1 : 2) * Nd.row0[kind] + Nd.ko)) : -1;
+        if (kind != 1) ipark[AP_AIDX(kind, 4) * 64] = has ? (int)(vb + 8u * (unsigned)((SM ? 1 : 4) * Nd.row0[kind] + Nd.ko)) : -1;
       }
       if (!live || row < 0 || !O.con[kind] || (ROLES && sw != 0)) continue;
       const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
@@ -567,7 +569,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       gel_au2 gd_;                                                                                                \
       __builtin_memcpy(&gd_, &gv, 8);                                                                             \
       if (WIDE) O.jac[kind][(size_t)b * O.ld + (size_t)bo * O.nrows[kind] + ((a8_ + (col) * ipark[kind * 64]) >> 3)] = gv;                     \
-      else if (O.sm) __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], a8_ + ((((boff) < 0) ? 11 : ((boff) == 0 ? 1 : ((boff) == 3 ? 4 : 7))) + (col)) * ipark[kind * 64], 0, 0); \
+      else if (SM) __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], a8_ + ((((boff) < 0) ? 11 : ((boff) == 0 ? 1 : ((boff) == 3 ? 4 : 7))) + (col)) * ipark[kind * 64], 0, 0); \
       else __builtin_amdgcn_raw_buffer_store_b64(gd_, jrs[kind], ((col) == 0) ? a8_ : a8_ + (col) * ipark[kind * 64], 8 * bo * O.nrows[kind], ROLES ? 2 : 0); /* ROLES = the one-vector callback: streamed to pinned host memory */ \
       chk += gv;                                                                                                  \
     }                                                                                                             \
@@ -700,6 +702,10 @@ __global__ __launch_bounds__(64 * kAeroWaves, GEL_AERO_MIN_WAVES) void aero_kern
                                                                 int tiles, int B, const double* __restrict__ x, AeroOut O) {
   aero_body<false>(P, nnodes, nodes, tiles, B, x, O, blockIdx.x);
 }
+__global__ __launch_bounds__(64 * kAeroWaves, GEL_AERO_MIN_WAVES) void aero_sm_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
+                                                                   int tiles, int B, const double* __restrict__ x, AeroOut O) {
+  aero_body<false, false, true>(P, nnodes, nodes, tiles, B, x, O, blockIdx.x);
+}
 __global__ __launch_bounds__(64 * kAeroWaves, 2) void aero_wide_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
                                                                 int B, const double* __restrict__ x, AeroOut O) {
   aero_body<false, true>(P, nnodes, nodes, 0, B, x, O, blockIdx.x);
@@ -750,7 +756,8 @@ hipError_t launch_aero(const ProblemDev& P, int nnodes, const AeroNodeDev* nodes
     tiles = 0;
   }
   const unsigned grid = (unsigned)((waves + kAeroWaves - 1) / kAeroWaves);
-  hipLaunchKernelGGL(aero_kernel, dim3(grid), dim3(64 * kAeroWaves), lds, s, P, nnodes, nodes, tiles, B, d_x, O);
+  if (O.sm) hipLaunchKernelGGL(aero_sm_kernel, dim3(grid), dim3(64 * kAeroWaves), lds, s, P, nnodes, nodes, tiles, B, d_x, O);
+  else hipLaunchKernelGGL(aero_kernel, dim3(grid), dim3(64 * kAeroWaves), lds, s, P, nnodes, nodes, tiles, B, d_x, O);
   return hipGetLastError();
 }
 
