@@ -483,3 +483,46 @@ def test_fused_aero_rows_take_the_recomputing_fallback_like_the_aero_kernel(monk
     for kind in KINDS:
         assert np.array_equal(a[:, ocon[kind]], con[kind], equal_nan=True), kind
         assert np.array_equal(a[:, ojac[kind]], jac[kind], equal_nan=True), kind
+
+
+@pytest.mark.parametrize("name", ["mixed-6x64", "stress-12x128", "example"])
+def test_aero_record_map_host_only(name):
+    """gel_aero_record_layout / gel_aero_record_map on a host-only handle (no GPU): every entry of gel_eval_aero_all's arrays has its
+    own cell of the per-vector record; the cells of part A -- the rows a lane of the fused kernel has -- form spec-major blocks of
+    13 n doubles whose columns are runs of the phase's n nodes starting on multiples of eight doubles (whole 64-byte lines at
+    n = 64), in the order [con | position 3 | velocity 3 | quaternion 4 | t 2]; state node 0 of every spec lies in part B."""
+    from gelato_amd import Engine, con_dynamics, problem
+    pdict, unitdict, _c, _x = problem.make_problem(name)
+    E = Engine(con_dynamics.problem_arrays(pdict, unitdict), device=-1)
+    S = pdict["num_sections"]
+    air = [pdict["params"][i]["reference_area"] != 0.0 for i in range(S)]
+    spec = {"alpha": [(i, 1, 0.2) for i in range(S - 1)], "q": [(i, 1, 4.0e4) for i in range(0, S - 1, 2)],
+            "qalpha": [(i, (i % 2), 5.0e3) for i in range(S - 1)]}
+    for kind in KINDS:
+        E.aero_configure(kind, spec[kind])
+    width, ci, ji = E.aero_record_layout()
+    allidx = np.concatenate([ci[k] for k in KINDS] + [ji[k] for k in KINDS])
+    assert len(np.unique(allidx)) == len(allidx) and allidx.min() >= 0 and allidx.max() < width and width % 8 == 0
+    nn = [int(v) for v in E.num_nodes]
+    for kind in KINDS:
+        nrow, nnz = E.aero_dims(kind)
+        rows, _cols = zip(*E.aero_pattern(kind))
+        r0 = 0
+        for (ph, rall, _lim) in spec[kind]:
+            nk = nn[ph] + 1 if rall else 1
+            c = ci[kind][r0:r0 + nk]
+            if rall and air[ph]:
+                base = c[1]
+                assert base % 8 == 0 and np.array_equal(c[1:], base + np.arange(nn[ph]))         # con: the block's first column
+                assert c[0] > c[1:].max()                                                          # state node 0: part B, behind part A
+                # the position block's entries of this spec: column j, node k  ->  base + (1 + j) n + (k - 1)
+                pr = rows[0]
+                sel = np.nonzero((pr >= r0) & (pr < r0 + nk))[0]
+                jp = ji[kind][:nnz[0]][sel].reshape(3, nk)
+                for j in range(3):
+                    assert np.array_equal(jp[j, 1:], base + (1 + j) * nn[ph] + np.arange(nn[ph])), (kind, ph, j)
+                tsel = np.nonzero((rows[3] >= r0) & (rows[3] < r0 + nk))[0]
+                jt = ji[kind][sum(nnz[:3]):][tsel].reshape(2, nk)
+                assert np.array_equal(jt[0, 1:], base + 11 * nn[ph] + np.arange(nn[ph]))
+            r0 += nk
+        assert r0 == nrow
