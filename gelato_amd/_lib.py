@@ -131,7 +131,7 @@ def build(force=False):
     src_dir = os.path.join(_HERE, "csrc")
     if force and os.path.exists(SO_PATH):
         os.remove(SO_PATH)
-    subprocess.check_call(["make", "-s", "-C", src_dir])
+    subprocess.check_call(["make", "-s", "-j3", "-C", src_dir])   # three translation units (kernels, the AERO instantiation, host side)
     if not os.path.exists(SO_PATH):
         raise RuntimeError("building %s failed" % SO_PATH)
     _write_build_info()
