@@ -314,9 +314,10 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     if (!rb) GEL_CHK(_v);                                                                 \
   } while (0)
 #define EMIT(slot, val) EMIT_AT(((int)(slot) - (SPLIT ? (((int)(slot) >= kSlotVP) ? sub_hi : sub_lo) : 0)) * cw8, val)
-  // AERO: this phase's record (scalar loads where a field is used), the vector's output record as a buffer resource (wave-uniform
-  // base; lane offset jvo; field offsets on the scalar unit), streamed like the Jacobian values.  A store of node j0 + lane + 1:
-  // field + column * nk8 + 8 j0 bytes into the record.
+  // AERO: this phase's record (scalar loads, once per group of entries: GEL_AERO_FETCH), the vector's output record as a buffer
+  // resource (wave-uniform base; lane offset jvo; block offsets on the scalar unit), streamed like the Jacobian values.  A store of
+  // node j0 + lane + 1, column c of a block whose first column is c0: base[kind] + ((c0 + c) n + j0) 8 bytes into the record
+  // (part A, spec-major: gel_device.h AeroPhaseDev).
   const AeroPhaseDev* const aph = AERO ? P.aero_ph + sec : nullptr;
   const int akinds = AERO ? __builtin_amdgcn_readfirstlane(load_const(&aph->kinds)) : 0;   // 0: no aero rows in this phase
   const __amdgpu_buffer_rsrc_t ars =
