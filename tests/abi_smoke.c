@@ -107,7 +107,25 @@ int main(int argc, char** argv) {
     CHECK(gel_jac_fd_block_cols(p, 0, bc) == GEL_OK && bc[0] == 0 && bc[6] == dm.M && bc[77] == dm.num_vars - 2);
     CHECK(gel_jac_fd_block_cols(p, 2, bc) == GEL_ERR_ARG);
   }
+  {
+    /* aero path constraints on phase 0, all nodes: the per-vector record of gel_eval_batch_aero_device and its gather map [r6] */
+    const int32_t aph[1] = {0}, aall[1] = {1};
+    const double alim[1] = {0.2};
+    int32_t nrow = 0;
+    int64_t nnz4[4], width = 0, oc[6], oj[6];
+    CHECK(gel_aero_configure(p, 0, 1, aph, aall, alim) == GEL_OK && gel_aero_dims(p, 0, &nrow, nnz4) == GEL_OK && nrow > 1);
+    CHECK(gel_aero_record_layout(p, &width, oc, oj) == GEL_OK && width >= nrow * 13 && width % 8 == 0);
+    int64_t* ci = malloc(sizeof(int64_t) * nrow);
+    int64_t* ji = malloc(sizeof(int64_t) * nnz4[0]);
+    CHECK(gel_aero_record_map(p, 0, -1, ci) == GEL_OK && gel_aero_record_map(p, 0, 0, ji) == GEL_OK);
+    for (int k = 0; k < nrow; k++) CHECK(ci[k] >= 0 && ci[k] < width);
+    for (int64_t k = 0; k < nnz4[0]; k++) CHECK(ji[k] >= 0 && ji[k] < width);
+    CHECK(gel_aero_record_map(p, 3, 0, ji) == GEL_ERR_ARG);
+    CHECK(gel_aero_configure(p, 0, 0, NULL, NULL, NULL) == GEL_OK);   /* and off again */
+    free(ci); free(ji);
+  }
   if (!gpu) {
+    CHECK(gel_eval_batch_aero_device(p, 1, x, res, vals, vals, NULL) == GEL_ERR_HIP);
     CHECK(gel_eval_residual(p, x, res) == GEL_ERR_HIP); /* host-only handles never evaluate */
     CHECK(gel_jac_fd_blocks(p, 2, x, vals) == GEL_ERR_HIP && gel_jac_fd_device(p, 2, x, vals, 1, NULL) == GEL_ERR_HIP);
     CHECK(gel_eval_shard_packed_device(p, 1, x, res, 0, 1, 2, NULL) == GEL_ERR_HIP);
