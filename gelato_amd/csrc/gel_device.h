@@ -64,9 +64,12 @@ struct AeroNodeDev {
 // The lanes of an aerodynamic phase's wavefront are its state nodes 1 .. n; where the phase has an "all nodes" spec of a kind they
 // also write that kind's constraint value and gradient entries of their node, from the centre evaluation and the position /
 // velocity / quaternion sweeps they run anyway.  Outputs: ONE record of aero_ld doubles per decision vector in two parts.
-// Part A = the rows the lanes write, SPEC-MAJOR: every (kind, phase) spec is one block of 13 n doubles,
-//   [con n | position 3 n | velocity 3 n | quaternion 4 n | t 2 n]      (columns [column][node]; the dynamic pressure leaves its
-// quaternion columns unwritten), so that a lane's store address is base[kind] + ((first column of the block + column) n + node) 8
+// Part A = the rows the lanes write, SPEC-MAJOR: every (kind, phase) spec is one block of 11 n doubles,
+//   [con n | position 3 n | velocity 3 n | quaternion 4 n]      (columns [column][node]; the dynamic pressure leaves its
+// quaternion columns unwritten; the t columns are exact zeros -- the air-relative velocity does not depend on the Earth angle --
+// and are not stored at all: gel_aero_record_map names them -1, like the constants of gel_full_source; a problem created with
+// GEL_FLAG_FD_RECOMPUTE runs the t sweeps and has them as columns 11, 12 of blocks of 13 n),
+// so that a lane's store address is base[kind] + ((first column of the block + column) n + node) 8
 // -- ONE scalar per kind and phase instead of a table of block offsets -- and a column's row is the phase's n nodes: whole 64-byte
 // lines at n = 64.  Part B = every other row (state node 0 of a phase, phases without aerodynamics, "initial" specs) in
 // gel_eval_aero_all's per-kind block layout, written by aero_wide_kernel.  gel_aero_record_map gives the record index of every entry
@@ -78,8 +81,8 @@ struct AeroPhaseDev {
   double il[3];        // 1 / limit (limit = units[3] of con_aero.py), divided on the host (the same IEEE quotient the kernels' frcp forms)
   double ilx[3];       // (1 / limit) * (1 / dx): what every gradient entry of the kind is scaled by
 };
-// first column (in units of n doubles) of a block inside a spec-major block: con 0, position 1, velocity 4, quaternion 7, t 11
-constexpr int kAeroSpecCols = 13;
+// first column (in units of n doubles) of a block inside a spec-major block: con 0, position 1, velocity 4, quaternion 7, (t 11)
+constexpr int kAeroSpecCols = 11, kAeroSpecColsWithT = 13;
 
 // knot / terminal / user rows (lib/con_init_terminal_knot.py, example/user_constraints.py): see gel_kernels.hip rows_kernel
 struct LinRowDev { int32_t idx0, idx1; double coef0, coef1, c0; };  // (coef0 x[idx0] + coef1 x[idx1]) + c0; idx1 < 0: one term

@@ -1378,8 +1378,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
             const double cv = 1.0 - ((kind == 0) ? alpha_c : (kind == 1) ? qdyn_c : qdyn_c * alpha_c) * il;
             AEMIT(ab_[kind] + j08_, cv);
             GEL_CHK(cv);
-#pragma unroll
-            for (int c = 0; c < 2; c++) AEMIT(ab_[kind] + (11 + c) * n8_ + j08_, 0.0);
+            // (the t0 / tf columns: exact zeros, not stored -- gel_aero_record_map names them -1)
           }
           if (a_need_alpha && !GEL_X_NOQUAT) {
             const double q[4] = {PARK_GET(PK_Q0), PARK_GET(PK_Q1), PARK_GET(PK_Q2), PARK_GET(PK_Q3)};

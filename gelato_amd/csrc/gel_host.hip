@@ -1784,14 +1784,14 @@ int gel_aero_configure(gel_problem* p, int32_t kind, int32_t nspec, const int32_
     p->aero_partA_base[kd].assign(A.size(), 0);
     for (size_t r0 = 0; r0 < A.size(); r0 += A[r0].nk) {
       for (int k = 0; k < A[r0].nk; k++) p->aero_partA_base[kd][r0 + k] = off;
-      off = pad8(off + (int64_t)gel::kAeroSpecCols * A[r0].nk);
+      off = pad8(off + (int64_t)(p->fd_recompute ? gel::kAeroSpecColsWithT : gel::kAeroSpecCols) * A[r0].nk);
     }
   }
   {   // the dump area: where the lanes' stores of a kind their phase does not have go (AeroPhaseDev::base)
     int nmax = 0;
     for (const auto& h : p->ph) nmax = std::max(nmax, h.n);
     p->aero_dump = off;
-    off = pad8(off + (int64_t)gel::kAeroSpecCols * nmax);
+    off = pad8(off + (int64_t)gel::kAeroSpecColsWithT * nmax);
   }
   p->aero_partA_len = off;
   // part B: gel_eval_aero_all's layout for its rows
@@ -1894,6 +1894,7 @@ int gel_aero_record_map(const gel_problem* p, int32_t kind, int32_t var, int64_t
         const int64_t R = (int64_t)p->aero_part_rows[part][kind].size();
         const int64_t ko = (po >> 1) - q.row0;
         if (part == 1) idx[o++] = p->aero_off_jac[1][kind] + bo * R + w * q.row0 + j * q.nk + ko;
+        else if (var == 3 && !p->fd_recompute) idx[o++] = -1;      // an exact zero, not stored (AeroPhaseDev)
         else idx[o++] = p->aero_partA_base[kind][po >> 1] + (((var == 0) ? 1 : ((var == 1) ? 4 : ((var == 2) ? 7 : 11))) + j) * q.nk + ko;
       }
   return GEL_OK;

@@ -562,6 +562,7 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
       if ((skip_q) && kind == 1) continue;                 /* dynamic pressure has no quaternion block */        \
       const int a8_ = ipark[AP_AIDX(kind, width) * 64];                                                           \
       if (a8_ == -1 || (skip_lane)) continue;                                                                     \
+      if (SM && (zero)) continue;                          /* spec-major records do not hold the exact zeros of the t columns */ \
       const int nq = (kind == 1) ? 0 : 4;                                                                         \
       const int bo = ((boff) < 0) ? (6 + nq) : (boff);                                                            \
       const double df_ = (kind == 0) ? t_ : ((kind == 1) ? dq_ : qp_ * t_ + dq_ * ac_);                           \

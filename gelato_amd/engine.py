@@ -477,8 +477,8 @@ class Engine:
 
     def aero_record_layout(self):
         """-> (width, {kind: con index [nrows]}, {kind: jac index [sum nnz]}): the per-vector record of eval_batch_aero_device and
-        the gather that restores eval_aero_all's arrays from it -- con[kind] = record[..., con_idx[kind]], jac likewise (the four
-        blocks position | velocity | quaternion | t concatenated, as eval_aero_all returns them)"""
+        the gather that restores eval_aero_all's arrays from it -- con[kind] = aero_gather(record, con_idx[kind]), jac likewise (the four
+        blocks position | velocity | quaternion | t concatenated, as eval_aero_all returns them; index -1: an exact zero, not stored)"""
         w = C.c_int64()
         oc, oj = (C.c_int64 * 6)(), (C.c_int64 * 6)()
         check(lib().gel_aero_record_layout(self._h, C.byref(w), oc, oj))
@@ -496,6 +496,15 @@ class Engine:
                 parts.append(ji)
             con[kind], jac[kind] = ci, np.concatenate(parts)
         return int(w.value), con, jac
+
+    @staticmethod
+    def aero_gather(records, idx):
+        """records [..., width], idx from aero_record_layout -> the reference's array; index -1 = an exact zero that is not stored"""
+        records = np.asarray(records)
+        out = records[..., np.maximum(idx, 0)]
+        if (idx < 0).any():
+            out[..., idx < 0] = 0.0
+        return out
 
     def eval_batch_aero_device(self, B, d_x, d_res, d_jvar, d_aero, stream=0):
         """defect groups + aero path constraints of a resident batch (device pointers as ints): res [B, nres], jvar [B, V] as

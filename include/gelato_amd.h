@@ -266,13 +266,14 @@ int gel_eval_aero_all_device(gel_problem* p, int32_t B, const double* d_x, doubl
  * chain at the same nodes; src/pybind_dynamics.cpp:42-59 / src/wrapper_utils.hpp:89-206).  d_res [B][11 N] and d_jvar [B][V] as
  * gel_eval_batch_device writes them; d_aero [B][width]: ONE record per decision vector in two parts, each
  *   [con alpha | con q | con q-alpha | jac alpha | jac q | jac q-alpha]
- * laid out like gel_eval_aero_all's arrays for ITS rows: part A = state nodes 1 .. n of the aerodynamic phases' "all nodes"
+ * (part B laid out like gel_eval_aero_all's arrays for its rows, part A spec-major): part A = state nodes 1 .. n of the aerodynamic phases' "all nodes"
  * specs (the rows a lane of the fused kernel has: a spec's row of a column is n doubles -- whole 64-byte lines per store), part
  * B = every other row (state node 0 of a phase, phases without aerodynamics, "initial" specs).  gel_aero_record_layout: width and
  * the twelve section offsets (off_con / off_jac [2][3]: part, kind; every section on a multiple of eight doubles);
  * gel_aero_record_map: the record index of every entry of gel_eval_aero_all's arrays (var = -1: the constraint vector; 0..3: the
  * position / velocity / quaternion / t block in gel_aero_pattern's order) -- the gather a consumer applies, like gel_full_source
- * for the compact Jacobian values.
+ * for the compact Jacobian values; index -1 = an exact zero that is not stored (the t0 / tf columns of part A: the air-relative
+ * velocity does not depend on the Earth angle; problems created with GEL_FLAG_FD_RECOMPUTE run those sweeps and store them).
  * Where the launch takes the throughput form with one decision vector per wavefront (not: a handful of vectors, meshes of phases
  * of at most 32 nodes, GEL_FLAG_FD_RECOMPUTE), the lanes of an aerodynamic phase write part A themselves, from the centre
  * evaluation and the position sweeps they run anyway; otherwise -- and with GEL_AERO_FUSED=0 in the environment -- aero_kernel

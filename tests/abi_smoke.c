@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
     int32_t nrow = 0;
     int64_t nnz4[4], width = 0, oc[6], oj[6];
     CHECK(gel_aero_configure(p, 0, 1, aph, aall, alim) == GEL_OK && gel_aero_dims(p, 0, &nrow, nnz4) == GEL_OK && nrow > 1);
-    CHECK(gel_aero_record_layout(p, &width, oc, oj) == GEL_OK && width >= nrow * 13 && width % 8 == 0);
+    CHECK(gel_aero_record_layout(p, &width, oc, oj) == GEL_OK && width >= nrow * 11 && width % 8 == 0);
     int64_t* ci = malloc(sizeof(int64_t) * nrow);
     int64_t* ji = malloc(sizeof(int64_t) * nnz4[0]);
     CHECK(gel_aero_record_map(p, 0, -1, ci) == GEL_OK && gel_aero_record_map(p, 0, 0, ji) == GEL_OK);

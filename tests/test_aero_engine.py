@@ -415,13 +415,15 @@ def test_defect_groups_and_aero_rows_in_one_call_equal_the_two_kernels(name, B, 
     covered = np.zeros(width, dtype=bool)
     for kind in KINDS:
         ci, ji = ocon[kind], ojac[kind]
-        assert not covered[ci].any() and not covered[ji].any() and len(np.unique(ci)) == len(ci) and len(np.unique(ji)) == len(ji)
+        js = ji[ji >= 0]       # index -1: an exact zero that is not stored (the t columns of part A)
+        assert ci.min(initial=0) >= 0 and not covered[ci].any() and not covered[js].any() and len(np.unique(ci)) == len(ci) and len(np.unique(js)) == len(js)
         covered[ci] = True
-        covered[ji] = True
+        covered[js] = True
         if len(ci) == 0:
             continue
-        assert np.array_equal(one["aero"][:, ci], two["con"][kind]), (kind, "values")
-        d = one["aero"][:, ji] != two["jac"][kind]
+        assert np.array_equal(E.aero_gather(one["aero"], ci), two["con"][kind]), (kind, "values")
+        assert not two["jac"][kind][:, ji < 0].any()      # what the map calls an exact zero is one in aero_kernel's arrays
+        d = E.aero_gather(one["aero"], ji) != two["jac"][kind]
         assert not d.any(), (kind, "gradient values", int(d.sum()), np.argwhere(d)[:5])
     # every entry of the reference's arrays has its own place in the record; what the map does not name is padding (sections
     # start on multiples of eight doubles) and is never written
@@ -481,16 +483,17 @@ def test_fused_aero_rows_take_the_recomputing_fallback_like_the_aero_kernel(monk
     con, jac, _rc = E.eval_aero_all(X)
     a = a1.cpu().numpy()
     for kind in KINDS:
-        assert np.array_equal(a[:, ocon[kind]], con[kind], equal_nan=True), kind
-        assert np.array_equal(a[:, ojac[kind]], jac[kind], equal_nan=True), kind
+        assert np.array_equal(E.aero_gather(a, ocon[kind]), con[kind], equal_nan=True), kind
+        assert np.array_equal(E.aero_gather(a, ojac[kind]), jac[kind], equal_nan=True), kind
 
 
 @pytest.mark.parametrize("name", ["mixed-6x64", "stress-12x128", "example"])
 def test_aero_record_map_host_only(name):
     """gel_aero_record_layout / gel_aero_record_map on a host-only handle (no GPU): every entry of gel_eval_aero_all's arrays has its
     own cell of the per-vector record; the cells of part A -- the rows a lane of the fused kernel has -- form spec-major blocks of
-    13 n doubles whose columns are runs of the phase's n nodes starting on multiples of eight doubles (whole 64-byte lines at
-    n = 64), in the order [con | position 3 | velocity 3 | quaternion 4 | t 2]; state node 0 of every spec lies in part B."""
+    11 n doubles whose columns are runs of the phase's n nodes starting on multiples of eight doubles (whole 64-byte lines at
+    n = 64), in the order [con | position 3 | velocity 3 | quaternion 4]; the t columns are exact zeros and not stored (-1); state
+    node 0 of every spec lies in part B."""
     from gelato_amd import Engine, con_dynamics, problem
     pdict, unitdict, _c, _x = problem.make_problem(name)
     E = Engine(con_dynamics.problem_arrays(pdict, unitdict), device=-1)
@@ -502,7 +505,8 @@ def test_aero_record_map_host_only(name):
         E.aero_configure(kind, spec[kind])
     width, ci, ji = E.aero_record_layout()
     allidx = np.concatenate([ci[k] for k in KINDS] + [ji[k] for k in KINDS])
-    assert len(np.unique(allidx)) == len(allidx) and allidx.min() >= 0 and allidx.max() < width and width % 8 == 0
+    stored = allidx[allidx >= 0]
+    assert len(np.unique(stored)) == len(stored) and allidx.min() >= -1 and allidx.max() < width and width % 8 == 0
     nn = [int(v) for v in E.num_nodes]
     for kind in KINDS:
         nrow, nnz = E.aero_dims(kind)
@@ -523,7 +527,7 @@ def test_aero_record_map_host_only(name):
                     assert np.array_equal(jp[j, 1:], base + (1 + j) * nn[ph] + np.arange(nn[ph])), (kind, ph, j)
                 tsel = np.nonzero((rows[3] >= r0) & (rows[3] < r0 + nk))[0]
                 jt = ji[kind][sum(nnz[:3]):][tsel].reshape(2, nk)
-                assert np.array_equal(jt[0, 1:], base + 11 * nn[ph] + np.arange(nn[ph]))
+                assert np.all(jt[:, 1:] == -1) and np.all(jt[:, 0] >= 0)          # t columns: exact zeros in part A, stored for node 0 (part B)
             r0 += nk
         assert r0 == nrow
 
@@ -549,7 +553,8 @@ def test_fused_defect_plus_aero_at_full_size(name, B):
     Xd = problem.synthetic_batch(pack_x(xdict), E.M, P, seed=3)
     dX = torch.from_numpy(Xd).to(dev).repeat(B // P, 1).contiguous()
     width, ci, ji = E.aero_record_layout()
-    named = torch.from_numpy(np.concatenate([ci[k] for k in KINDS] + [ji[k] for k in KINDS])).to(dev)
+    named = np.concatenate([ci[k] for k in KINDS] + [ji[k] for k in KINDS])
+    named = torch.from_numpy(named[named >= 0]).to(dev)
     outs = []
     for _ in range(2):
         r = torch.empty((B, E.nres), dtype=torch.float64, device=dev)
@@ -572,4 +577,4 @@ def test_fused_defect_plus_aero_at_full_size(name, B):
         assert rc1 == 0
         rec = a[B - P + b].cpu().numpy()
         for kind in KINDS:
-            assert np.array_equal(rec[ci[kind]], c1[kind][0]) and np.array_equal(rec[ji[kind]], j1[kind][0]), (kind, b)
+            assert np.array_equal(E.aero_gather(rec, ci[kind]), c1[kind][0]) and np.array_equal(E.aero_gather(rec, ji[kind]), j1[kind][0]), (kind, b)
