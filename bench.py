@@ -789,6 +789,8 @@ def main():
         # lanes of the aerodynamic phases (gel_eval_batch_aero_device), against the two kernels one after the other
         try:
             width, _oc, _oj = E.aero_record_layout()
+            n_ref = sum(len(v) for v in _oc.values()) + sum(len(v) for v in _oj.values())                     # the reference's values per vector
+            n_stored = sum(int((v >= 0).sum()) for v in _oc.values()) + sum(int((v >= 0).sum()) for v in _oj.values())   # without the exact zeros
             dims = [E.aero_dims(k) for k in E.AERO_KINDS]
             daero = torch.empty((B, width), dtype=torch.float64, device=dev)
             dcon = [torch.empty((B, d[0]), dtype=torch.float64, device=dev) for d in dims]
@@ -817,9 +819,9 @@ def main():
             ms_two2 = time_of(two_calls)
             ms_one2 = time_of(fused_call)
             ms_def = time_of(step)
-            a_bytes = E.algorithmic_bytes + 8 * width
+            a_bytes = E.algorithmic_bytes + 8 * n_ref      # SURVEY 8(d)'s A_min of the defect path + every aero value of the reference once
             out["defect_plus_aero"] = {
-                "batch": B, "aero_rows": rows, "aero_values_per_vector": width,
+                "batch": B, "aero_rows": rows, "aero_values_per_vector": n_ref, "aero_values_stored_per_vector": n_stored, "aero_record_doubles": width,
                 "one_call_ms": min(ms_one, ms_one2), "two_kernels_ms": min(ms_two, ms_two2), "defect_alone_ms": ms_def,
                 "ns_per_vector_one_call": 1e6 * min(ms_one, ms_one2) / B, "ns_per_vector_two_kernels": 1e6 * min(ms_two, ms_two2) / B,
                 "ns_per_vector_defect_alone": 1e6 * ms_def / B,
