@@ -578,3 +578,17 @@ def test_fused_defect_plus_aero_at_full_size(name, B):
         rec = a[B - P + b].cpu().numpy()
         for kind in KINDS:
             assert np.array_equal(E.aero_gather(rec, ci[kind]), c1[kind][0]) and np.array_equal(E.aero_gather(rec, ji[kind]), j1[kind][0]), (kind, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [2, 8])
+def test_defect_plus_aero_call_on_problems_that_cannot_take_the_fused_form(flags):
+    """GEL_FLAG_DX_VALU (2: D.X on the vector unit -- no cooperative form) and GEL_FLAG_FD_RECOMPUTE (8: every sweep re-run like the
+    reference, the t0 / tf columns of the aero rows included): gel_eval_batch_aero_device runs the two kernels, the record holds
+    the t columns where they are computed (flags = 8: no -1 in the map), and every value is the bits of the separate calls."""
+    E, one, two, (width, ocon, ojac) = _fused_case("mixed-6x64", 70, _all_air(), flags=flags)
+    assert np.array_equal(one["res"], two["res"]) and np.array_equal(one["jvar"], two["jvar"])
+    for kind in KINDS:
+        assert (ojac[kind] < 0).any() == (flags != 8)
+        assert np.array_equal(E.aero_gather(one["aero"], ocon[kind]), two["con"][kind]), kind
+        assert np.array_equal(E.aero_gather(one["aero"], ojac[kind]), two["jac"][kind]), kind
