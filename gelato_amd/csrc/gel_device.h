@@ -33,6 +33,12 @@ template <class T>
 __device__ __forceinline__ T load_const(const T* p) {
   return *(const T __attribute__((address_space(4)))*)p;
 }
+__device__ __forceinline__ int4 load_const_int4(const int4* p) {   // one s_load_dwordx4
+  const int32_t* ip = (const int32_t*)p;
+  int4 v;
+  v.x = load_const(ip); v.y = load_const(ip + 1); v.z = load_const(ip + 2); v.w = load_const(ip + 3);
+  return v;
+}
 __device__ __forceinline__ PhaseDev load_phase(const PhaseDev* g) {
   PhaseDev q;
   q.n = load_const(&g->n); q.ua = load_const(&g->ua); q.xa = load_const(&g->xa);

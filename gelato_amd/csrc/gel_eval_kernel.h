@@ -98,6 +98,13 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #endif
 
 
+#ifndef GEL_FRONT_BATCH
+#define GEL_FRONT_BATCH 1  // cooperative forms: the kernel arguments of the walk to the phase record in one round trip, one chunk-record fetch
+#endif
+#ifndef GEL_DX_HOLD7
+#define GEL_DX_HOLD7 1  // hold-type phases: D.X without the quaternion columns (two column tiles per wavefront instead of three)
+#endif
+
 #ifndef GEL_STORE_AUX
 #define GEL_STORE_AUX 2  // cache policy of the Jacobian stores: 2 = nt (A/B: 0 plain, 1 sc0, 16 sc1, 18 sc1+nt)
 #endif
@@ -133,6 +140,16 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // the matrix-pipe forms are only launched when residual rows are asked for (eval_form(): mfma = use_mfma && want_res): knowing
   // that, the compiler drops the `if (rb)` tests of the cooperative forms and the thirty zero-initialisations in front of them
   if (MFMA) __builtin_assume(res != nullptr);
+  // Cooperative forms: what the walk to the phase record needs of the kernel arguments, taken TOGETHER at the top -- the compiler
+  // fetches an argument where it is first used, and the walk (workgroup -> work item -> chunk record -> phase record -> addresses
+  // of the state rows) used them one or two at a time: three scalar-load round trips in a row before the chunk record was even
+  // asked for, in front of every wavefront's first request to HBM.  One asm statement that wants them all in scalar registers
+  // makes them one round trip (in-process A/B: -0.25 % mixed-6x64, -0.45 % 3 x 32 residual-only: such a round trip is a hit in the
+  // scalar cache, 100-200 cycles; fetching the scalars of the LATER stages here as well costs registers and was not kept).
+  int fB = B, f_chunk0 = P.chunk0, f_vmajor = P.vmajor, f_nchunks = P.nchunks;
+  const int4* f_chunks = P.chunks;
+  const PhaseDev* f_phases = P.phases;
+  if (GEL_FRONT_BATCH && MFMA && !SPLIT) asm volatile("" : "+s"(fB), "+s"(f_chunk0), "+s"(f_vmajor), "+s"(f_nchunks), "+s"(f_chunks), "+s"(f_phases));
   const int park_off = P.park_off;
   // the cooperative forms meet at a barrier (operand image / hand-over) before any table lookup: no barrier of its own
   constexpr bool kSplitStage = MFMA && !SPLIT;   // cooperative forms: table entry requested now, written before their first barrier
@@ -161,7 +178,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   constexpr int kVecWg = PACK ? 8 : 4;   // decision vectors per workgroup
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int half = PACK ? (lane >> 5) : 0;
-  const int nb4 = (B + kVecWg - 1) / kVecWg;  // COOP: workgroups per work item
+  const int nb4 = (fB + kVecWg - 1) / kVecWg;  // COOP: workgroups per work item
   const long long item = COOP ? 0 : __builtin_amdgcn_readfirstlane((int)(((long long)vblk * blockDim.x + threadIdx.x) >> 6));
   if (!COOP && item >= (long long)B * (SPLIT ? P.nunits : P.nchunks)) return;
   // work-item major: all B vectors of one (phase, chunk) are neighbours, so the four wavefronts of a
@@ -177,21 +194,26 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // reach their DRAM pages together.  Measured on 12 x 128 (two chunks per phase), same box: +4.6 % with the chunks merely
   // adjacent in dispatch order; phases of at most 64 nodes have one chunk and keep plain work-item major order.
   int q, b0;
+  int4 ck_it = int4{0, 0, 0, 0};
+  bool ck_same = false;   // COOP: ck_it is this workgroup's record
   if (COOP) {
     const unsigned p = vblk, nb = (unsigned)nb4;
     unsigned it = p / nb, r = p - it * nb;
-    if (P.vmajor) {
+    if (f_vmajor) {
       // Vector-group major, XCD aware (meshes whose phases all have at most 32 nodes): the work items of ONE group of vectors run
       // as consecutive workgroups of ONE XCD (workgroup p lands on XCD p % 8), so the 128-byte lines that neighbouring phases'
       // state rows share in x -- and the partial lines of their residual rows -- meet in that XCD's L2 instead of being
       // fetched and written once per phase (3 x 32 residual-only: HBM traffic 1.11 -> 1.0x of the algorithmic bytes).
-      const unsigned xcd = p & 7u, qq = p >> 3, items = (unsigned)P.nchunks;
+      const unsigned xcd = p & 7u, qq = p >> 3, items = (unsigned)f_nchunks;
       const unsigned gl = qq / items;
       it = qq - gl * items;
       r = gl * 8u + xcd;
       if (r >= nb) return;   // the last block of eight groups may be short (whole workgroup: before any barrier)
     }
-    const int cw = __builtin_amdgcn_readfirstlane(P.chunks[P.chunk0 + it].w);   // (position in the phase's run of chunks) << 16 | chunks
+    // the work item's WHOLE chunk record at once: with one chunk per phase (every phase of at most 64 nodes) it is the record this
+    // workgroup works on -- no second fetch behind the first
+    ck_it = load_const_int4(f_chunks + f_chunk0 + it);
+    const int cw = __builtin_amdgcn_readfirstlane(ck_it.w);   // (position in the phase's run of chunks) << 16 | chunks
     const unsigned pos = (unsigned)cw >> 16, nc = (unsigned)cw & 0xffffu;
     unsigned c = pos, bg = r;
     if (nc > 1) {
@@ -202,6 +224,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
       bg = blk * 8 + (rem - c * m);
     }
     q = (int)(it - pos + c);
+    ck_same = GEL_FRONT_BATCH && nc <= 1;
     b0 = (int)bg * kVecWg;                             // first vector of the workgroup
   } else {
     q = (int)(item / B);
@@ -210,17 +233,18 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // COOP: a wavefront (PACK: a half) past the end of the batch (B not a multiple of 4 / 8) still computes its tiles for
   // the others; it reads vector B - 1 and leaves after the hand-over without writing anything
   const int bw = PACK ? b0 + 2 * wv + half : b0 + wv;
-  const bool ghost = COOP && bw >= B;
+  const bool ghost = COOP && bw >= fB;
   const bool pack_full = PACK && __builtin_amdgcn_ballot_w64(ghost) == 0;   // both vectors of this wavefront exist (wave-uniform)
-  const int b = COOP ? min(bw, B - 1) : (int)(item - (long long)q * B);
+  const int b = COOP ? min(bw, fB - 1) : (int)(item - (long long)q * B);
   const int ci = SPLIT ? ((P.unit0 + q) >> 2) : q;
   const int part = SPLIT ? ((P.unit0 + q) & 3) : 0;  // wave-uniform
-  const int4 ck = P.chunks[(SPLIT ? 0 : P.chunk0) + ci];
+  int4 ck = ck_it;
+  if (!ck_same) ck = COOP ? load_const_int4(f_chunks + f_chunk0 + ci) : P.chunks[(SPLIT ? 0 : P.chunk0) + ci];   // wave-uniform
   const int sec = __builtin_amdgcn_readfirstlane(ck.x);
   const int j0 = __builtin_amdgcn_readfirstlane(ck.y);
   const int dsw = __builtin_amdgcn_readfirstlane(ck.z);  // first gel_double4 of this work item in Dsw
   const int j = PACK ? (lane & 31) : j0 + lane;  // node inside the phase (PACK: one chunk per phase, j0 = 0)
-  const PhaseDev ph = load_phase(P.phases + sec);  // by value, in SGPRs, before any store
+  const PhaseDev ph = load_phase((COOP ? f_phases : P.phases) + sec);  // by value, in SGPRs, before any store
   // Latency form of a WHOLE one-vector VALUES-ONLY evaluation (the optimiser's objfunc): the four wavefronts of a workgroup are the
   // four parts of ONE work item, of which only the lead has anything to do -- so each forms one 16-row tile of D.X (17 instead of 68
   // matrix instructions in the lead; the state rows cross the bus once, a quarter per wavefront); the tiles meet in the lead's
@@ -252,7 +276,14 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #define GEL_UNI(v) (PACK ? (v) : wave_uniform(v))
   // The phase's two knot times: requested here, TAKEN (v_readfirstlane: the first wait of the wavefront) only once every other
   // load of phase A has been requested -- one HBM round trip instead of two in a row in front of the D.X product.
-  const double to_ld = xt[sec], tf_ld = xt[sec + 1];
+#ifndef GEL_KNOT_VLOAD
+#define GEL_KNOT_VLOAD 1   // the knot times by a VECTOR load (the index made opaque): a wave-uniform address becomes a scalar load, which the
+                           // compiler -- short of scalar registers here -- waits for on the spot (to park the pair in a VGPR's lanes): an HBM
+                           // round trip IN FRONT of the requests for the state rows, the very thing the comment above is about
+#endif
+  int sec_ld = sec;
+  if (GEL_KNOT_VLOAD && JAC) asm volatile("" : "+v"(sec_ld));   // (the residual-only forms have the scalar registers to let the pair wait with the others)
+  const double to_ld = xt[sec_ld], tf_ld = xt[sec_ld + 1];
   double to = 0.0, tf = 0.0, fds = 0.0, fdt = 0.0;
   const double dx = P.dx, ut = P.ut;
   // unit_t / 2 (exact): v * unit_t / 2.0 as the reference writes it is round(v unit_t) / 2 = round(v (unit_t / 2)) -- scaling by a power
@@ -459,12 +490,14 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
     }
     const double dlast = (SPLIT && tail1) ? dcol[jc] : 0.0;     // latency form: D[j][n]
     double xl[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // latency form: state row n
-#define GEL_DX_TAIL_ACC(xn_of_ct)                                                                   \
+#define GEL_DX_TAIL_ACC(nct_, xn_of_ct)                                                             \
   do {                                                                                              \
     if (tail1) {                                                                                    \
       _Pragma("unroll") for (int ct = 0; ct < 3; ct++) {                                            \
-        const double xn_ = (xn_of_ct);                                                              \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) acc[ct][i] = __builtin_fma(dl4[i], xn_, acc[ct][i]); \
+        if (ct < (nct_)) {   /* wave-uniform: column tiles in use */                                \
+          const double xn_ = (xn_of_ct);                                                            \
+          _Pragma("unroll") for (int i = 0; i < 4; i++) acc[ct][i] = __builtin_fma(dl4[i], xn_, acc[ct][i]); \
+        }                                                                                           \
       }                                                                                             \
     }                                                                                               \
   } while (0)
@@ -489,14 +522,20 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         lds_double* regions = (lds_double*)lds + park_off;
         // PACK: [32 x (n+1)] . [(n+1) x 88]: row tiles 0 and 1 only, six column tiles; wavefront w forms row tile w & 1 for
         // column tiles 3 (w >> 1) .. + 2; vector v's image lies in wavefront v >> 1's region, half v & 1.
-        constexpr int kCols = 11 * kVecWg;
-        const int ct0 = PACK ? 3 * (wv >> 1) : 0;
+        // Hold-type phases (attitude hold / vertical: quaternion rows q[1:] - q[0], lib/con_dynamics.py:521-522) never read the
+        // quaternion columns of D.X: their vectors are packed seven columns each (mass | position | velocity) -- 28 (PACK: 56)
+        // columns in TWO column tiles per wavefront instead of 44 (88) in three, a third of the phase's matrix instructions less.
+        // A column's sums do not depend on its neighbours in the tile: the columns that are formed keep their bits.
+        const bool h7 = GEL_DX_HOLD7 && !PACK && ph.hold;   // wave-uniform (one work item per workgroup); PACK: not taken (3 x 32 residual-only +1.1 % with it)
+        const int ncv = h7 ? 7 : 11;               // columns per vector
+        const int ncols = ncv * kVecWg;
+        const int ct0 = PACK ? (h7 ? 2 : 3) * (wv >> 1) : 0;
         int xoff[3];
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
-          const int c = 16 * (ct0 + ct) + c16;    // packed column: vector c / 11, state column c % 11
-          const int vb = min(c / 11, kVecWg - 1); // the last columns are padding: computed on the last vector, never read
-          const int col = (c < kCols) ? c - 11 * vb : 0;
+          const int c = 16 * (ct0 + ct) + c16;    // packed column: vector c / ncv, state column c % ncv
+          const int vb = min(h7 ? c / 7 : c / 11, kVecWg - 1); // the last columns are padding: computed on the last vector, never read
+          const int col = (c < ncols) ? c - ncv * vb : 0;
           xoff[ct] = PACK ? (vb >> 1) * kWL + (vb & 1) * kPackRows * 11 + col + kq * 11 : vb * kWL + col + kq * 11;
         }
         gel_double4 acc[3];
@@ -554,46 +593,52 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
           for (int c = 0; c < 11; c++) dst[c] = st[c];
 #pragma unroll
           for (int i = 0; i < (kExtra + 63) / 64; i++) {
-            const int e = lane + 64 * i;
-            if (e < kExtra) wave_lds[(64 + (e & (kER - 1))) * 11 + (e >> kERs)] = sx[i];
+            // no branch: the lanes past the last element were given its address (clamped above) and write its value once more -- a
+            // lane-conditional store drew its load into the branch, behind a wait of its own (two vectors per wavefront: an extra
+            // round trip in front of the operand barrier)
+            const int e = min(lane + 64 * i, kExtra - 1);
+            wave_lds[(64 + (e & (kER - 1))) * 11 + (e >> kERs)] = sx[i];
           }
         }
         stage_tables_commit(P, lds, tab_mine);
         __syncthreads();
         const int klast = ksteps;
-        if (kAAll) {
-#pragma unroll
-          for (int ks = 0; ks < kAllN; ks++) {
-            if (ks == 0 || ks < klast) {   // wave-uniform; a phase has at least one k-step (the no-D.X ablation multiplies one, too)
-              const int ro = ks * 44;                                        // 4 rows of 11 columns per k-step
-              const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
-              // the first k-step takes the constant 0 as its C operand (an inline operand of the instruction) instead of
-              // accumulators that twenty-four v_mov have cleared
-              const gel_double4 zero4 = gel_double4{0.0, 0.0, 0.0, 0.0};
-              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl0, ks ? acc[0] : zero4, 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl1, ks ? acc[1] : zero4, 0, 0, 0);
-              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl2, ks ? acc[2] : zero4, 0, 0, 0);
-            }
-          }
-        } else {
-          // k-steps of A slabs in flight ahead of the matrix pipe (an L2 round trip each; the first ones requested before the barrier)
-#pragma unroll
-          for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};
-          for (int ks = 0; ks < klast; ks += kAPF) {
-#pragma unroll
-            for (int i = 0; i < kAPF; i++) {
-              if (ks + i < klast) {   // wave-uniform
-                const int ro = (ks + i) * 44;
-                const double bl0 = regions[xoff[0] + ro], bl1 = regions[xoff[1] + ro], bl2 = regions[xoff[2] + ro];
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ring[i], bl0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ring[i], bl1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ring[i], bl2, acc[2], 0, 0, 0);
-              }
-              a_ring[i] = ap[min(ks + i + kAPF, ksteps - 1) * 256];
-            }
-          }
-        }
-        GEL_DX_TAIL_ACC(regions[xoff[ct] + (n - kq) * 11]);   // row n of this lane's column (xoff points at row kq)
+        // (the loops exist twice, with and without the third column tile: one scalar branch per phase instead of one per k-step)
+#define GEL_DX_ONE_SLAB(kTiles)                                                                                          \
+  do {                                                                                                                   \
+    if (kAAll) {                                                                                                         \
+      _Pragma("unroll") for (int ks = 0; ks < kAllN; ks++) {                                                             \
+        if (ks == 0 || ks < klast) {   /* wave-uniform; a phase has at least one k-step (the no-D.X ablation multiplies one, too) */ \
+          const int ro = ks * 44;      /* 4 rows of 11 columns per k-step */                                             \
+          /* the first k-step takes the constant 0 as its C operand (an inline operand of the instruction) instead of    \
+             accumulators that twenty-four v_mov have cleared */                                                         \
+          const gel_double4 zero4 = gel_double4{0.0, 0.0, 0.0, 0.0};                                                     \
+          double bl_[kTiles];                                                                                            \
+          _Pragma("unroll") for (int ct = 0; ct < (kTiles); ct++) bl_[ct] = regions[xoff[ct] + ro];                      \
+          _Pragma("unroll") for (int ct = 0; ct < (kTiles); ct++)                                                        \
+            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_all[ks], bl_[ct], ks ? acc[ct] : zero4, 0, 0, 0);           \
+        }                                                                                                                \
+      }                                                                                                                  \
+    } else {                                                                                                             \
+      /* k-steps of A slabs in flight ahead of the matrix pipe (an L2 round trip each; the first ones requested before the barrier) */ \
+      _Pragma("unroll") for (int ct = 0; ct < 3; ct++) acc[ct] = gel_double4{0.0, 0.0, 0.0, 0.0};                        \
+      for (int ks = 0; ks < klast; ks += kAPF) {                                                                         \
+        _Pragma("unroll") for (int i = 0; i < kAPF; i++) {                                                               \
+          if (ks + i < klast) {   /* wave-uniform */                                                                     \
+            const int ro = (ks + i) * 44;                                                                                \
+            double bl_[kTiles];                                                                                          \
+            _Pragma("unroll") for (int ct = 0; ct < (kTiles); ct++) bl_[ct] = regions[xoff[ct] + ro];                    \
+            _Pragma("unroll") for (int ct = 0; ct < (kTiles); ct++)                                                      \
+              acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ring[i], bl_[ct], acc[ct], 0, 0, 0);                      \
+          }                                                                                                              \
+          a_ring[i] = ap[min(ks + i + kAPF, ksteps - 1) * 256];                                                          \
+        }                                                                                                                \
+      }                                                                                                                  \
+    }                                                                                                                    \
+  } while (0)
+        if (h7) GEL_DX_ONE_SLAB(2); else GEL_DX_ONE_SLAB(3);
+#undef GEL_DX_ONE_SLAB
+        GEL_DX_TAIL_ACC(h7 ? 2 : 3, regions[xoff[ct] + (n - kq) * 11]);   // row n of this lane's column (xoff points at row kq)
         {
           // the node's own state row comes from the same image (after the product: nothing of it is live across the loop)
           lds_double* src = wave_lds + (half * kPackRows + jc + 1) * 11;
@@ -615,8 +660,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
           const int c = 16 * (ct0 + ct) + c16;
-          const int vb = c / 11, col = c - 11 * vb;
-          if (c < kCols) {
+          const int vb = h7 ? c / 7 : c / 11, col = c - ncv * vb;
+          if (c < ncols && (ct < 2 || !h7)) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
               if (PACK)   // node 16 (w & 1) + .. of vector vb -> lane 32 (vb & 1) + node of wavefront vb >> 1
@@ -655,11 +700,13 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         static_assert(!COOP || PACK || !LONGP || kRingOff + 64 * kPipeK <= kWL, "two images and the A ring must fit the wave's region");
         constexpr int kBP = kPipeRows, kBV = 4 * kPipeRows, kBQ = 7 * kPipeRows;   // blocks of an image
         lds_double* regions = (lds_double*)lds + park_off;
+        const bool h7 = GEL_DX_HOLD7 && ph.hold;   // hold-type phase: seven columns per vector in two column tiles (see the one-slab form)
+        const int ncv = h7 ? 7 : 11, ncols = 4 * ncv;
         int xoff[3], xstr[3];
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
           const int c = 16 * ct + c16;
-          const int vb = min(c / 11, 3), col = (c < 44) ? c - 11 * vb : 0;
+          const int vb = min(h7 ? c / 7 : c / 11, 3), col = (c < ncols) ? c - ncv * vb : 0;
           const int base = (col == 0) ? 0 : ((col < 4) ? kBP + col - 1 : ((col < 7) ? kBV + col - 4 : kBQ + col - 7));
           const int stride = (col == 0) ? 1 : ((col < 7) ? 3 : 4);
           xoff[ct] = vb * kWL + base + stride * kq;      // row kq of the lane's column
@@ -700,35 +747,38 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         const lds_double* ring = wave_lds + kRingOff + lane;
         for (int sl = 0; sl < nslab; sl++) {
           const int bo = (sl & 1) * kPipeBuf;
-          const bool more = sl + 1 < nslab;                 // wave-uniform
+          const bool more = sl + 1 < nslab;  /* wave-uniform */
           const int k0 = sl * kPipeK;
-          if (more) GEL_PIPE_ROWS(sl + 1, (sl + 1) & 1);    // in flight while this slab multiplies
-          int p0 = xoff[0] + bo, p1 = xoff[1] + bo, p2 = xoff[2] + bo;   // running operand addresses (not 24 hoisted ones)
+          if (more) GEL_PIPE_ROWS(sl + 1, (sl + 1) & 1);  /* in flight while this slab multiplies */
+          int p0 = xoff[0] + bo, p1 = xoff[1] + bo, p2 = xoff[2] + bo;  /* running operand addresses (not 24 hoisted ones) */
 #pragma unroll
           for (int pr = 0; pr < kPairs; pr++) {
-            // this pair's refill was the pr-th of the previous slab: behind it in the queue are that slab's later refills
-            // (kPairs - 1 - pr), this slab's three row pieces and its earlier refills (pr) -- or, in the last slab, only the former
+            /* this pair's refill was the pr-th of the previous slab: behind it in the queue are that slab's later refills */
+            /* (kPairs - 1 - pr), this slab's three row pieces and its earlier refills (pr) -- or, in the last slab, only the former */
             if (more) GEL_PIPE_WAIT(kPairs + 2); else GEL_PIPE_WAIT(kPairs - 1 - pr);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
               const int ks = 2 * pr + h;
-              if (k0 + ks < ksteps) {                        // wave-uniform
+              if (k0 + ks < ksteps) {  /* wave-uniform */
                 const double a = ring[64 * ks];
-                const double bl0 = regions[p0], bl1 = regions[p1], bl2 = regions[p2];
+                const double bl0 = regions[p0], bl1 = regions[p1];
                 acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl0, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl2, acc[2], 0, 0, 0);
+                if (!h7) {
+                  const double bl2 = regions[p2];
+                  acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl2, acc[2], 0, 0, 0);
+                }
               }
               p0 += 4 * xstr[0]; p1 += 4 * xstr[1]; p2 += 4 * xstr[2];
-              asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));       // keep them running
+              asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));  /* keep them running */
             }
             if (more) {
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the pair's slots have been read
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* the pair's slots have been read */
               GEL_PIPE_A(pr, k0 + kPipeK + 2 * pr);
             }
           }
           {
-            const int ol = own - sl * kPipeRows;          // the node's own state row, if it lies in this slab
+            const int ol = own - sl * kPipeRows;  /* the node's own state row, if it lies in this slab */
             if (ol >= 0 && ol < kPipeRows) {
               const lds_double* img = wave_lds + bo;
               me = img[ol];
@@ -738,13 +788,13 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
               for (int c = 0; c < 4; c++) q[c] = img[kBQ + 4 * ol + c];
             }
           }
-          if (n >= sl * kPipeRows && n < (sl + 1) * kPipeRows)      // wave-uniform: the tail row lies in this slab's image
-            GEL_DX_TAIL_ACC(regions[xoff[ct] + bo + (n - sl * kPipeRows - kq) * xstr[ct]]);
+          if (n >= sl * kPipeRows && n < (sl + 1) * kPipeRows)  /* wave-uniform: the tail row lies in this slab's image */
+            GEL_DX_TAIL_ACC(h7 ? 2 : 3, regions[xoff[ct] + bo + (n - sl * kPipeRows - kq) * xstr[ct]]);
           if (more) {
-            GEL_PIPE_WAIT(kPairs);                         // the next slab's rows have landed (behind them: this slab's refills)
+            GEL_PIPE_WAIT(kPairs);  /* the next slab's rows have landed (behind them: this slab's refills) */
             if (!tail1 && sl + 2 == nslab && lane < 3) {
-              // rows past n of the last k-step multiply columns of D that hold zeros: they must not hold another phase's numbers
-              // (a NaN there would reach this phase's rows)
+              /* rows past n of the last k-step multiply columns of D that hold zeros: they must not hold another phase's numbers */
+              /* (a NaN there would reach this phase's rows) */
               const int rz = n + 1 + lane - (sl + 1) * kPipeRows;
               if (rz < kPipeRows && n + 1 + lane < 4 * ksteps) {
                 lds_double* img = wave_lds + ((sl + 1) & 1) * kPipeBuf;
@@ -757,7 +807,7 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
             }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();                     // slab sl is consumed everywhere, slab sl + 1 is in place
+          __builtin_amdgcn_s_barrier();  /* slab sl is consumed everywhere, slab sl + 1 is in place */
         }
 #undef GEL_PIPE_ROWS
 #undef GEL_PIPE_A
@@ -766,8 +816,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
           const int c = 16 * ct + c16;
-          const int vb = c / 11, col = c - 11 * vb;
-          if (c < 44) {
+          const int vb = h7 ? c / 7 : c / 11, col = c - ncv * vb;
+          if (c < ncols && (ct < 2 || !h7)) {
 #pragma unroll
             for (int i = 0; i < 4; i++) wg_lds[vb * kWL + (16 * wv + kq + 4 * i) * 11 + col] = acc[ct][i];
           }

@@ -35,12 +35,12 @@ GEL_DEV Tables table_view(const double* base, int Kw, int Kc) {
 // Tables longer than the workgroup fall back to the loop at the commit.
 GEL_DEV double stage_tables_issue(const ProblemDev& P) {
   const int ntab = table_doubles(P.Kw, P.Kc);
-  return ((int)threadIdx.x < ntab) ? P.tables[threadIdx.x] : 0.0;
+  return P.tables[min((int)threadIdx.x, ntab - 1)];   // no branch around the load (a block boundary the argument fetches behind it would not cross)
 }
 GEL_DEV void stage_tables_commit(const ProblemDev& P, double* lds, double mine) {
   const int ntab = table_doubles(P.Kw, P.Kc);
   if ((int)threadIdx.x < ntab) lds[threadIdx.x] = mine;
-  for (int i = threadIdx.x + blockDim.x; i < ntab; i += blockDim.x) lds[i] = P.tables[i];
+  for (int i = threadIdx.x + kBlock; i < ntab; i += kBlock) lds[i] = P.tables[i];   // (cooperative forms only: kBlock threads -- no look at the dispatch packet)
 }
 GEL_DEV Tables stage_tables(const ProblemDev& P, double* lds, bool sync = true) {
   const int ntab = table_doubles(P.Kw, P.Kc);
