@@ -121,8 +121,6 @@ struct ProblemDev {
   int32_t park_off;          // first double of the per-lane LDS park (after the staged tables)
   int32_t vmajor;            // cooperative launches in vector-group major, XCD-aware order (every phase one chunk)
   int32_t fd_recompute;      // GEL_FLAG_FD_RECOMPUTE: every finite-difference sweep re-runs the reference's chain
-  int32_t grid3d;            // cooperative launches (set by the launcher): the grid's coordinates are (vector group, work item) /
-                             // (XCD, work item, block of eight groups); 0: a linear grid (dimensions past the y / z limits)
   int64_t shard_width;       // split form, packed unit-shard output (gel_eval_shard_packed_device): doubles per vector in a rank's
                              // slice of the exchange buffer; 0: the ordinary res / jvar layouts
   const int64_t* unit_base;  // packed output: first double of every unit's block inside its rank's per-vector block [4 * work items]

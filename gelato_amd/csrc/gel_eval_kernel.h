@@ -98,9 +98,6 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #endif
 
 
-#ifndef GEL_GRID3D
-#define GEL_GRID3D 1  // cooperative forms: work item and vector group from the workgroup's coordinates (gel_kernels.hip launch_coop)
-#endif
 #ifndef GEL_FRONT_BATCH
 #define GEL_FRONT_BATCH 1  // cooperative forms: the kernel arguments of the walk to the phase record in one round trip, one chunk-record fetch
 #endif
@@ -149,10 +146,10 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   // asked for, in front of every wavefront's first request to HBM.  One asm statement that wants them all in scalar registers
   // makes them one round trip (in-process A/B: -0.25 % mixed-6x64, -0.45 % 3 x 32 residual-only: such a round trip is a hit in the
   // scalar cache, 100-200 cycles; fetching the scalars of the LATER stages here as well costs registers and was not kept).
-  int fB = B, f_chunk0 = P.chunk0, f_vmajor = P.vmajor, f_nchunks = P.nchunks, f_grid3d = P.grid3d;
+  int fB = B, f_chunk0 = P.chunk0, f_vmajor = P.vmajor, f_nchunks = P.nchunks;
   const int4* f_chunks = P.chunks;
   const PhaseDev* f_phases = P.phases;
-  if (GEL_FRONT_BATCH && MFMA && !SPLIT) asm volatile("" : "+s"(fB), "+s"(f_chunk0), "+s"(f_vmajor), "+s"(f_nchunks), "+s"(f_chunks), "+s"(f_phases), "+s"(f_grid3d));
+  if (GEL_FRONT_BATCH && MFMA && !SPLIT) asm volatile("" : "+s"(fB), "+s"(f_chunk0), "+s"(f_vmajor), "+s"(f_nchunks), "+s"(f_chunks), "+s"(f_phases));
   const int park_off = P.park_off;
   // the cooperative forms meet at a barrier (operand image / hand-over) before any table lookup: no barrier of its own
   constexpr bool kSplitStage = MFMA && !SPLIT;   // cooperative forms: table entry requested now, written before their first barrier
@@ -201,17 +198,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
   bool ck_same = false;   // COOP: ck_it is this workgroup's record
   if (COOP) {
     const unsigned p = vblk, nb = (unsigned)nb4;
-    // GEL_GRID3D: the launch's grid is (vector groups, work items) -- vector-group major: (8 XCDs, work items, blocks of eight groups)
-    // -- in the order the linear form walks, so that the work item and the group are the workgroup's coordinates instead of a
-    // quotient and a remainder formed by every wavefront (a reciprocal on the vector unit, its way to the scalar unit, twenty
-    // scalar instructions: in front of the chunk record's fetch)
-    unsigned it, r;
-    if (GEL_GRID3D && f_grid3d) {
-      it = blockIdx.y; r = blockIdx.x;
-      if (f_vmajor) { r = blockIdx.z * 8u + blockIdx.x; if (r >= nb) return; }
-    } else if (!f_vmajor) {
-      it = p / nb; r = p - it * nb;
-    } else {
+    unsigned it = p / nb, r = p - it * nb;
+    if (f_vmajor) {
       // Vector-group major, XCD aware (meshes whose phases all have at most 32 nodes): the work items of ONE group of vectors run
       // as consecutive workgroups of ONE XCD (workgroup p lands on XCD p % 8), so the 128-byte lines that neighbouring phases'
       // state rows share in x -- and the partial lines of their residual rows -- meet in that XCD's L2 instead of being

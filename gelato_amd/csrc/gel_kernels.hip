@@ -1235,15 +1235,9 @@ template <bool JAC, bool PACK, bool LONGP, bool NTS = true>
 static void launch_coop(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {
   const unsigned nb = (unsigned)((B + (PACK ? 7 : 3)) / (PACK ? 8 : 4));
   // vector-group major order deals the groups to the eight XCDs in blocks of eight (short last block: idle workgroups leave at once)
-  // the grid's coordinates ARE (vector group, work item) -- vector-group major: (XCD, work item, block of eight groups) --: the x index
-  // runs fastest in dispatch order, which is the order the linear form walked (GEL_GRID3D, gel_eval_kernel.h)
-  const unsigned nblk8 = (nb + 7u) / 8u;
-  ProblemDev Q = P;
-  Q.grid3d = (GEL_GRID3D && (unsigned)P.nchunks <= 65535u && (!P.vmajor || nblk8 <= 65535u)) ? 1 : 0;
-  const dim3 grid = Q.grid3d ? (P.vmajor ? dim3(8u, (unsigned)P.nchunks, nblk8) : dim3(nb, (unsigned)P.nchunks))
-                             : dim3(P.vmajor ? (unsigned)P.nchunks * 8u * nblk8 : (unsigned)P.nchunks * nb);
+  const unsigned grid = P.vmajor ? (unsigned)P.nchunks * 8u * ((nb + 7u) / 8u) : (unsigned)P.nchunks * nb;
   const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(JAC, true, PACK, false, LONGP) * (kBlock / 64));
-  hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK, LONGP, NTS>), grid, dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
+  hipLaunchKernelGGL((eval_kernel<JAC, true, false, PACK, LONGP, NTS>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
 }
 
 hipError_t launch_eval(const ProblemDev& P, int B, const double* d_x, double* d_res, double* d_jvar, hipStream_t s) {

@@ -21,13 +21,9 @@ hipError_t launch_eval_aero(const ProblemDev& P, int B, const double* d_x, doubl
   if (!eval_aero_fusable(P, B) || !P.aero_ph || !P.aero_out || !d_res || !d_jvar) return hipErrorInvalidValue;
   // grid and LDS as launch_coop() of gel_kernels.hip (one vector per wavefront, four per workgroup)
   const unsigned nb = (unsigned)((B + 3) / 4);
-  const unsigned nblk8 = (nb + 7u) / 8u;
-  ProblemDev Q = P;
-  Q.grid3d = (GEL_GRID3D && (unsigned)P.nchunks <= 65535u && (!P.vmajor || nblk8 <= 65535u)) ? 1 : 0;
-  const dim3 grid = Q.grid3d ? (P.vmajor ? dim3(8u, (unsigned)P.nchunks, nblk8) : dim3(nb, (unsigned)P.nchunks))
-                             : dim3(P.vmajor ? (unsigned)P.nchunks * 8u * nblk8 : (unsigned)P.nchunks * nb);
+  const unsigned grid = P.vmajor ? (unsigned)P.nchunks * 8u * ((nb + 7u) / 8u) : (unsigned)P.nchunks * nb;
   const size_t lds = sizeof(double) * ((size_t)P.park_off + (size_t)wave_lds_doubles(true, true, false, false, true) * (kBlock / 64));
-  hipLaunchKernelGGL((eval_kernel<true, true, false, false, true, true, true>), grid, dim3(kBlock), lds, s, Q, B, d_x, d_res, d_jvar);
+  hipLaunchKernelGGL((eval_kernel<true, true, false, false, true, true, true>), dim3(grid), dim3(kBlock), lds, s, P, B, d_x, d_res, d_jvar);
   return hipGetLastError();
 }
 
