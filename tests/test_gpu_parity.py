@@ -1330,6 +1330,28 @@ def test_long_phases_slab_staged_product(nn):
         assert rc == 0 and np.array_equal(r2, res)
 
 
+@pytest.mark.parametrize("nn,hold", [((64, 63, 66), (1, 1, 0)), ((70, 128, 9), (1, 1, 1)), ((33, 67, 101), (0, 1, 1)), ((64,), (1,))])
+def test_hold_phases_form_the_product_without_the_quaternion_columns(nn, hold):
+    """Hold-type phases (lib/con_dynamics.py:521-522: quaternion rows q[1:] - q[0]) never read the quaternion columns of D.X; the
+    cooperative form packs their vectors seven columns each and multiplies two column tiles instead of three (one-slab form and
+    slab loop, last state row on the vector unit or in a k-step of its own).  The columns that are formed keep their bits: against
+    the oracle, and the same vector inside a batch against the latency form (which multiplies all eleven columns)."""
+    import states
+    prob, x = states.long_state(nn)
+    prob["attitude_hold"] = np.array(hold, dtype=np.int32)
+    E, P = make_pair(prob)
+    res1, vals1 = check_against_oracle(E, P, x, "hold-%s" % (nn,), prob=prob)
+    for B in (260, 515):
+        X = np.tile(x, (B, 1))
+        X[B // 2] *= 1.0 + 1e-9
+        res, jv, rc = E.eval_batch(X)
+        assert rc == 0 and E.launch_info(B)[2] == 0                   # cooperative form, not the split latency form
+        assert np.array_equal(res[B - 1], res1) and np.array_equal(E.expand(jv[B - 1]), vals1)
+        assert np.array_equal(res[0], res1) and not np.array_equal(res[B // 2], res1)
+        r2, _, rc = E.eval_batch(X, want_jac=False)
+        assert rc == 0 and np.array_equal(r2, res)
+
+
 @pytest.mark.parametrize("nn", [(70, 5), (69, 9, 4), (71, 3)])
 def test_long_phase_rows_do_not_see_the_next_phase(nn):
     """The image of a long phase's last slab holds rows past the phase -- the next phase's first state rows, as they lie in x.  The
