@@ -523,8 +523,8 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
         // PACK: [32 x (n+1)] . [(n+1) x 88]: row tiles 0 and 1 only, six column tiles; wavefront w forms row tile w & 1 for
         // column tiles 3 (w >> 1) .. + 2; vector v's image lies in wavefront v >> 1's region, half v & 1.
         // Hold-type phases (attitude hold / vertical: quaternion rows q[1:] - q[0], lib/con_dynamics.py:521-522) never read the
-        // quaternion columns of D.X: their vectors are packed seven columns each (mass | position | velocity) -- 28 (PACK: 56)
-        // columns in TWO column tiles per wavefront instead of 44 (88) in three, a third of the phase's matrix instructions less.
+        // quaternion columns of D.X: their vectors are packed seven columns each (mass | position | velocity) -- 28 columns in TWO
+        // column tiles per wavefront instead of 44 in three, a third of the phase's matrix instructions less (one vector per wavefront only).
         // A column's sums do not depend on its neighbours in the tile: the columns that are formed keep their bits.
         const bool h7 = GEL_DX_HOLD7 && !PACK && ph.hold;   // wave-uniform (one work item per workgroup); PACK: not taken (3 x 32 residual-only +1.1 % with it)
         const int ncv = h7 ? 7 : 11;               // columns per vector
