@@ -282,7 +282,9 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
                            // round trip IN FRONT of the requests for the state rows, the very thing the comment above is about
 #endif
   int sec_ld = sec;
-  if (GEL_KNOT_VLOAD && JAC) asm volatile("" : "+v"(sec_ld));   // (the residual-only forms have the scalar registers to let the pair wait with the others)
+  // (the residual-only forms have the scalar registers to let the pair wait with the others; the latency form reads x from pinned
+  // host memory, where the pair as a vector load cost a one-vector evaluation with derivatives 2.5 us: 31.6-34.3 -> 36.2-37.1)
+  if (GEL_KNOT_VLOAD && JAC && !SPLIT) asm volatile("" : "+v"(sec_ld));
   const double to_ld = xt[sec_ld], tf_ld = xt[sec_ld + 1];
   double to = 0.0, tf = 0.0, fds = 0.0, fdt = 0.0;
   const double dx = P.dx, ut = P.ut;
