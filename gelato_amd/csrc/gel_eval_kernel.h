@@ -98,6 +98,12 @@ typedef double gel_double4 __attribute__((ext_vector_type(4)));
 #endif
 
 
+#ifndef GEL_XCD_RANGES
+#define GEL_XCD_RANGES 1   // cooperative launches, work-item major order: every XCD takes contiguous runs of vector groups
+#endif
+#ifndef GEL_XCD_BLOCK
+#define GEL_XCD_BLOCK 0    // groups per run (a power of two), 0: an eighth of the batch
+#endif
 #ifndef GEL_FRONT_BATCH
 #define GEL_FRONT_BATCH 1  // cooperative forms: the kernel arguments of the walk to the phase record in one round trip, one chunk-record fetch
 #endif
@@ -222,6 +228,20 @@ __device__ __forceinline__ void eval_body(const ProblemDev P, int B, const doubl
       const unsigned m = min(8u, nb - blk * 8);        // vector groups in this block of eight (the last one may be short)
       c = rem / m;
       bg = blk * 8 + (rem - c * m);
+    }
+    // XCD-contiguous vector groups: workgroup p runs on XCD p % 8, so with the groups dealt in dispatch order every XCD touched
+    // every eighth group of the batch -- every page of x / res / jvar that is being worked on, eight times over.  Within a block of
+    // 8 G groups, XCD j instead takes the G consecutive groups j G .. (j + 1) G - 1 (for every work item alike: the same XCD comes
+    // back to the same vectors' rows): each XCD's translations and lines cover an eighth of the pages.  G = GEL_XCD_BLOCK groups,
+    // or a whole eighth of the batch (0: in-process A/B at B = 65536, mixed-6x64 -2.2 %, dense -4.6 %, 12 x 128 -1.0 %; runs of 64 / 512
+    // groups -1.8 / -2.1 %, 0 / -0.7 %); the groups behind the last full block keep the dispatch order.  (Applied to the group index
+    // the order ends with: the chunks of a long phase stay together on their XCD.)
+    if (GEL_XCD_RANGES && !f_vmajor) {   // (the vector-group major order of the small-phase meshes: +1.0 % with it at 3 x 32, left alone)
+      const unsigned G = GEL_XCD_BLOCK ? (unsigned)GEL_XCD_BLOCK : (nb >> 3), blk8 = 8u * G;
+      if (G != 0) {
+        const unsigned bq = bg / blk8, inb = bg - bq * blk8;   // blk8 a power of two when GEL_XCD_BLOCK is one: shifts
+        if ((bq + 1u) * blk8 <= nb) bg = bq * blk8 + (p & 7u) * G + (inb >> 3);
+      }
     }
     q = (int)(it - pos + c);
     ck_same = GEL_FRONT_BATCH && nc <= 1;
