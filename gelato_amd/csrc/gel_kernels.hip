@@ -699,13 +699,23 @@ __device__ __forceinline__ void aero_body(const ProblemDev P, int nnodes, const 
 #ifndef GEL_AERO_MIN_WAVES
 #define GEL_AERO_MIN_WAVES 3
 #endif
+// Workgroup p runs on XCD p % 8: in dispatch order every XCD works on every eighth run of entries, i.e. on every page of x and of the
+// outputs that is in flight.  The workgroup index is permuted so that XCD j takes a contiguous eighth of the launch (as the fused
+// kernel's vector groups, gel_eval_kernel.h GEL_XCD_RANGES); the workgroups behind the last multiple of eight keep their place.
+#ifndef GEL_AERO_XCD_RANGES
+#define GEL_AERO_XCD_RANGES 1
+#endif
+__device__ __forceinline__ unsigned aero_xcd_block(unsigned p, unsigned n) {
+  const unsigned n8 = n >> 3;
+  return (GEL_AERO_XCD_RANGES && p < 8u * n8) ? (p & 7u) * n8 + (p >> 3) : p;
+}
 __global__ __launch_bounds__(64 * kAeroWaves, GEL_AERO_MIN_WAVES) void aero_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
                                                                 int tiles, int B, const double* __restrict__ x, AeroOut O) {
-  aero_body<false>(P, nnodes, nodes, tiles, B, x, O, blockIdx.x);
+  aero_body<false>(P, nnodes, nodes, tiles, B, x, O, aero_xcd_block(blockIdx.x, gridDim.x));
 }
 __global__ __launch_bounds__(64 * kAeroWaves, GEL_AERO_MIN_WAVES) void aero_sm_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
                                                                    int tiles, int B, const double* __restrict__ x, AeroOut O) {
-  aero_body<false, false, true>(P, nnodes, nodes, tiles, B, x, O, blockIdx.x);
+  aero_body<false, false, true>(P, nnodes, nodes, tiles, B, x, O, aero_xcd_block(blockIdx.x, gridDim.x));
 }
 __global__ __launch_bounds__(64 * kAeroWaves, 2) void aero_wide_kernel(ProblemDev P, int nnodes, const AeroNodeDev* __restrict__ nodes,
                                                                 int B, const double* __restrict__ x, AeroOut O) {
